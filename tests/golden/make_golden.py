@@ -1,0 +1,291 @@
+"""Generate the golden fixtures in tests/golden/*.npz from the upstream reference.
+
+Run ONLY in the build container (the reference is mounted at /root/reference):
+
+    python tests/golden/make_golden.py
+
+The fixtures are data: seeded synthetic uint8 frames (inputs) and the arrays the
+reference's own functions return for them (expected outputs).  No reference
+source text is stored.  The reference ships no tests/golden vectors of its own
+ and its test_images are absent from the checkout, so these
+files are the parity pin for the oracle and, through it, for the HIP path.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+from ref_loader import load_reference          # noqa: E402
+from torchpiv_amd import synth                 # noqa: E402
+
+ref = load_reference()
+torch.set_num_threads(8)
+
+
+def t8(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def special_regions(a, b):
+    """An all-black block and a saturated block, in both frames."""
+    a, b = a.clone(), b.clone()
+    H, W = a.shape
+    a[: H // 4, : W // 4] = 0
+    b[: H // 4, : W // 4] = 0
+    a[H // 2: H // 2 + H // 5, W // 2:] = 255
+    b[H // 2: H // 2 + H // 5, W // 2:] = 255
+    return a, b
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ---------------------------------------------------------------- G1 geometry
+def g1_geometry():
+    out = {}
+    cases = []
+    for (H, W) in [(256, 256), (512, 512), (2048, 2048), (4096, 4096), (2000, 3000), (200, 264)]:
+        for (ws, ov) in [(128, 64), (64, 32), (32, 16), (16, 8), (8, 4), (32, 0), (48, 12)]:
+            if ws > H or ws > W:
+                continue
+            fs = ref.get_field_shape((H, W), ws, ov)
+            x, y = ref.get_coordinates((H, W), ws, ov)
+            key = f"{H}_{W}_{ws}_{ov}"
+            cases.append([H, W, ws, ov])
+            out["fs_" + key] = np.asarray(fs)
+            out["x_" + key] = x[0, :].copy()
+            out["y_" + key] = y[:, 0].copy()
+    out["cases"] = np.array(cases)
+    save("g1_geometry", **out)
+
+
+# ------------------------------------------------------------------ G3 pass 1
+P1_CASES = [
+    # name, H, W, ws, ov, kind, noise, special, index
+    ("uniform", 256, 256, 32, 16, "uniform", 0.0, False, 0),
+    ("shear_noise", 200, 264, 32, 16, "shear", 3.0, False, 1),
+    ("vortex64", 256, 320, 64, 32, "vortex", 0.0, False, 2),
+    ("special", 192, 256, 32, 16, "wavy", 2.0, True, 3),
+    ("ws16", 128, 160, 16, 8, "uniform", 1.0, False, 4),
+    ("ws8", 64, 96, 8, 4, "zero", 1.0, False, 5),
+    ("ws128", 384, 512, 128, 64, "wavy", 0.0, False, 6),
+    ("ov0", 160, 192, 32, 0, "wavy", 3.0, False, 7),
+]
+
+
+def make_frames(H, W, kind, noise, special, index):
+    a, b = synth.make_pair(H, W, index, kind=kind, noise=noise)
+    if special:
+        a, b = special_regions(a, b)
+    return a, b
+
+
+def g3_pass1():
+    out = {}
+    names = []
+    for (name, H, W, ws, ov, kind, noise, special, index) in P1_CASES:
+        a, b = make_frames(H, W, kind, noise, special, index)
+        u, v, x, y, mask = ref.extended_search_area_piv(a, b, window_size=ws, overlap=ov, validate=True)
+        names.append(name)
+        out[name + "_a"] = a.numpy()
+        out[name + "_b"] = b.numpy()
+        out[name + "_cfg"] = np.array([ws, ov])
+        out[name + "_u"], out[name + "_v"], out[name + "_mask"] = u, v, mask
+        print(f"  pass1 {name}: grid {u.shape}, invalid {int(mask.sum())}, |u|max {np.abs(u).max():.3f}")
+    out["names"] = np.array(names)
+    save("g3_pass1", **out)
+
+
+# ---------------------------------------------------------------- G4 multipass
+MP_CASES = [
+    # name, H, W, ws, ov, passes, kind, noise, special, index
+    ("wavy64x2", 256, 320, 64, 32, 2, "wavy", 0.0, False, 10),
+    ("vortex32x3", 264, 200, 32, 16, 3, "vortex", 2.0, False, 11),
+    ("special32x2", 192, 256, 32, 16, 2, "wavy", 2.0, True, 12),
+    ("shear128x2", 512, 640, 128, 64, 2, "shear", 1.0, False, 13),
+    ("noisy64x3", 320, 256, 64, 32, 3, "wavy", 12.0, False, 14),
+]
+
+
+def g4_multipass():
+    out = {}
+    names = []
+    for (name, H, W, ws, ov, n_pass, kind, noise, special, index) in MP_CASES:
+        a, b = make_frames(H, W, kind, noise, special, index)
+        names.append(name)
+        out[name + "_a"] = a.numpy()
+        out[name + "_b"] = b.numpy()
+        out[name + "_cfg"] = np.array([ws, ov, n_pass])
+        for mode in ("DWS", "CWS"):
+            u, v, x, y, val = ref.extended_search_area_piv(a, b, window_size=ws, overlap=ov, validate=True)
+            out[f"{name}_{mode}_p0_u"], out[f"{name}_{mode}_p0_v"], out[f"{name}_{mode}_p0_val"] = u, v, val
+            w, o = ws, ov
+            for p in range(1, n_pass):
+                w, o = int(w // 2.0), int(o // 2.0)
+                it = ref.IterModMap.functions[mode](a.shape, w, o, torch.device("cpu"))
+                u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
+                out[f"{name}_{mode}_p{p}_u"], out[f"{name}_{mode}_p{p}_v"] = u.copy(), v.copy()
+                out[f"{name}_{mode}_p{p}_val"] = val.copy()
+                print(f"\n  {name} {mode} pass {p}: grid {u.shape} invalid {int(val.sum())}")
+    out["names"] = np.array(names)
+    save("g4_multipass", **out)
+
+
+# ---------------------------------------------------------------- G5 generator
+def g5_generator():
+    """Full OfflinePIV generator on a folder of 8-bit BMPs (decoded by the stub
+    cv2.imdecode = PIL 'L'), including pairs that the reference silently drops."""
+    from PIL import Image
+    out = {}
+    H, W = 192, 256
+    specs = [  # (kind, noise, special) per pair; clean pairs have no invalid vector => dropped
+        ("uniform", 0.0, False),
+        ("wavy", 2.0, True),
+        ("vortex", 4.0, True),
+        ("zero", 0.0, False),
+    ]
+    with tempfile.TemporaryDirectory() as d:
+        frames = []
+        for i, (kind, noise, special) in enumerate(specs):
+            a, b = make_frames(H, W, kind, noise, special, 20 + i)
+            frames.append((a.numpy(), b.numpy()))
+            # names chosen so that natural sort != lexicographic sort
+            Image.fromarray(a.numpy(), "L").save(os.path.join(d, f"image{8 + i}_a.bmp"))
+            Image.fromarray(b.numpy(), "L").save(os.path.join(d, f"image{8 + i}_b.bmp"))
+        out["frames_a"] = np.stack([f[0] for f in frames])
+        out["frames_b"] = np.stack([f[1] for f in frames])
+        runs = [
+            ("r1", dict(wind_size=32, overlap=16, multipass=1, multipass_mode="CWS", dt=1, scale=1.0)),
+            ("r2", dict(wind_size=64, overlap=32, multipass=2, multipass_mode="CWS", dt=2, scale=0.5)),
+            ("r3", dict(wind_size=64, overlap=32, multipass=2, multipass_mode="DWS", dt=1, scale=1.0)),
+            ("r4", dict(wind_size=32, overlap=16, multipass=3, multipass_mode="CWS", dt=1, scale=1.0)),
+        ]
+        for rname, kw in runs:
+            gen = ref.OfflinePIV(folder=d, device="cpu", file_fmt="bmp", multipass_scale=2.0,
+                                 folder_mode="pairs", **kw)
+            res = list(gen())
+            out[rname + "_count"] = np.array([len(gen), len(res)])
+            out[rname + "_kw"] = np.array([kw["wind_size"], kw["overlap"], kw["multipass"],
+                                           0 if kw["multipass_mode"] == "DWS" else 1, kw["dt"]])
+            out[rname + "_scale"] = np.array([kw["scale"]])
+            for j, (x, y, u, v) in enumerate(res):
+                out[f"{rname}_{j}_x"], out[f"{rname}_{j}_y"] = x, y
+                out[f"{rname}_{j}_u"], out[f"{rname}_{j}_v"] = u, v
+            print(f"\n  generator {rname}: {len(res)} of {len(gen)} pairs yielded")
+        # sequential mode pairing (names only) and natural sort
+        seq = ref.PIVDataset(d, "bmp", "sequential")
+        out["seq_pairs"] = np.array([[os.path.basename(p[0]), os.path.basename(p[1])] for p in seq.img_pairs])
+        prs = ref.PIVDataset(d, "bmp", "pairs")
+        out["pairs_pairs"] = np.array([[os.path.basename(p[0]), os.path.basename(p[1])] for p in prs.img_pairs])
+    save("g5_generator", **out)
+
+
+# --------------------------------------------------------------------- G6 KATs
+def g6_kats():
+    out = {}
+    rng = np.random.default_rng(7)
+    # (1) correlation_to_displacement on hand-made maps, float32 and float64
+    maps = []
+    k = 16
+    yy, xx = np.mgrid[0:k, 0:k]
+    maps.append(100 * np.exp(-((xx - 6.8) ** 2 + (yy - 9.3) ** 2) / 4.0))            # interior
+    m = np.ones((k, k)); m[0, 0] = 100; m[0, 1] = 40; m[1, 0] = 30; maps.append(m)    # peak at flat 0
+    m = np.ones((k, k)); m[15, 15] = 100; m[15, 14] = 40; m[14, 15] = 30; maps.append(m)
+    m = np.ones((k, k)); m[5, 15] = 100; m[6, 0] = 50; m[5, 14] = 20; maps.append(m)  # row-wrap neighbour
+    m = np.ones((k, k)); m[5, 15] = 100; m[6, 0] = 1; m[5, 14] = 20; maps.append(m)
+    m = np.ones((k, k)); m[8, 8] = 100; m[8, 11] = 90; maps.append(m)                 # 2nd peak at dist 3
+    m = np.ones((k, k)); m[8, 8] = 100; m[8, 12] = 90; maps.append(m)                 # dist 4 -> invalid
+    m = np.ones((k, k)); m[8, 8] = 100; m[8, 12] = 80; maps.append(m)                 # 1.25 >= 1.2 valid
+    m = np.ones((k, k)); m[8, 1] = 100; m[7, 14] = 99; m[8, 14] = 98; maps.append(m)  # wrap masks
+    m = np.ones((k, k)); m[3, 3] = 100; m[10, 10] = 100; maps.append(m)               # exact tie
+    maps.append(np.full((k, k), np.nan))                                              # all NaN
+    maps.append(np.full((k, k), 5.0))                                                 # constant
+    m = np.ones((k, k)); m[0, 1] = 100; m[0, 0] = 30; m[0, 2] = 50; maps.append(m)    # m == 1
+    m = np.ones((k, k)); m[15, 14] = 100; m[15, 13] = 30; m[15, 15] = 50; maps.append(m)  # m == kd-2
+    m = np.ones((k, k)); m[1, 0] = 100; m[0, 0] = 30; m[2, 0] = 50; maps.append(m)    # m == k
+    m = np.ones((k, k)); m[14, 15] = 100; m[13, 15] = 30; m[15, 15] = 50; maps.append(m)  # m == k(d-1)-1
+    for _ in range(8):
+        maps.append(rng.random((k, k)) * 10 + 1e-3)
+    maps = np.stack(maps)
+    for dt, nm in ((np.float32, "f32"), (np.float64, "f64")):
+        c = torch.from_numpy(maps.astype(dt).copy())
+        u, v, mask = ref.correlation_to_displacement(c, maps.shape[0], 1, validate=True)
+        out[f"c2d16_{nm}_u"], out[f"c2d16_{nm}_v"], out[f"c2d16_{nm}_mask"] = u, v, mask
+    out["c2d16_maps"] = maps
+    # 8x8 maps
+    maps8 = []
+    m = np.ones((8, 8)); m[4, 4] = 100; m[0, 0] = 95; maps8.append(m)
+    m = np.ones((8, 8)); m[4, 4] = 100; m[0, 7] = 95; maps8.append(m)
+    m = np.ones((8, 8)); m[4, 4] = 100; m[4, 5] = 60; m[3, 4] = 70; maps8.append(m)
+    for _ in range(5):
+        maps8.append(rng.random((8, 8)) * 10 + 1e-3)
+    maps8 = np.stack(maps8)
+    c = torch.from_numpy(maps8.astype(np.float32).copy())
+    u, v, mask = ref.correlation_to_displacement(c, maps8.shape[0], 1, validate=True)
+    out["c2d8_maps"], out["c2d8_u"], out["c2d8_v"], out["c2d8_mask"] = maps8, u, v, mask
+    # non-square map (d != k) to pin which of d/k each formula uses
+    mapsr = rng.random((6, 8, 16)) * 10 + 1e-3
+    c = torch.from_numpy(mapsr.astype(np.float64).copy())
+    u, v, mask = ref.correlation_to_displacement(c, 6, 1, validate=True)
+    out["c2dr_maps"], out["c2dr_u"], out["c2dr_v"], out["c2dr_mask"] = mapsr, u, v, mask
+
+    # (2) window shifts on a small textured frame
+    H, W, ws, ov = 40, 56, 8, 4
+    frame = (rng.integers(0, 256, size=(H, W))).astype(np.uint8)
+    ft = torch.from_numpy(frame)
+    idx = ref.moving_window_array(torch.arange(H * W, dtype=torch.int64).reshape(H, W), ws, ov)
+    n = idx.shape[0]
+    vx = rng.uniform(-6, 6, n).astype(np.float32)
+    vy = rng.uniform(-6, 6, n).astype(np.float32)
+    # force the quirk cases into the first windows
+    vx[:8] = [0.0, 0.5, 0.0, 1.0, -1.5, 2.0, 0.5, -0.25]
+    vy[:8] = [0.0, 0.5, 0.5, 0.5, 0.0, -3.0, 0.0, 7.75]
+    vx[-3:] = [5.5, 9.25, -9.5]
+    vy[-3:] = [6.5, 8.0, -8.5]
+    cws = ref.biliniar_interpolation_CWS(ft, idx, torch.from_numpy(vx)[:, None, None],
+                                         torch.from_numpy(vy)[:, None, None])
+    ix = np.rint(vx).astype(np.int64)
+    iy = np.rint(vy).astype(np.int64)
+    dws = ref.interpolation_DWS(ft, idx, torch.from_numpy(ix)[:, None, None],
+                                torch.from_numpy(iy)[:, None, None])
+    out["shift_frame"] = frame
+    out["shift_cfg"] = np.array([ws, ov])
+    out["shift_vx"], out["shift_vy"] = vx, vy
+    out["shift_ix"], out["shift_iy"] = ix, iy
+    out["shift_cws"] = cws.numpy()
+    out["shift_dws"] = dws.numpy()
+    # (3) correalte_fft on random small windows (uint8 -> float32, and float64)
+    wa = rng.integers(0, 256, size=(5, 16, 16)).astype(np.uint8)
+    wb = rng.integers(0, 256, size=(5, 16, 16)).astype(np.uint8)
+    out["xc_a"], out["xc_b"] = wa, wb
+    out["xc_u8"] = ref.correalte_fft(torch.from_numpy(wa), torch.from_numpy(wb)).numpy()
+    out["xc_f64"] = ref.correalte_fft(torch.from_numpy(wa.astype(np.float64)),
+                                      torch.from_numpy(wb.astype(np.float64))).numpy()
+    # (4) post-validation helpers
+    f = rng.random((9, 11))
+    holes = [(0, 3), (0, 4), (8, 0), (4, 10), (3, 3), (3, 4), (6, 7), (0, 0)]
+    g = f.copy()
+    for (r, c_) in holes:
+        g[r, c_] = np.nan
+    out["pv_in"] = g.copy()
+    gb = ref.interpolate_boarders(g.copy())
+    out["pv_borders"] = gb.copy()
+    out["pv_filled"] = ref.fillMissingValues(gb.copy())
+    save("g6_kats", **out)
+
+
+if __name__ == "__main__":
+    g1_geometry()
+    g3_pass1()
+    g4_multipass()
+    g5_generator()
+    g6_kats()
