@@ -1,0 +1,137 @@
+/* torchpiv_hip.h -- C ABI of the MI355X-native PIV cross-correlation engine.
+ *
+ * The reference (NikNazarov/TorchPIV) has no FFI layer: its boundary is the Python
+ * class OfflinePIV (src/torchPIV/PIVbackend.py:824-903) calling pure functions on
+ * torch tensors.  This library replaces the device part of those functions; the
+ * Python host (torchpiv_amd/backend.py) binds it with ctypes and keeps the
+ * reference's class / function signatures.  Each entry point cites the reference
+ * code it replaces (B: = src/torchPIV/PIVbackend.py).
+ *
+ * Conventions
+ *   - every pointer named *_dev is device memory on the CURRENT HIP device, owned by
+ *     the caller (PyTorch-ROCm tensors: tensor.data_ptr()); nothing is allocated or
+ *     freed by the run functions, which only enqueue work on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream) and return at once;
+ *   - fields are row-major [batch, n_rows, n_cols]; frames are uint8 [batch, H, W];
+ *   - return value: TPIV_OK or an error code; tpiv_last_error() gives the message
+ *     of the calling thread's last failure.  Nothing is thrown across the ABI.
+ */
+#ifndef TORCHPIV_HIP_H
+#define TORCHPIV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPIV_VERSION 1
+
+enum tpiv_status {
+    TPIV_OK = 0,
+    TPIV_EINVAL = 1,  /* bad window / overlap / shape: the reference raises ValueError (B:503-507) */
+    TPIV_EKEY = 2,    /* unknown multipass mode: the reference raises KeyError (B:850) */
+    TPIV_EHIP = 3,    /* a HIP runtime call failed */
+    TPIV_ENOMEM = 4,
+    TPIV_EUNSUPPORTED = 5 /* valid for the reference but outside what the kernels cover */
+};
+
+enum tpiv_mode {
+    TPIV_MODE_DWS = 1, /* discrete window shift,  piv_iteration_DWS  B:744-812 */
+    TPIV_MODE_CWS = 2  /* continuous window shift, piv_iteration_CWS B:677-740 */
+};
+
+typedef struct tpiv_plan tpiv_plan;
+
+int tpiv_version(void);
+const char* tpiv_last_error(void);
+
+/* ---- host-side geometry (no GPU needed) -------------------------------------- */
+
+/* get_field_shape, B:425-456: (size - ws)//(ws - ov) + 1 per axis. */
+int tpiv_field_shape(int H, int W, int ws, int ov, int* n_rows, int* n_cols);
+
+/* get_coordinates, B:522-597: window-centre coordinates along each axis
+ * (x: n_cols values, y: n_rows values); the reference returns their meshgrid. */
+int tpiv_coordinates(int H, int W, int ws, int ov, double* x, double* y);
+
+/* The predictor operator of scipy.interpolate.RectBivariateSpline(kx=ky=3, s=0)
+ * as the reference calls it (B:700-704, 710-711, 769-773, 777-778): row-major
+ * A[nf, nc] such that fine = A_y * coarse * A_x^T.  1-D not-a-knot cubic spline
+ * interpolation from the nc coarse coordinates xc to the nf fine coordinates xf,
+ * evaluation points clamped to [xc[0], xc[nc-1]] (FITPACK does not extrapolate).
+ * Needs nc >= 4 (as scipy does). */
+int tpiv_spline_matrix(int nc, const double* xc, int nf, const double* xf, double* A);
+
+/* ---- function-level seam (device pointers) ---------------------------------- */
+
+/* Tensor part of extended_search_area_piv(frame_a, frame_b, window_size, overlap,
+ * validate=True, validation_ratio), B:459-520 (+ correalte_fft B:249-257,
+ * correlation_to_displacement B:360-422, peak2peak_secondpeak B:346-358).
+ * Outputs: u, v float64 and invalid uint8 (1 = peak ratio < val_ratio). */
+int tpiv_pass1(const uint8_t* a_dev, const uint8_t* b_dev, int batch, int H, int W,
+               int ws, int ov, double val_ratio, int val_win,
+               double* u_dev, double* v_dev, uint8_t* invalid_dev, void* stream);
+
+/* Predictor of one multipass iteration (host-side scipy calls in the reference,
+ * B:700-717 CWS / B:769-790 DWS): spline-upsample u, v and the invalid mask from
+ * the coarse grid [nrc, ncc] to the fine grid [nrf, ncf] with the operators of
+ * tpiv_spline_matrix (Ay [nrf, nrc], Ax [ncf, ncc], device memory), threshold the
+ * mask at 0.5, zero the predictor where invalid and form the window half-shift
+ * (CWS: u0/2 taken before the zeroing; DWS: rint(u0/2) after it).
+ * work_dev: batch*3*nrc*ncf float64 of scratch. */
+int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf,
+                 const double* Ay_dev, const double* Ax_dev,
+                 const double* u_c_dev, const double* v_c_dev, const uint8_t* invalid_c_dev,
+                 double* work_dev, double* u0_dev, double* v0_dev, double* u2_dev, double* v2_dev,
+                 void* stream);
+
+/* Tensor part of piv_iteration_DWS.__call__ (B:791-810, interpolation_DWS B:197-216)
+ * or piv_iteration_CWS.__call__ (B:719-738, biliniar_interpolation_CWS B:147-194):
+ * shift the windows of frame a by -(u2, v2) and of frame b by +(u2, v2), correlate,
+ * find the peak, validate and combine with the predictor
+ * (u = 2*u2 + du, fallback to u0 where (du > u0 and rint(u0) > 0) or invalid).
+ * du_dev / dv_dev (optional, may be NULL) receive the raw displacement of this pass. */
+int tpiv_iter(int mode, const uint8_t* a_dev, const uint8_t* b_dev, int batch, int H, int W,
+              int ws, int ov,
+              const double* u0_dev, const double* v0_dev, const double* u2_dev, const double* v2_dev,
+              double val_ratio, int val_win,
+              double* u_dev, double* v_dev, uint8_t* invalid_dev,
+              double* du_dev, double* dv_dev, void* stream);
+
+/* ---- plan: the whole multipass pipeline of OfflinePIV.__call__ for a batch ---- */
+
+/* Mirrors OfflinePIV.__init__ (B:825-858): pass p > 0 uses ws_p = int(ws_{p-1} // pass_scale),
+ * ov_p = int(ov_{p-1} // pass_scale).  Allocates (on the current device) the spline
+ * operators and the per-pass field workspace for up to max_batch pairs. */
+int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, int mode,
+                     double pass_scale, double val_ratio, int val_win, int max_batch);
+void tpiv_plan_destroy(tpiv_plan* plan);
+int tpiv_plan_n_pass(const tpiv_plan* plan);
+int tpiv_plan_pass_geometry(const tpiv_plan* plan, int pass, int* ws, int* ov, int* n_rows, int* n_cols);
+
+/* Pass 1 and every further pass (B:873-882) for `batch` <= max_batch pairs; the last
+ * pass writes straight into u_dev / v_dev / invalid_dev ([batch, n_rows_last, n_cols_last]). */
+int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a_dev, const uint8_t* b_dev, int batch,
+                  double* u_dev, double* v_dev, uint8_t* invalid_dev, void* stream);
+
+/* Device pointers to the fields pass `pass` (< n_pass - 1) left in the plan's workspace
+ * during the last run (for parity tests of the intermediate passes). */
+int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u_dev, double** v_dev,
+                          uint8_t** invalid_dev);
+
+/* ---- test hook ------------------------------------------------------------------ */
+
+/* Runs one pass like tpiv_pass1 (mode 0) / tpiv_iter (mode DWS/CWS, with u0 = v0 = 0)
+ * and additionally writes the staged windows win_dev [batch, N, 2, ws, ws] float32
+ * (frame a, frame b, after the shift) and the correlation maps corr_dev
+ * [batch, N, ws, ws] float32 (corr - min + 1e-7, fftshift layout). Either may be NULL. */
+int tpiv_debug_pass(int mode, const uint8_t* a_dev, const uint8_t* b_dev, int batch, int H, int W,
+                    int ws, int ov, const double* u2_dev, const double* v2_dev,
+                    double* u_dev, double* v_dev, uint8_t* invalid_dev,
+                    float* win_dev, float* corr_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORCHPIV_HIP_H */

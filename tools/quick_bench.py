@@ -1,0 +1,36 @@
+"""Quick timing of the multipass plan on synthetic frames (development aid; bench.py is the contract)."""
+import argparse, sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torchpiv_amd import engine, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=2048)
+ap.add_argument("--ws", type=int, default=64)
+ap.add_argument("--passes", type=int, default=2)
+ap.add_argument("--mode", default="CWS")
+ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--distinct", type=int, default=2)
+ap.add_argument("--iters", type=int, default=5)
+a = ap.parse_args()
+H = W = a.size
+A0, B0 = synth.make_batch(a.distinct, H, W, device="cuda")
+A = A0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
+B = B0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
+plan = engine.Plan(H, W, a.ws, a.ws // 2, n_pass=a.passes, mode=a.mode, max_batch=a.batch)
+out = plan.run(A, B)
+torch.cuda.synchronize()
+for p in range(a.passes):
+    print("pass", p, plan.geometry[p])
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.iters + 1)]
+ev[0].record()
+for i in range(a.iters):
+    plan.run(A, B, out=out)
+    ev[i + 1].record()
+torch.cuda.synchronize()
+ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters)]
+t = sorted(ts)[len(ts) // 2]
+print(f"size {H} ws {a.ws} passes {a.passes} {a.mode} batch {a.batch}: {t:.3f} ms/batch, "
+      f"{t / a.batch * 1000:.1f} us/pair, {a.batch / t * 1000:.1f} pairs/s  (all: {[round(x, 2) for x in ts]})")
+u, v, inv = out
+print("invalid frac", inv.float().mean().item(), "u mean", u.mean().item(), "v mean", v.mean().item())

@@ -1,0 +1,85 @@
+"""ctypes binding of libtorchpiv_hip.so (include/torchpiv_hip.h).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded the
+import of this module raises, so a GPU box can never silently run without the HIP path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtorchpiv_hip.so")
+
+OK, EINVAL, EKEY, EHIP, ENOMEM, EUNSUPPORTED = 0, 1, 2, 3, 4, 5
+MODE_DWS, MODE_CWS = 1, 2
+MODES = {"DWS": MODE_DWS, "CWS": MODE_CWS}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C torchpiv_amd/csrc)")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_u8p = C.c_void_p
+_f64p = C.c_void_p
+_f32p = C.c_void_p
+_int = C.c_int
+_dbl = C.c_double
+_vp = C.c_void_p
+
+# every symbol include/torchpiv_hip.h declares
+SIGNATURES = {
+    "tpiv_version": (C.c_int, []),
+    "tpiv_last_error": (C.c_char_p, []),
+    "tpiv_field_shape": (C.c_int, [_int, _int, _int, _int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tpiv_coordinates": (C.c_int, [_int, _int, _int, _int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "tpiv_spline_matrix": (C.c_int, [_int, C.POINTER(C.c_double), _int, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double)]),
+    "tpiv_pass1": (C.c_int, [_u8p, _u8p, _int, _int, _int, _int, _int, _dbl, _int, _f64p, _f64p, _u8p, _vp]),
+    "tpiv_predict": (C.c_int, [_int, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p, _f64p, _u8p,
+                               _f64p, _f64p, _f64p, _f64p, _f64p, _vp]),
+    "tpiv_iter": (C.c_int, [_int, _u8p, _u8p, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p, _f64p,
+                            _dbl, _int, _f64p, _f64p, _u8p, _f64p, _f64p, _vp]),
+    "tpiv_plan_create": (C.c_int, [C.POINTER(C.c_void_p), _int, _int, _int, _int, _int, _int, _dbl, _dbl,
+                                   _int, _int]),
+    "tpiv_plan_destroy": (None, [C.c_void_p]),
+    "tpiv_plan_n_pass": (C.c_int, [C.c_void_p]),
+    "tpiv_plan_pass_geometry": (C.c_int, [C.c_void_p, _int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "tpiv_plan_run": (C.c_int, [C.c_void_p, _u8p, _u8p, _int, _f64p, _f64p, _u8p, _vp]),
+    "tpiv_plan_pass_fields": (C.c_int, [C.c_void_p, _int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p)]),
+    "tpiv_debug_pass": (C.c_int, [_int, _u8p, _u8p, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p,
+                                  _f64p, _u8p, _f32p, _f32p, _vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)        # AttributeError if the library lacks a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(rc: int) -> None:
+    """Map a status code to the exception type the reference raises in that situation."""
+    if rc == OK:
+        return
+    msg = lib.tpiv_last_error().decode("utf-8", "replace")
+    if rc == EINVAL:
+        raise ValueError(msg)
+    if rc == EKEY:
+        raise KeyError(msg)
+    if rc == EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == ENOMEM:
+        raise MemoryError(msg)
+    raise HipError(msg)

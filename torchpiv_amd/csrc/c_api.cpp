@@ -1,0 +1,526 @@
+// C ABI of the PIV engine (include/torchpiv_hip.h): argument checking, geometry,
+// the predictor's spline operators (host, float64) and the multipass plan.
+// Compiled with hipcc as host code; the kernels live in xcorr_ws*.hip / piv_launch.hip.
+#include "../../include/torchpiv_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "piv_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(TPIV_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+bool supported_ws(int ws) { return ws == 8 || ws == 16 || ws == 32 || ws == 64 || ws == 128; }
+
+// B:503-507 argument checks, then what the kernels cover
+int check_window(int H, int W, int ws, int ov, int val_win) {
+    if (ov >= ws) return fail(TPIV_EINVAL, "Overlap has to be smaller than the window_size");
+    if (ws > H || ws > W) return fail(TPIV_EINVAL, "window size cannot be larger than the image");
+    if (ws <= 0 || ov < 0 || H <= 0 || W <= 0) return fail(TPIV_EINVAL, "non-positive size");
+    if (!supported_ws(ws))
+        return fail(TPIV_EUNSUPPORTED, "window size must be one of 8, 16, 32, 64, 128 (got " +
+                                           std::to_string(ws) + ")");
+    if (val_win < 0 || 2 * val_win >= ws)
+        return fail(TPIV_EUNSUPPORTED, "validation half-window must satisfy 2*val_win < window size");
+    if ((long long)H * W >= (1LL << 31)) return fail(TPIV_EUNSUPPORTED, "frame too large");
+    return TPIV_OK;
+}
+
+int n_cu_of_current_device(int* n_cu) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    static thread_local int cached_dev = -1, cached_cu = 0;
+    if (cached_dev != dev) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        cached_dev = dev;
+        cached_cu = prop.multiProcessorCount;
+    }
+    *n_cu = cached_cu;
+    return TPIV_OK;
+}
+
+void field_shape(int H, int W, int ws, int ov, int* nr, int* nc) {
+    *nr = (H - ws) / (ws - ov) + 1;
+    *nc = (W - ws) / (ws - ov) + 1;
+}
+
+// floor division for the (possibly negative) centring shift of B:582-592
+long long floordiv(long long a, long long b) {
+    long long q = a / b, r = a % b;
+    return (r != 0 && ((r < 0) != (b < 0))) ? q - 1 : q;
+}
+
+void coords_1d(int size, int n, int ws, int ov, double* out) {
+    const long long shift = floordiv((long long)size - 1 - ((long long)(n - 1) * (ws - ov) + (ws - 1)), 2);
+    for (int i = 0; i < n; ++i) out[i] = (double)i * (ws - ov) + ws / 2.0 + (double)shift;
+}
+
+// ---- cubic B-spline interpolation operator (FITPACK regrid, s = 0) -------------
+// knots: 4x x[0], x[2..n-3], 4x x[n-1]  (not-a-knot at x[1] and x[n-2])
+struct Bspl {
+    std::vector<long double> t;
+    int n;
+    explicit Bspl(int n_, const double* x) : t(n_ + 4), n(n_) {
+        for (int i = 0; i < 4; ++i) t[i] = x[0];
+        for (int i = 2; i <= n - 3; ++i) t[i + 2] = x[i];
+        for (int i = 0; i < 4; ++i) t[n + i] = x[n - 1];
+    }
+    // span l with t[l] <= xx < t[l+1], 3 <= l <= n-1; the 4 non-zero cubic B-splines
+    // N_{l-3..l}(xx) by the de Boor-Cox recurrence
+    int eval(long double xx, long double h[4]) const {
+        int l = 3;
+        while (l < n - 1 && xx >= t[l + 1]) ++l;
+        long double hh[4];
+        h[0] = 1.0L;
+        for (int j = 1; j <= 3; ++j) {
+            for (int i = 0; i < j; ++i) hh[i] = h[i];
+            h[0] = 0.0L;
+            for (int i = 0; i < j; ++i) {
+                const int li = l + i + 1, lj = li - j;
+                const long double f = hh[i] / (t[li] - t[lj]);
+                h[i] += f * (t[li] - xx);
+                h[i + 1] = f * (xx - t[lj]);
+            }
+        }
+        return l;
+    }
+};
+
+int spline_matrix(int nc, const double* xc, int nf, const double* xf, double* A) {
+    if (nc < 4) return fail(TPIV_EINVAL, "the spline predictor needs at least 4 coarse points per axis");
+    for (int i = 1; i < nc; ++i)
+        if (!(xc[i] > xc[i - 1])) return fail(TPIV_EINVAL, "coarse coordinates must increase strictly");
+    Bspl bs(nc, xc);
+    const int n = nc;
+    // collocation matrix C[i][j] = B_j(x_i): rows have 4 non-zeros at columns l-3..l
+    std::vector<long double> C((size_t)n * n, 0.0L);
+    for (int i = 0; i < n; ++i) {
+        long double h[4];
+        const int l = bs.eval((long double)xc[i], h);
+        for (int k = 0; k < 4; ++k) C[(size_t)i * n + (l - 3 + k)] = h[k];
+    }
+    // Inv = C^-1: banded LU (forward elimination with partial pivoting inside the band,
+    // lower bandwidth <= 3) applied to the identity, then back-substitution (the upper
+    // bandwidth grows to <= 6 through the row swaps).
+    std::vector<long double> Inv((size_t)n * n, 0.0L);
+    for (int i = 0; i < n; ++i) Inv[(size_t)i * n + i] = 1.0L;
+    const int kl = 3, ku = 6;
+    for (int col = 0; col < n; ++col) {
+        int piv = col;
+        long double best = fabsl(C[(size_t)col * n + col]);
+        for (int r = col + 1; r < n && r <= col + kl; ++r) {
+            const long double v = fabsl(C[(size_t)r * n + col]);
+            if (v > best) {
+                best = v;
+                piv = r;
+            }
+        }
+        if (best == 0.0L) return fail(TPIV_EINVAL, "singular spline collocation matrix");
+        if (piv != col) {
+            for (int k = 0; k < n; ++k) {
+                std::swap(C[(size_t)piv * n + k], C[(size_t)col * n + k]);
+                std::swap(Inv[(size_t)piv * n + k], Inv[(size_t)col * n + k]);
+            }
+        }
+        const int k_hi = col + ku + 1 < n ? col + ku + 1 : n;
+        for (int r = col + 1; r < n && r <= col + kl; ++r) {
+            const long double f = C[(size_t)r * n + col] / C[(size_t)col * n + col];
+            if (f == 0.0L) continue;
+            for (int k = col; k < k_hi; ++k) C[(size_t)r * n + k] -= f * C[(size_t)col * n + k];
+            for (int k = 0; k < n; ++k) Inv[(size_t)r * n + k] -= f * Inv[(size_t)col * n + k];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        const int k_hi = i + ku + 1 < n ? i + ku + 1 : n;
+        const long double d = 1.0L / C[(size_t)i * n + i];
+        for (int j = 0; j < n; ++j) {
+            long double acc = Inv[(size_t)i * n + j];
+            for (int k = i + 1; k < k_hi; ++k) acc -= C[(size_t)i * n + k] * Inv[(size_t)k * n + j];
+            Inv[(size_t)i * n + j] = acc * d;
+        }
+    }
+    for (int f = 0; f < nf; ++f) {
+        long double xx = xf[f];
+        if (xx < xc[0]) xx = xc[0];            // FITPACK fpbisp clamps the arguments
+        if (xx > xc[n - 1]) xx = xc[n - 1];
+        long double h[4];
+        const int l = bs.eval(xx, h);
+        for (int j = 0; j < n; ++j) {
+            long double acc = 0.0L;
+            for (int k = 0; k < 4; ++k) acc += h[k] * Inv[(size_t)(l - 3 + k) * n + j];
+            A[(size_t)f * n + j] = (double)acc;
+        }
+    }
+    return TPIV_OK;
+}
+
+struct PassGeo {
+    int ws, ov, n_rows, n_cols;
+    std::vector<double> x, y;
+};
+
+}  // namespace
+
+struct tpiv_plan {
+    int H = 0, W = 0, n_pass = 0, mode = 0, max_batch = 0, val_win = 3, device = 0;
+    double val_ratio = 1.2;
+    std::vector<PassGeo> geo;
+    // device workspace
+    std::vector<double*> u, v;           // per pass (all but the last): [max_batch, N_p]
+    std::vector<uint8_t*> val;
+    std::vector<double*> Ay, Ax;         // per pass p >= 1: operators from pass p-1 to p
+    double *u0 = nullptr, *v0 = nullptr, *u2 = nullptr, *v2 = nullptr, *T = nullptr;
+    std::vector<void*> allocs;
+
+    ~tpiv_plan() {
+        for (void* p : allocs) (void)hipFree(p);
+    }
+    template <typename T_>
+    int alloc(T_** out, size_t count) {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, count * sizeof(T_) + 16);
+        if (e != hipSuccess) return fail(TPIV_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+        allocs.push_back(p);
+        *out = static_cast<T_*>(p);
+        return TPIV_OK;
+    }
+};
+
+extern "C" {
+
+int tpiv_version(void) { return TPIV_VERSION; }
+
+const char* tpiv_last_error(void) { return g_err.c_str(); }
+
+int tpiv_field_shape(int H, int W, int ws, int ov, int* n_rows, int* n_cols) {
+    if (ov >= ws) return fail(TPIV_EINVAL, "Overlap has to be smaller than the window_size");
+    if (ws > H || ws > W) return fail(TPIV_EINVAL, "window size cannot be larger than the image");
+    field_shape(H, W, ws, ov, n_rows, n_cols);
+    return TPIV_OK;
+}
+
+int tpiv_coordinates(int H, int W, int ws, int ov, double* x, double* y) {
+    int nr, nc;
+    int rc = tpiv_field_shape(H, W, ws, ov, &nr, &nc);
+    if (rc) return rc;
+    coords_1d(W, nc, ws, ov, x);
+    coords_1d(H, nr, ws, ov, y);
+    return TPIV_OK;
+}
+
+int tpiv_spline_matrix(int nc, const double* xc, int nf, const double* xf, double* A) {
+    return spline_matrix(nc, xc, nf, xf, A);
+}
+
+int tpiv_pass1(const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws, int ov,
+               double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, void* stream) {
+    int rc = check_window(H, W, ws, ov, val_win);
+    if (rc) return rc;
+    if (batch <= 0) return TPIV_OK;
+    tpiv::PassParams p{};
+    p.A = a;
+    p.B = b;
+    p.batch = batch;
+    p.H = H;
+    p.W = W;
+    p.ws = ws;
+    p.ov = ov;
+    field_shape(H, W, ws, ov, &p.n_rows, &p.n_cols);
+    p.u = u;
+    p.v = v;
+    p.val = invalid;
+    p.val_ratio = val_ratio;
+    p.val_win = val_win;
+    int n_cu;
+    rc = n_cu_of_current_device(&n_cu);
+    if (rc) return rc;
+    HIP_TRY(tpiv::launch_xcorr(p, tpiv::MODE_PASS1, n_cu, (hipStream_t)stream));
+    return TPIV_OK;
+}
+
+int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf, const double* Ay,
+                 const double* Ax, const double* u_c, const double* v_c, const uint8_t* invalid_c,
+                 double* work, double* u0, double* v0, double* u2, double* v2, void* stream) {
+    if (mode != TPIV_MODE_DWS && mode != TPIV_MODE_CWS) return fail(TPIV_EKEY, "unknown multipass mode");
+    if (batch <= 0) return TPIV_OK;
+    tpiv::PredictParams q{};
+    q.batch = batch;
+    q.mode = mode;
+    q.nrc = nrc;
+    q.ncc = ncc;
+    q.nrf = nrf;
+    q.ncf = ncf;
+    q.Ay = Ay;
+    q.Ax = Ax;
+    q.u_c = u_c;
+    q.v_c = v_c;
+    q.val_c = invalid_c;
+    q.T = work;
+    q.u0 = u0;
+    q.v0 = v0;
+    q.u2 = u2;
+    q.v2 = v2;
+    HIP_TRY(tpiv::launch_predict(q, (hipStream_t)stream));
+    return TPIV_OK;
+}
+
+static int run_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
+                    int ov, const double* u0, const double* v0, const double* u2, const double* v2,
+                    double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, double* du,
+                    double* dv, float* dbg_win, float* dbg_corr, void* stream) {
+    if (mode != TPIV_MODE_DWS && mode != TPIV_MODE_CWS) return fail(TPIV_EKEY, "unknown multipass mode");
+    int rc = check_window(H, W, ws, ov, val_win);
+    if (rc) return rc;
+    if (batch <= 0) return TPIV_OK;
+    tpiv::PassParams p{};
+    p.A = a;
+    p.B = b;
+    p.batch = batch;
+    p.H = H;
+    p.W = W;
+    p.ws = ws;
+    p.ov = ov;
+    field_shape(H, W, ws, ov, &p.n_rows, &p.n_cols);
+    p.u0 = u0;
+    p.v0 = v0;
+    p.u2 = u2;
+    p.v2 = v2;
+    p.u = u;
+    p.v = v;
+    p.val = invalid;
+    p.du = du;
+    p.dv = dv;
+    p.val_ratio = val_ratio;
+    p.val_win = val_win;
+    p.dbg_win = dbg_win;
+    p.dbg_corr = dbg_corr;
+    int n_cu;
+    rc = n_cu_of_current_device(&n_cu);
+    if (rc) return rc;
+    HIP_TRY(tpiv::launch_xcorr(p, mode, n_cu, (hipStream_t)stream));
+    return TPIV_OK;
+}
+
+int tpiv_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws, int ov,
+              const double* u0, const double* v0, const double* u2, const double* v2,
+              double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, double* du,
+              double* dv, void* stream) {
+    return run_iter(mode, a, b, batch, H, W, ws, ov, u0, v0, u2, v2, val_ratio, val_win, u, v, invalid,
+                    du, dv, nullptr, nullptr, stream);
+}
+
+int tpiv_debug_pass(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
+                    int ov, const double* u2, const double* v2, double* u, double* v,
+                    uint8_t* invalid, float* win, float* corr, void* stream) {
+    if (mode == 0) {
+        int rc = check_window(H, W, ws, ov, 3);
+        if (rc) return rc;
+        tpiv::PassParams p{};
+        p.A = a;
+        p.B = b;
+        p.batch = batch;
+        p.H = H;
+        p.W = W;
+        p.ws = ws;
+        p.ov = ov;
+        field_shape(H, W, ws, ov, &p.n_rows, &p.n_cols);
+        p.u = u;
+        p.v = v;
+        p.val = invalid;
+        p.val_ratio = 1.2;
+        p.val_win = 3;
+        p.dbg_win = win;
+        p.dbg_corr = corr;
+        int n_cu;
+        rc = n_cu_of_current_device(&n_cu);
+        if (rc) return rc;
+        HIP_TRY(tpiv::launch_xcorr(p, tpiv::MODE_PASS1, n_cu, (hipStream_t)stream));
+        return TPIV_OK;
+    }
+    int nr, nc;
+    int rc = tpiv_field_shape(H, W, ws, ov, &nr, &nc);
+    if (rc) return rc;
+    const size_t n = (size_t)batch * nr * nc;
+    double* zero = nullptr;
+    HIP_TRY(hipMalloc((void**)&zero, n * sizeof(double)));
+    hipError_t e = hipMemsetAsync(zero, 0, n * sizeof(double), (hipStream_t)stream);
+    if (e == hipSuccess) {
+        rc = run_iter(mode, a, b, batch, H, W, ws, ov, zero, zero, u2, v2, 1.2, 3, u, v, invalid, nullptr,
+                      nullptr, win, corr, stream);
+        e = hipStreamSynchronize((hipStream_t)stream);
+    }
+    (void)hipFree(zero);
+    if (e != hipSuccess) return hip_fail(e, "tpiv_debug_pass");
+    return rc;
+}
+
+int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, int mode,
+                     double pass_scale, double val_ratio, int val_win, int max_batch) {
+    if (!out) return fail(TPIV_EINVAL, "null plan pointer");
+    *out = nullptr;
+    if (n_pass < 1) n_pass = 1;     // range(multipass - 1) is empty for multipass <= 1 (B:855)
+    if (n_pass > 1 && mode != TPIV_MODE_DWS && mode != TPIV_MODE_CWS)
+        return fail(TPIV_EKEY, "unknown multipass mode");
+    if (max_batch < 1) return fail(TPIV_EINVAL, "max_batch must be >= 1");
+    if (!(pass_scale > 0)) return fail(TPIV_EINVAL, "multipass_scale must be positive");
+    tpiv_plan* pl = new tpiv_plan();
+    pl->H = H;
+    pl->W = W;
+    pl->n_pass = n_pass;
+    pl->mode = mode;
+    pl->max_batch = max_batch;
+    pl->val_ratio = val_ratio;
+    pl->val_win = val_win;
+    int rc = TPIV_OK;
+    hipError_t he = hipGetDevice(&pl->device);
+    if (he != hipSuccess) {
+        delete pl;
+        return hip_fail(he, "hipGetDevice");
+    }
+    int w = ws, o = ov;
+    for (int p = 0; p < n_pass && rc == TPIV_OK; ++p) {
+        if (p > 0) {
+            w = (int)std::floor((double)w / pass_scale);   // int(ws // scale), B:856-857
+            o = (int)std::floor((double)o / pass_scale);
+        }
+        rc = check_window(H, W, w, o, val_win);
+        if (rc) break;
+        PassGeo g;
+        g.ws = w;
+        g.ov = o;
+        field_shape(H, W, w, o, &g.n_rows, &g.n_cols);
+        g.x.resize(g.n_cols);
+        g.y.resize(g.n_rows);
+        coords_1d(W, g.n_cols, w, o, g.x.data());
+        coords_1d(H, g.n_rows, w, o, g.y.data());
+        pl->geo.push_back(std::move(g));
+    }
+    size_t max_fine = 0, max_T = 0;
+    pl->Ay.assign(n_pass, nullptr);
+    pl->Ax.assign(n_pass, nullptr);
+    pl->u.assign(n_pass, nullptr);
+    pl->v.assign(n_pass, nullptr);
+    pl->val.assign(n_pass, nullptr);
+    for (int p = 0; p < n_pass && rc == TPIV_OK; ++p) {
+        const PassGeo& g = pl->geo[p];
+        const size_t N = (size_t)g.n_rows * g.n_cols;
+        if (p < n_pass - 1) {
+            rc = pl->alloc(&pl->u[p], N * max_batch);
+            if (!rc) rc = pl->alloc(&pl->v[p], N * max_batch);
+            if (!rc) rc = pl->alloc(&pl->val[p], N * max_batch);
+        }
+        if (p > 0 && rc == TPIV_OK) {
+            const PassGeo& c = pl->geo[p - 1];
+            std::vector<double> ay((size_t)g.n_rows * c.n_rows), ax((size_t)g.n_cols * c.n_cols);
+            rc = spline_matrix(c.n_rows, c.y.data(), g.n_rows, g.y.data(), ay.data());
+            if (!rc) rc = spline_matrix(c.n_cols, c.x.data(), g.n_cols, g.x.data(), ax.data());
+            if (!rc) rc = pl->alloc(&pl->Ay[p], ay.size());
+            if (!rc) rc = pl->alloc(&pl->Ax[p], ax.size());
+            if (!rc) {
+                he = hipMemcpy(pl->Ay[p], ay.data(), ay.size() * sizeof(double), hipMemcpyHostToDevice);
+                if (he == hipSuccess)
+                    he = hipMemcpy(pl->Ax[p], ax.data(), ax.size() * sizeof(double), hipMemcpyHostToDevice);
+                if (he != hipSuccess) rc = hip_fail(he, "hipMemcpy(spline operators)");
+            }
+            if (N > max_fine) max_fine = N;
+            const size_t t = (size_t)3 * c.n_rows * g.n_cols;
+            if (t > max_T) max_T = t;
+        }
+    }
+    if (rc == TPIV_OK && n_pass > 1) {
+        rc = pl->alloc(&pl->u0, max_fine * max_batch);
+        if (!rc) rc = pl->alloc(&pl->v0, max_fine * max_batch);
+        if (!rc) rc = pl->alloc(&pl->u2, max_fine * max_batch);
+        if (!rc) rc = pl->alloc(&pl->v2, max_fine * max_batch);
+        if (!rc) rc = pl->alloc(&pl->T, max_T * max_batch);
+    }
+    if (rc) {
+        const std::string keep = g_err;
+        delete pl;
+        g_err = keep;
+        return rc;
+    }
+    *out = pl;
+    return TPIV_OK;
+}
+
+void tpiv_plan_destroy(tpiv_plan* plan) { delete plan; }
+
+int tpiv_plan_n_pass(const tpiv_plan* plan) { return plan ? plan->n_pass : 0; }
+
+int tpiv_plan_pass_geometry(const tpiv_plan* plan, int pass, int* ws, int* ov, int* n_rows, int* n_cols) {
+    if (!plan || pass < 0 || pass >= plan->n_pass) return fail(TPIV_EINVAL, "bad plan / pass index");
+    const PassGeo& g = plan->geo[pass];
+    if (ws) *ws = g.ws;
+    if (ov) *ov = g.ov;
+    if (n_rows) *n_rows = g.n_rows;
+    if (n_cols) *n_cols = g.n_cols;
+    return TPIV_OK;
+}
+
+int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u, double** v, uint8_t** invalid) {
+    if (!plan || pass < 0 || pass >= plan->n_pass - 1)
+        return fail(TPIV_EINVAL, "only the passes before the last keep their fields in the plan");
+    if (u) *u = plan->u[pass];
+    if (v) *v = plan->v[pass];
+    if (invalid) *invalid = plan->val[pass];
+    return TPIV_OK;
+}
+
+int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch, double* u, double* v,
+                  uint8_t* invalid, void* stream) {
+    if (!plan) return fail(TPIV_EINVAL, "null plan");
+    if (batch < 0 || batch > plan->max_batch) return fail(TPIV_EINVAL, "batch exceeds the plan's max_batch");
+    if (batch == 0) return TPIV_OK;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != plan->device) return fail(TPIV_EINVAL, "plan was created on another device");
+    const int last = plan->n_pass - 1;
+    for (int p = 0; p <= last; ++p) {
+        const PassGeo& g = plan->geo[p];
+        double* pu = p == last ? u : plan->u[p];
+        double* pv = p == last ? v : plan->v[p];
+        uint8_t* pval = p == last ? invalid : plan->val[p];
+        int rc;
+        if (p == 0) {
+            rc = tpiv_pass1(a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->val_ratio, plan->val_win, pu,
+                            pv, pval, stream);
+        } else {
+            const PassGeo& c = plan->geo[p - 1];
+            rc = tpiv_predict(plan->mode, batch, c.n_rows, c.n_cols, g.n_rows, g.n_cols, plan->Ay[p],
+                              plan->Ax[p], plan->u[p - 1], plan->v[p - 1], plan->val[p - 1], plan->T,
+                              plan->u0, plan->v0, plan->u2, plan->v2, stream);
+            if (!rc)
+                rc = tpiv_iter(plan->mode, a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->u0, plan->v0,
+                               plan->u2, plan->v2, plan->val_ratio, plan->val_win, pu, pv, pval, nullptr,
+                               nullptr, stream);
+        }
+        if (rc) return rc;
+    }
+    return TPIV_OK;
+}
+
+}  // extern "C"

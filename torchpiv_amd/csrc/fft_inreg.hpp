@@ -1,0 +1,113 @@
+// In-register (per-lane) complex FFT codelets for the PIV tile kernels.
+//
+// One lane holds a whole line of N complex samples in registers (N = 8..128)
+// and transforms it with compile-time-unrolled radix-4 (first stage radix-2
+// when log2 N is odd) decimation-in-frequency butterflies.  All array indices
+// and twiddles are compile-time constants, so the array lives in VGPRs and the
+// trivial twiddles (1, -i, -1, i) cost nothing.  The output is left in
+// digit-reversed order: output bin k sits at fft_pos(k, N).
+//
+// The header also compiles as plain host C++ (tests/test_fft_codelets.py builds
+// it with g++ and checks it against numpy.fft).
+#pragma once
+#include <type_traits>
+
+#if defined(__HIPCC__)
+#define TPIV_HD __host__ __device__ __forceinline__
+#else
+#define TPIV_HD inline
+#endif
+
+namespace tpiv {
+
+#include "twiddles.inc"
+
+struct cf {
+    float x, y;
+};
+
+TPIV_HD cf cadd(cf a, cf b) { return cf{a.x + b.x, a.y + b.y}; }
+TPIV_HD cf csub(cf a, cf b) { return cf{a.x - b.x, a.y - b.y}; }
+
+constexpr bool radix2_first(int n) { return n == 2 || n == 8 || n == 32 || n == 128; }
+
+// register position of output bin k after the size-n DIF transform
+constexpr int fft_pos(int k, int n) {
+    if (n <= 1) return 0;
+    if (radix2_first(n)) return (k % 2) * (n / 2) + fft_pos(k / 2, n / 2);
+    return (k % 4) * (n / 4) + fft_pos(k / 4, n / 4);
+}
+
+template <int J, int END, typename F>
+TPIV_HD void static_for(F&& f) {
+    if constexpr (J < END) {
+        f(std::integral_constant<int, J>{});
+        static_for<J + 1, END>(f);
+    }
+}
+
+// a * exp(-DIR * 2*pi*i * K / N)   (DIR = +1 forward, -1 inverse)
+template <int K, int N, int DIR>
+TPIV_HD cf twmul(cf a) {
+    constexpr int idx = ((K % N) * (128 / N)) % 128;
+    if constexpr (idx == 0) {
+        return a;
+    } else if constexpr (idx == 32) {
+        return DIR > 0 ? cf{a.y, -a.x} : cf{-a.y, a.x};
+    } else if constexpr (idx == 64) {
+        return cf{-a.x, -a.y};
+    } else if constexpr (idx == 96) {
+        return DIR > 0 ? cf{-a.y, a.x} : cf{a.y, -a.x};
+    } else {
+        constexpr float c = TW_COS[idx];
+        constexpr float s = DIR > 0 ? -TW_SIN[idx] : TW_SIN[idx];
+        return cf{a.x * c - a.y * s, a.x * s + a.y * c};
+    }
+}
+
+template <int N, int OFF, int DIR, int TOTAL>
+struct FFTStage {
+    static TPIV_HD void run(cf (&x)[TOTAL]) {
+        if constexpr (N == 2) {
+            cf a = x[OFF], b = x[OFF + 1];
+            x[OFF] = cadd(a, b);
+            x[OFF + 1] = csub(a, b);
+        } else if constexpr (radix2_first(N)) {
+            static_for<0, N / 2>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                cf a = x[OFF + j], b = x[OFF + j + N / 2];
+                x[OFF + j] = cadd(a, b);
+                x[OFF + j + N / 2] = twmul<j, N, DIR>(csub(a, b));
+            });
+            FFTStage<N / 2, OFF, DIR, TOTAL>::run(x);
+            FFTStage<N / 2, OFF + N / 2, DIR, TOTAL>::run(x);
+        } else if constexpr (N >= 4) {
+            static_for<0, N / 4>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                cf a = x[OFF + j], b = x[OFF + j + N / 4], c = x[OFF + j + N / 2],
+                   d = x[OFF + j + 3 * N / 4];
+                cf t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), bd = csub(b, d);
+                // forward: t3 = -i (b - d); inverse: t3 = +i (b - d)
+                cf t3 = DIR > 0 ? cf{bd.y, -bd.x} : cf{-bd.y, bd.x};
+                x[OFF + j] = cadd(t0, t2);
+                x[OFF + j + N / 4] = twmul<j, N, DIR>(cadd(t1, t3));
+                x[OFF + j + N / 2] = twmul<2 * j, N, DIR>(csub(t0, t2));
+                x[OFF + j + 3 * N / 4] = twmul<3 * j, N, DIR>(csub(t1, t3));
+            });
+            if constexpr (N > 4) {
+                FFTStage<N / 4, OFF, DIR, TOTAL>::run(x);
+                FFTStage<N / 4, OFF + N / 4, DIR, TOTAL>::run(x);
+                FFTStage<N / 4, OFF + N / 2, DIR, TOTAL>::run(x);
+                FFTStage<N / 4, OFF + 3 * N / 4, DIR, TOTAL>::run(x);
+            }
+        }
+    }
+};
+
+// Unnormalised N-point transform of x[0..N) in place; bin k ends at x[fft_pos(k, N)].
+template <int N, int DIR>
+TPIV_HD void fft_inreg(cf (&x)[N]) {
+    FFTStage<N, 0, DIR, N>::run(x);
+}
+
+}  // namespace tpiv

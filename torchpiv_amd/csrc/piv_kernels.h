@@ -1,0 +1,52 @@
+// Internal launch interface between the C-ABI layer (c_api.cpp) and the kernels
+// (piv_kernels.hip).  Not part of the public boundary (include/torchpiv_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tpiv {
+
+enum { MODE_PASS1 = 0, MODE_DWS = 1, MODE_CWS = 2 };
+
+struct PassParams {
+    const uint8_t* A;      // [batch, H, W] frame a
+    const uint8_t* B;      // [batch, H, W] frame b
+    int batch, H, W;
+    int ws, ov, n_rows, n_cols;
+    // predictor inputs of passes >= 2, [batch, n_rows, n_cols] float64
+    const double* u0;      // predictor after invalid-zeroing (fallback value)
+    const double* v0;
+    const double* u2;      // window half-shift: DWS rint(u0/2), CWS u0_prezero/2
+    const double* v2;
+    // outputs [batch, n_rows, n_cols]
+    double* u;
+    double* v;
+    uint8_t* val;          // 1 = invalid (peak ratio below val_ratio)
+    double* du;            // optional: raw displacement of this pass (passes >= 2)
+    double* dv;
+    double val_ratio;
+    int val_win;
+    // test hooks (nullptr in production)
+    float* dbg_win;        // [batch, N, 2, ws, ws] staged windows (after the shift)
+    float* dbg_corr;       // [batch, N, ws, ws] corr - min + eps, fftshift layout
+};
+
+struct PredictParams {
+    int batch, mode;
+    int nrc, ncc, nrf, ncf;       // coarse / fine grid
+    const double* Ay;             // [nrf, nrc]
+    const double* Ax;             // [ncf, ncc]
+    const double* u_c;            // [batch, nrc, ncc]
+    const double* v_c;
+    const uint8_t* val_c;
+    double* T;                    // workspace [batch, 3, nrc, ncf]
+    double* u0;                   // [batch, nrf, ncf]
+    double* v0;
+    double* u2;
+    double* v2;
+};
+
+hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+hipError_t launch_predict(const PredictParams& q, hipStream_t stream);
+
+}  // namespace tpiv

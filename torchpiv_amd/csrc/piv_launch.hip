@@ -1,0 +1,113 @@
+// Predictor kernels and the tile-size dispatch (see xcorr_kernel.hpp for the tile kernel).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "piv_kernels.h"
+
+namespace tpiv {
+
+template <int WS>
+hipError_t launch_xcorr_ws(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+extern template hipError_t launch_xcorr_ws<8>(const PassParams&, int, int, hipStream_t);
+extern template hipError_t launch_xcorr_ws<16>(const PassParams&, int, int, hipStream_t);
+extern template hipError_t launch_xcorr_ws<32>(const PassParams&, int, int, hipStream_t);
+extern template hipError_t launch_xcorr_ws<64>(const PassParams&, int, int, hipStream_t);
+extern template hipError_t launch_xcorr_ws<128>(const PassParams&, int, int, hipStream_t);
+
+hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream) {
+    switch (p.ws) {
+        case 8: return launch_xcorr_ws<8>(p, mode, n_cu, stream);
+        case 16: return launch_xcorr_ws<16>(p, mode, n_cu, stream);
+        case 32: return launch_xcorr_ws<32>(p, mode, n_cu, stream);
+        case 64: return launch_xcorr_ws<64>(p, mode, n_cu, stream);
+        case 128: return launch_xcorr_ws<128>(p, mode, n_cu, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ----------------------------------------------------------------------------
+// predictor: Z_f = Ay * Z_c * Ax^T  (float64), PIVbackend.py:700-713 / 769-785
+// ----------------------------------------------------------------------------
+// step 1: T[b, f, rc, cf] = sum_cc Z[b, f, rc, cc] * Ax[cf, cc]
+__global__ void predict_cols_kernel(PredictParams q) {
+    const long long total = (long long)q.batch * 3 * q.nrc * q.ncf;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cfi = (int)(i % q.ncf);
+        const int rc = (int)((i / q.ncf) % q.nrc);
+        const int f = (int)((i / ((long long)q.ncf * q.nrc)) % 3);
+        const int b = (int)(i / ((long long)q.ncf * q.nrc * 3));
+        const double* ax = q.Ax + (size_t)cfi * q.ncc;
+        const size_t zoff = ((size_t)b * q.nrc + rc) * q.ncc;
+        double acc = 0.0;
+        if (f == 2) {
+            const uint8_t* z = q.val_c + zoff;
+            for (int k = 0; k < q.ncc; ++k) acc += (double)z[k] * ax[k];
+        } else {
+            const double* z = (f == 0 ? q.u_c : q.v_c) + zoff;
+            for (int k = 0; k < q.ncc; ++k) acc += z[k] * ax[k];
+        }
+        q.T[i] = acc;
+    }
+}
+
+// step 2: out[b, f, rf, cf] = sum_rc Ay[rf, rc] * T[b, f, rc, cf], then the per-mode
+// predictor post-processing.
+__global__ void predict_rows_kernel(PredictParams q) {
+    const long long total = (long long)q.batch * q.nrf * q.ncf;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int cfi = (int)(i % q.ncf);
+        const int rf = (int)((i / q.ncf) % q.nrf);
+        const int b = (int)(i / ((long long)q.ncf * q.nrf));
+        const double* ay = q.Ay + (size_t)rf * q.nrc;
+        const double* t0 = q.T + ((size_t)b * 3 + 0) * q.nrc * q.ncf + cfi;
+        const double* t1 = q.T + ((size_t)b * 3 + 1) * q.nrc * q.ncf + cfi;
+        const double* t2 = q.T + ((size_t)b * 3 + 2) * q.nrc * q.ncf + cfi;
+        double u0 = 0.0, v0 = 0.0, vm = 0.0;
+        for (int k = 0; k < q.nrc; ++k) {
+            const double a = ay[k];
+            u0 += a * t0[(size_t)k * q.ncf];
+            v0 += a * t1[(size_t)k * q.ncf];
+            vm += a * t2[(size_t)k * q.ncf];
+        }
+        const bool val = vm >= 0.5;                 // B:711 / B:778
+        double u2, v2;
+        if (q.mode == MODE_CWS) {                   // B:705-706: halves taken BEFORE the zeroing
+            u2 = u0 / 2;
+            v2 = v0 / 2;
+        }
+        if (val) {
+            u0 = 0.0;
+            v0 = 0.0;
+        }
+        if (q.mode == MODE_DWS) {                   // B:782-785: AFTER the zeroing, half-even
+            u2 = rint(u0 / 2);
+            v2 = rint(v0 / 2);
+        }
+        q.u0[i] = u0;
+        q.v0[i] = v0;
+        q.u2[i] = u2;
+        q.v2[i] = v2;
+    }
+}
+
+hipError_t launch_predict(const PredictParams& q, hipStream_t stream) {
+    {
+        const long long total = (long long)q.batch * 3 * q.nrc * q.ncf;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(predict_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    {
+        const long long total = (long long)q.batch * q.nrf * q.ncf;
+        long long blocks = (total + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(predict_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, q);
+        return hipGetLastError();
+    }
+}
+
+}  // namespace tpiv

@@ -1,0 +1,5 @@
+// Tile kernels for 64x64 interrogation windows (see xcorr_kernel.hpp).
+#include "xcorr_kernel.hpp"
+namespace tpiv {
+template hipError_t launch_xcorr_ws<64>(const PassParams&, int, int, hipStream_t);
+}

@@ -1,0 +1,219 @@
+"""Thin tensor-level wrappers over the C ABI: PyTorch-ROCm tensors in, tensors out.
+
+PyTorch is used for device memory and streams only; all arithmetic of the hot path
+happens in libtorchpiv_hip.so.  Every function requires CUDA(HIP) tensors and raises
+otherwise -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MODES, check, lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("torchpiv_amd: the HIP path needs tensors on a ROCm device "
+                               "(there is no CPU fallback)")
+
+
+def _frames(a: torch.Tensor, b: torch.Tensor):
+    _need_cuda(a, b)
+    if a.dtype != torch.uint8 or b.dtype != torch.uint8:
+        raise TypeError("frames must be uint8")
+    if a.shape != b.shape:
+        raise ValueError("frame shapes differ")
+    if a.dim() == 2:
+        a, b = a[None], b[None]
+    if a.dim() != 3:
+        raise ValueError("frames must be [H, W] or [batch, H, W]")
+    return a.contiguous(), b.contiguous()
+
+
+def field_shape(H, W, ws, ov):
+    """get_field_shape, PIVbackend.py:425-456."""
+    nr, nc = C.c_int(), C.c_int()
+    check(lib.tpiv_field_shape(H, W, ws, ov, C.byref(nr), C.byref(nc)))
+    return nr.value, nc.value
+
+
+def coordinates_1d(H, W, ws, ov):
+    """Axis vectors of get_coordinates, PIVbackend.py:522-597."""
+    nr, nc = field_shape(H, W, ws, ov)
+    x = np.empty(nc, dtype=np.float64)
+    y = np.empty(nr, dtype=np.float64)
+    check(lib.tpiv_coordinates(H, W, ws, ov, x.ctypes.data_as(C.POINTER(C.c_double)),
+                               y.ctypes.data_as(C.POINTER(C.c_double))))
+    return x, y
+
+
+def spline_matrix(xc: np.ndarray, xf: np.ndarray) -> np.ndarray:
+    """1-D operator of the RectBivariateSpline predictor (host, float64)."""
+    xc = np.ascontiguousarray(xc, dtype=np.float64)
+    xf = np.ascontiguousarray(xf, dtype=np.float64)
+    A = np.empty((xf.size, xc.size), dtype=np.float64)
+    P = C.POINTER(C.c_double)
+    check(lib.tpiv_spline_matrix(xc.size, xc.ctypes.data_as(P), xf.size, xf.ctypes.data_as(P),
+                                 A.ctypes.data_as(P)))
+    return A
+
+
+def pass1(a, b, ws, ov, val_ratio=1.2, val_win=3):
+    """Device part of extended_search_area_piv(validate=True). Returns u, v (float64) and
+    invalid (uint8), each [batch, n_rows, n_cols], on the frames' device."""
+    a, b = _frames(a, b)
+    B, H, W = a.shape
+    nr, nc = field_shape(H, W, ws, ov)
+    u = torch.empty(B, nr, nc, dtype=torch.float64, device=a.device)
+    v = torch.empty_like(u)
+    inv = torch.empty(B, nr, nc, dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        check(lib.tpiv_pass1(a.data_ptr(), b.data_ptr(), B, H, W, ws, ov, val_ratio, val_win,
+                             u.data_ptr(), v.data_ptr(), inv.data_ptr(), _stream()))
+    return u, v, inv
+
+
+def predict(mode, Ay, Ax, u_c, v_c, inv_c):
+    """Spline predictor of one iteration: returns u0, v0 (zeroed where invalid), u2, v2."""
+    _need_cuda(Ay, Ax, u_c, v_c, inv_c)
+    B, nrc, ncc = u_c.shape
+    nrf, ncf = Ay.shape[0], Ax.shape[0]
+    dev = u_c.device
+    work = torch.empty(B * 3 * nrc * ncf, dtype=torch.float64, device=dev)
+    outs = [torch.empty(B, nrf, ncf, dtype=torch.float64, device=dev) for _ in range(4)]
+    with torch.cuda.device(dev):
+        check(lib.tpiv_predict(MODES[mode], B, nrc, ncc, nrf, ncf, Ay.data_ptr(), Ax.data_ptr(),
+                               u_c.contiguous().data_ptr(), v_c.contiguous().data_ptr(),
+                               inv_c.contiguous().data_ptr(), work.data_ptr(),
+                               *[o.data_ptr() for o in outs], _stream()))
+    return outs
+
+
+def iterate(mode, a, b, ws, ov, u0, v0, u2, v2, val_ratio=1.2, val_win=3, want_raw=False):
+    """Device part of piv_iteration_{DWS,CWS}.__call__ after the predictor."""
+    a, b = _frames(a, b)
+    _need_cuda(u0, v0, u2, v2)
+    B, H, W = a.shape
+    nr, nc = field_shape(H, W, ws, ov)
+    dev = a.device
+    u = torch.empty(B, nr, nc, dtype=torch.float64, device=dev)
+    v = torch.empty_like(u)
+    inv = torch.empty(B, nr, nc, dtype=torch.uint8, device=dev)
+    du = torch.empty_like(u) if want_raw else None
+    dv = torch.empty_like(u) if want_raw else None
+    with torch.cuda.device(dev):
+        check(lib.tpiv_iter(MODES[mode], a.data_ptr(), b.data_ptr(), B, H, W, ws, ov,
+                            u0.contiguous().data_ptr(), v0.contiguous().data_ptr(),
+                            u2.contiguous().data_ptr(), v2.contiguous().data_ptr(),
+                            val_ratio, val_win, u.data_ptr(), v.data_ptr(), inv.data_ptr(),
+                            du.data_ptr() if want_raw else None, dv.data_ptr() if want_raw else None,
+                            _stream()))
+    if want_raw:
+        return u, v, inv, du, dv
+    return u, v, inv
+
+
+def debug_pass(mode, a, b, ws, ov, u2=None, v2=None):
+    """Test hook: one pass plus the staged windows and the correlation maps."""
+    a, b = _frames(a, b)
+    B, H, W = a.shape
+    nr, nc = field_shape(H, W, ws, ov)
+    dev = a.device
+    N = nr * nc
+    u = torch.empty(B, nr, nc, dtype=torch.float64, device=dev)
+    v = torch.empty_like(u)
+    inv = torch.empty(B, nr, nc, dtype=torch.uint8, device=dev)
+    win = torch.empty(B, N, 2, ws, ws, dtype=torch.float32, device=dev)
+    corr = torch.empty(B, N, ws, ws, dtype=torch.float32, device=dev)
+    m = 0 if mode in (0, None, "PASS1") else MODES[mode]
+    with torch.cuda.device(dev):
+        check(lib.tpiv_debug_pass(m, a.data_ptr(), b.data_ptr(), B, H, W, ws, ov,
+                                  u2.contiguous().data_ptr() if u2 is not None else None,
+                                  v2.contiguous().data_ptr() if v2 is not None else None,
+                                  u.data_ptr(), v.data_ptr(), inv.data_ptr(), win.data_ptr(),
+                                  corr.data_ptr(), _stream()))
+    return u, v, inv, win, corr
+
+
+class Plan:
+    """The multipass pipeline of OfflinePIV.__call__ (PIVbackend.py:873-882) for batches of
+    pairs resident on one GPU.  Owns the device workspace; `run` only enqueues kernels."""
+
+    def __init__(self, H, W, ws, ov, n_pass=1, mode="CWS", pass_scale=2.0, val_ratio=1.2,
+                 val_win=3, max_batch=1, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("torchpiv_amd.Plan needs a ROCm device (there is no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
+            else torch.device(device)
+        if n_pass > 1 and mode not in MODES:
+            raise KeyError(mode)
+        self._h = C.c_void_p()
+        self.H, self.W, self.max_batch = H, W, max_batch
+        with torch.cuda.device(self.device):
+            check(lib.tpiv_plan_create(C.byref(self._h), H, W, ws, ov, n_pass, MODES.get(mode, 0),
+                                       float(pass_scale), float(val_ratio), int(val_win),
+                                       int(max_batch)))
+        self.n_pass = lib.tpiv_plan_n_pass(self._h)
+        self.geometry = []
+        for p in range(self.n_pass):
+            w, o, nr, nc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            check(lib.tpiv_plan_pass_geometry(self._h, p, C.byref(w), C.byref(o), C.byref(nr),
+                                              C.byref(nc)))
+            self.geometry.append((w.value, o.value, nr.value, nc.value))
+
+    def close(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value and lib is not None:     # lib is None at interpreter teardown
+            lib.tpiv_plan_destroy(h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    @property
+    def out_shape(self):
+        return self.geometry[-1][2], self.geometry[-1][3]
+
+    def run(self, a, b, out=None):
+        """a, b uint8 [batch, H, W] (or [H, W]) on the plan's device.  Returns u, v float64 and
+        invalid uint8, [batch, n_rows, n_cols] of the last pass (async on the current stream)."""
+        a, b = _frames(a, b)
+        B = a.shape[0]
+        if a.shape[1] != self.H or a.shape[2] != self.W:
+            raise ValueError("frame shape differs from the plan's")
+        nr, nc = self.out_shape
+        if out is None:
+            u = torch.empty(B, nr, nc, dtype=torch.float64, device=a.device)
+            v = torch.empty_like(u)
+            inv = torch.empty(B, nr, nc, dtype=torch.uint8, device=a.device)
+        else:
+            u, v, inv = out
+        with torch.cuda.device(self.device):
+            check(lib.tpiv_plan_run(self._h, a.data_ptr(), b.data_ptr(), B, u.data_ptr(),
+                                    v.data_ptr(), inv.data_ptr(), _stream()))
+        return u, v, inv
+
+    def pass_fields(self, p, batch):
+        """Fields pass p (< n_pass-1) left in the workspace by the last run (copies)."""
+        pu, pv, pi = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.tpiv_plan_pass_fields(self._h, p, C.byref(pu), C.byref(pv), C.byref(pi)))
+        _, _, nr, nc = self.geometry[p]
+        n = batch * nr * nc
+        u = torch.empty(batch, nr, nc, dtype=torch.float64, device=self.device)
+        v = torch.empty_like(u)
+        inv = torch.empty(batch, nr, nc, dtype=torch.uint8, device=self.device)
+        torch.cuda.synchronize(self.device)
+        hip = C.CDLL("libamdhip64.so")
+        for dst, src, nbytes in ((u, pu, n * 8), (v, pv, n * 8), (inv, pi, n)):
+            rc = hip.hipMemcpy(C.c_void_p(dst.data_ptr()), src, C.c_size_t(nbytes), 3)  # D2D
+            if rc != 0:
+                raise _lib.HipError(f"hipMemcpy failed: {rc}")
+        return u, v, inv
