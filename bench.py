@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the PIV cross-correlation hot path (driver contract).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): image-pairs/sec at 4 MP, wind=64 ov=32, 2-pass CWS x2.0.
+Workload (BASELINE.json configs[1]): synthetic 2048x2048 pairs, batch = 256 pairs resident in
+HBM per GPU.  A "step" = one pass of the whole hot path (pass 1 + predictor + CWS pass 2, all
+kernels of tpiv_plan_run) over that batch.  N > 1: one process per GPU (torchrun), every rank
+owns its own batch (weak scaling, no data-path collective), and ONE RCCL all-gather of the
+(u, v) fields of the last step closes the timed region.
+
+Rank 0 prints one JSON line with `roofline` (dominant kernel, HIP-event timed on the launch
+stream during the timed steps) and, at N = 1, `cpu_baseline` (the CPU oracle on host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_VALU_PEAK_TFLOPS = 157.3   # vector fp32 peak, same guide
+
+
+def alg_bytes(H, W, n_windows, first_pass):
+    """both uint8 frames once per pass + 9 B/window out (+ 8 B/window predictor in)."""
+    return 2 * H * W + n_windows * 9 + (0 if first_pass else n_windows * 8)
+
+
+def alg_flops(ws, n_windows, cws):
+    import math
+    f = n_windows * (7.5 * ws * ws * math.log2(ws * ws) + 6 * ws * (ws / 2 + 1))
+    if cws:
+        f += 2 * n_windows * ws * ws * 14
+    return f
+
+
+def cpu_baseline(H, W, ws, ov, n_pass, mode, budget_s=20.0):
+    """The CPU oracle (a port of the reference's algorithm, oracle/piv_oracle.py) timed on this
+    box's host cores on a bounded sample of the same workload."""
+    from oracle import piv_oracle as O
+    from torchpiv_amd import synth
+    threads = torch.get_num_threads()
+    pairs = [synth.make_pair(H, W, 900 + i) for i in range(2)]
+    pairs = [(a.numpy(), b.numpy()) for a, b in pairs]
+
+    def one(a, b):
+        u, v, x, y, val = O.pass1(a, b, ws, ov, validate=True)
+        w, o = ws, ov
+        for _ in range(n_pass - 1):
+            w, o = w // 2, o // 2
+            u, v, x, y, val = O.ITER[mode](a.shape, w, o)(a, b, x, y, u, v, val)
+        return u
+
+    one(*pairs[0])                      # warm-up (MKL plans, page faults)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(*pairs[n % len(pairs)])
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 8:
+            break
+    return {"value": n / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{n} pairs of the same {H}x{W} {n_pass}-pass {mode} workload, oracle/piv_oracle.py "
+                      f"(numpy + torch-CPU FFT), no file I/O, no hole fill; survey-container figure for the "
+                      f"reference itself: 0.24 pairs/s on 8 threads (BASELINE.md)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step (configs[1]: 256)")
+    ap.add_argument("--size", type=int, default=2048)
+    ap.add_argument("--ws", type=int, default=64)
+    ap.add_argument("--passes", type=int, default=2)
+    ap.add_argument("--mode", default="CWS")
+    ap.add_argument("--distinct", type=int, default=0,
+                    help="distinct synthetic pairs to render (0 = all of the batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from torchpiv_amd import dist as pdist
+    from torchpiv_amd import engine, synth
+    import torch.distributed as dist
+
+    rank, world, local = pdist.init_from_env()
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    H = W = args.size
+    ws, ov = args.ws, args.ws // 2
+
+    # synthetic frames rendered on the device (seed = 1234 + global pair index), resident in HBM
+    distinct = args.batch if args.distinct <= 0 else min(args.distinct, args.batch)
+    A0, B0 = synth.make_batch(distinct, H, W, first_index=rank * args.batch, device=dev)
+    reps = (args.batch + distinct - 1) // distinct
+    A = A0.repeat(reps, 1, 1)[: args.batch].contiguous()
+    B = B0.repeat(reps, 1, 1)[: args.batch].contiguous()
+    del A0, B0
+
+    plan = engine.Plan(H, W, ws, ov, n_pass=args.passes, mode=args.mode, max_batch=args.batch, device=dev)
+    nr, nc = plan.out_shape
+    out = (torch.empty(args.batch, nr, nc, dtype=torch.float64, device=dev),
+           torch.empty(args.batch, nr, nc, dtype=torch.float64, device=dev),
+           torch.empty(args.batch, nr, nc, dtype=torch.uint8, device=dev))
+
+    for _ in range(args.warmup):
+        plan.run(A, B, out=out)
+    torch.cuda.synchronize()
+    plan.set_timing(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.run(A, B, out=out)
+    if world > 1:
+        # the single end-of-stream collective: (u, v) of every rank's batch, float64 as yielded
+        uv = torch.stack([out[0], out[1]], dim=1)
+        ids = torch.arange(rank * args.batch, (rank + 1) * args.batch, device=dev)
+        pdist.gather_fields(ids, uv)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing, n_runs = plan.get_timing()
+    plan.set_timing(False)
+
+    if rank == 0:
+        pairs_total = args.batch * args.steps * world
+        value = pairs_total / elapsed
+        # dominant kernel = the slot with the largest mean duration
+        dom = max(timing, key=timing.get)
+        p_idx = 0 if dom.startswith("pass1") else int(dom[4]) - 1
+        g_ws, g_ov, g_nr, g_nc = plan.geometry[p_idx]
+        n_win = g_nr * g_nc
+        b_launch = alg_bytes(H, W, n_win, p_idx == 0) * args.batch
+        f_launch = alg_flops(g_ws, n_win, args.mode == "CWS" and p_idx > 0) * args.batch
+        t_dom = timing[dom] * 1e-3
+        achieved = b_launch / t_dom / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    traffic = json.load(f).get(dom)
+            except Exception:
+                traffic = None
+        b_pair = sum(alg_bytes(H, W, g[2] * g[3], i == 0) for i, g in enumerate(plan.geometry))
+        f_pair = sum(alg_flops(g[0], g[2] * g[3], args.mode == "CWS" and i > 0)
+                     for i, g in enumerate(plan.geometry))
+        rec = {
+            "metric": "image-pairs/sec at 4 MP, wind=64 ov=32 2-pass CWS; % HBM roofline",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {H}x{W} pair batch={args.batch} per GPU, wind={ws} overlap={ov}, "
+                                   f"{args.passes}-pass {args.mode} x2.0 (BASELINE.json configs[1])",
+                       "batch_per_gpu": args.batch, "distinct_pairs": distinct,
+                       "parallelism": f"pair-sharded x{world}, one RCCL all-gather of (u,v) at the end"},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": f"xcorr_kernel<{g_ws}, {'PASS1' if p_idx == 0 else args.mode}> ({dom})",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "alg_bytes_per_launch": b_launch,
+                "launch_ms": timing[dom],
+                "launches_timed": n_runs,
+                "valu_frac": f_launch / t_dom / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                "note": "the path is VALU/LDS-bound (SURVEY.md 8d): valu_frac is the binding fraction",
+            },
+            "kernel_ms": timing,
+            "whole_path": {"alg_bytes_per_pair": b_pair, "hbm_frac": b_pair * value / world / 1e9 / HBM_PEAK_GBS,
+                           "alg_flops_per_pair": f_pair,
+                           "valu_frac": f_pair * value / world / 1e12 / FP32_VALU_PEAK_TFLOPS},
+            "published_ref": {"value": 6.7, "unit": "pairs/s",
+                              "note": "'>6.7 pairs/s' incl. file I/O, GPU unnamed (GTX 1660 Ti era), "
+                                      "reference README.md:58; not this exact metric, so vs_baseline is null"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(H, W, ws, ov, args.passes, args.mode)
+        print(json.dumps(rec), flush=True)
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

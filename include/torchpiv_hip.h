@@ -120,6 +120,18 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a_dev, const uint8_t* b_dev, i
 int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u_dev, double** v_dev,
                           uint8_t** invalid_dev);
 
+/* ---- measurement ------------------------------------------------------------------ */
+
+/* Per-kernel timing with hipEvents recorded on the run's own stream (torch.cuda.Event only
+ * sees torch's current stream).  While enabled, every tpiv_plan_run brackets each launch
+ * with an event pair (no host synchronisation; up to 512 runs are kept).  Slots:
+ * 0 = pass-1 tile kernel; for pass p >= 1: 2p-1 = predictor kernels, 2p = tile kernel. */
+int tpiv_plan_set_timing(tpiv_plan* plan, int enable);
+/* Waits for the recorded events, writes the MEAN duration in milliseconds of every slot over
+ * the runs recorded since the last call into avg_ms[0..n_slots) and the number of runs into
+ * n_runs, then clears the record.  n_slots must be 2*n_pass - 1. */
+int tpiv_plan_get_timing(tpiv_plan* plan, double* avg_ms, int n_slots, int* n_runs);
+
 /* ---- test hook ------------------------------------------------------------------ */
 
 /* Runs one pass like tpiv_pass1 (mode 0) / tpiv_iter (mode DWS/CWS, with u0 = v0 = 0)

@@ -1,0 +1,72 @@
+"""The N > 1 path on CPU: two processes, gloo backend -- sharding policy and the single
+end-of-stream gather with data-dependent shard sizes (dropped pairs)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from torchpiv_amd import dist as pdist
+    r, w, _ = pdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    n_pairs = 11
+    mine = pdist.shard_indices(n_pairs, rank, world, "block")
+    # rank 1 "drops" one of its pairs, as the hole-fill quirk would
+    kept = [i for i in mine if not (rank == 1 and i == mine[1])]
+    fields = torch.stack([torch.full((2, 3, 4), float(i), dtype=torch.float64) for i in kept]) \
+        if kept else torch.zeros(0, 2, 3, 4, dtype=torch.float64)
+    ids, allf = pdist.gather_fields(torch.tensor(kept, dtype=torch.int64), fields)
+    if rank == 0:
+        q.put((ids.tolist(), allf[:, 0, 0, 0].tolist()))
+    else:
+        assert ids is None and allf is None
+    # cyclic policy partitions too
+    cyc = pdist.shard_indices(n_pairs, rank, world, "cyclic")
+    t = torch.zeros(n_pairs)
+    t[cyc] = 1
+    dist.all_reduce(t)
+    assert bool((t == 1).all())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gather_two_ranks():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ids, vals = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # 11 pairs: rank 0 owns 0..5, rank 1 owns 6..10 and dropped pair 7
+    assert ids == [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]
+    assert vals == [float(i) for i in ids]
+
+
+def test_shard_indices_cover_everything():
+    from torchpiv_amd import dist as pdist
+    for n in (0, 1, 7, 8, 4000):
+        for world in (1, 2, 8):
+            for pol in ("block", "cyclic"):
+                got = sorted(sum((pdist.shard_indices(n, r, world, pol) for r in range(world)), []))
+                assert got == list(range(n))
+    assert len(pdist.shard_indices(4000, 3, 8)) == 500

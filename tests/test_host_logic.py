@@ -1,0 +1,172 @@
+"""CPU-side tests: C-ABI symbols, geometry, spline operators, decoding, pairing, post-validation,
+error mapping, FFT codelets.  No GPU compute is called here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    """The library must load and export every function include/torchpiv_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "torchpiv_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tpiv_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    from torchpiv_amd import _lib
+    for name in sorted(declared):
+        assert hasattr(_lib.lib, name), name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.lib.tpiv_version() == 1
+
+
+def test_geometry_matches_reference(golden):
+    from torchpiv_amd import backend, engine
+    g = golden("g1_geometry")
+    for H, W, ws, ov in g["cases"]:
+        key = f"{H}_{W}_{ws}_{ov}"
+        assert tuple(g["fs_" + key]) == engine.field_shape(int(H), int(W), int(ws), int(ov))
+        assert np.array_equal(backend.get_field_shape((H, W), ws, ov), g["fs_" + key])
+        x, y = backend.get_coordinates((H, W), ws, ov)
+        assert np.array_equal(x[0, :], g["x_" + key]) and np.array_equal(y[:, 0], g["y_" + key])
+        assert x.shape == (g["fs_" + key][0], g["fs_" + key][1])
+
+
+def test_error_codes_map_to_reference_exceptions():
+    from torchpiv_amd import engine
+    with pytest.raises(ValueError, match="Overlap has to be smaller"):
+        engine.field_shape(64, 64, 32, 32)
+    with pytest.raises(ValueError, match="window size cannot be larger"):
+        engine.field_shape(64, 64, 128, 0)
+    with pytest.raises(ValueError):
+        engine.spline_matrix(np.arange(3.0), np.arange(5.0))     # scipy needs > 3 points too
+
+
+@pytest.mark.parametrize("nc,st,off", [(4, 32, 16.0), (5, 16, 8.0), (15, 32, 32.0), (63, 32, 32.0),
+                                       (91, 32, 44.0), (255, 16, 16.0)])
+def test_spline_operator_matches_fitpack(nc, st, off):
+    """The C-side predictor operator against scipy's RectBivariateSpline (what the reference calls)."""
+    from scipy import interpolate
+    from torchpiv_amd import engine
+    xc = off + st * np.arange(nc, dtype=np.float64)
+    xf = off - st / 2 + (st / 2) * np.arange(2 * nc + 1, dtype=np.float64)   # spills over both ends
+    A = engine.spline_matrix(xc, xf)
+    rng = np.random.default_rng(nc)
+    z = rng.standard_normal((nc, nc))
+    ref = interpolate.RectBivariateSpline(xc, xc, z)(xf, xf)
+    assert np.abs(A @ z @ A.T - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+    # partition of unity and interpolation at the nodes
+    assert np.abs(A.sum(axis=1) - 1).max() < 1e-13
+    on = np.isin(xf, xc)
+    assert on.sum() == nc
+    assert np.abs(A[on] - np.eye(nc)[np.searchsorted(xc, xf[on])]).max() < 1e-13
+
+
+def test_bmp_decode_and_pairing(tmp_path, golden):
+    from PIL import Image
+    from torchpiv_amd import io as pio
+    rng = np.random.default_rng(3)
+    gray = rng.integers(0, 256, size=(37, 53), dtype=np.uint8)       # odd width: row padding
+    Image.fromarray(gray, "L").save(tmp_path / "g.bmp")
+    assert np.array_equal(pio.imdecode_gray(str(tmp_path / "g.bmp")), gray)
+    rgb = rng.integers(0, 256, size=(20, 31, 3), dtype=np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.bmp")
+    got = pio.imdecode_gray(str(tmp_path / "c.bmp")).astype(int)
+    want = (rgb[..., 2].astype(int) * 1868 + rgb[..., 1].astype(int) * 9617 + rgb[..., 0].astype(int) * 4899
+            + 8192) >> 14
+    assert np.array_equal(got, want)
+    Image.fromarray(gray, "L").save(tmp_path / "g.png")
+    assert np.array_equal(pio.imdecode_gray(str(tmp_path / "g.png")), gray)
+    (tmp_path / "bad.bmp").write_bytes(b"not an image")
+    assert pio.imdecode_gray(str(tmp_path / "bad.bmp")) is None
+    # natural sort + pairing against the reference's own listing (golden g5)
+    g = golden("g5_generator")
+    d = tmp_path / "seq"
+    d.mkdir()
+    for i in range(4):
+        for s in "ab":
+            Image.fromarray(gray, "L").save(d / f"image{8 + i}_{s}.bmp")
+    ds = pio.PIVDataset(str(d), "bmp", "pairs")
+    assert [[os.path.basename(p) for p in pr] for pr in ds.img_pairs] == g["pairs_pairs"].tolist()
+    ds = pio.PIVDataset(str(d), "bmp", "sequential")
+    assert [[os.path.basename(p) for p in pr] for pr in ds.img_pairs] == g["seq_pairs"].tolist()
+    assert len(pio.PIVDataset(str(d), "bmp", "other")) == 0
+    assert len(pio.PIVDataset(str(d), "tif", "pairs")) == 0
+    a, b = pio.PIVDataset(str(d), "bmp", "pairs", transform=pio.ToTensor(dtype=__import__("torch").uint8))[0]
+    assert a.dtype == __import__("torch").uint8 and tuple(a.shape) == gray.shape
+
+
+def test_post_validation_matches_reference(golden):
+    from torchpiv_amd import backend
+    g = golden("g6_kats")
+    gb = backend.interpolate_boarders(g["pv_in"].copy())
+    assert np.allclose(gb, g["pv_borders"], rtol=0, atol=1e-12, equal_nan=True)
+    filled = backend.fillMissingValues(gb.copy())
+    assert np.allclose(filled, g["pv_filled"], rtol=0, atol=1e-12, equal_nan=True)
+    assert backend.fillMissingValues(np.ones((5, 5))) is None          # the dropped-clean-pair quirk
+    many = np.full((6, 6), np.nan)
+    many[::2, ::2] = 1.0
+    assert backend.fillMissingValues(many) is None                     # too many invalid
+    u, v = backend.post_validate(np.ones((4, 4)), np.ones((4, 4)), None)
+    assert u is not None                                               # val None: no post-processing
+
+
+def test_api_surface_and_errors_without_gpu(tmp_path):
+    import torch
+    import torchpiv_amd as T
+    assert "cpu" in T.DeviceMap.devicies
+    assert set(T.IterModMap.functions) == {"DWS", "CWS"}
+    with pytest.raises(KeyError):
+        T.OfflinePIV(str(tmp_path), "no-such-device", "bmp", 64, 32)
+    with pytest.raises(KeyError):
+        T.OfflinePIV(str(tmp_path), "cpu", "bmp", 64, 32, multipass_mode="XWS")
+    empty = T.OfflinePIV(str(tmp_path), "cpu", "bmp", 64, 32)          # empty folder: fine, yields nothing
+    assert len(empty) == 0 and list(empty()) == []
+    from PIL import Image
+    Image.fromarray(np.zeros((64, 64), np.uint8), "L").save(tmp_path / "a1.bmp")
+    Image.fromarray(np.zeros((64, 64), np.uint8), "L").save(tmp_path / "a2.bmp")
+    with pytest.raises(RuntimeError, match="no compute path"):
+        T.OfflinePIV(str(tmp_path), "cpu", "bmp", 32, 16)               # no silent CPU fallback
+    w = T.moving_window_array(torch.arange(12 * 10).reshape(12, 10), 4, 2)
+    assert tuple(w.shape) == (5 * 4, 4, 4) and w[1, 0, 0] == 2 and w[4, 0, 0] == 20
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            T.engine.pass1(torch.zeros(64, 64, dtype=torch.uint8), torch.zeros(64, 64, dtype=torch.uint8), 32, 16)
+
+
+def test_fft_codelets_on_host(tmp_path):
+    """fft_inreg.hpp compiled as host C++ against numpy.fft (forward and inverse, N = 8..128)."""
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include "fft_inreg.hpp"
+#include <cstdio>
+using namespace tpiv;
+template<int N, int DIR> void run() {
+  cf x[N];
+  for (int i = 0; i < N; ++i) { x[i].x = (float)((i*37+11)%101) - 50.f; x[i].y = (float)((i*53+7)%89) - 44.f; }
+  fft_inreg<N, DIR>(x);
+  printf("%d %d", N, DIR);
+  for (int k = 0; k < N; ++k) printf(" %.9g %.9g", x[fft_pos(k,N)].x, x[fft_pos(k,N)].y);
+  printf("\n");
+}
+int main(){ run<8,1>(); run<16,1>(); run<32,1>(); run<64,1>(); run<128,1>();
+            run<8,-1>(); run<16,-1>(); run<32,-1>(); run<64,-1>(); run<128,-1>(); }
+''')
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "torchpiv_amd", "csrc"), str(src),
+                    "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    for line in out.strip().splitlines():
+        t = line.split()
+        N, D = int(t[0]), int(t[1])
+        v = np.array(t[2:], dtype=float)
+        z = v[0::2] + 1j * v[1::2]
+        i = np.arange(N)
+        x = ((i * 37 + 11) % 101 - 50.0) + 1j * ((i * 53 + 7) % 89 - 44.0)
+        ref = np.fft.fft(x) if D > 0 else np.fft.ifft(x) * N
+        assert np.abs(z - ref).max() / np.abs(ref).max() < 3e-7, (N, D)

@@ -1,0 +1,367 @@
+"""Drop-in host side of the engine: the reference's public names with the reference's
+signatures, defaults and error behaviour (NikNazarov/TorchPIV, src/torchPIV/PIVbackend.py,
+cited as B:), driving the HIP library through torchpiv_amd.engine.
+
+What runs where
+  * device (libtorchpiv_hip.so): every pass of a pair -- windows, shift, FFT correlation,
+    peak, validation, predictor, combine -- with the fields staying on the GPU between passes
+    (the reference does three D2H copies and one H2D per pass);
+  * host (this file): dataset/decoding, the post-validation hole fill of B:884-892
+    (numpy + scipy, as in the reference), flip and unit scaling, the generator protocol.
+
+There is no CPU compute path: device="cpu" raises.
+"""
+from __future__ import annotations
+
+from time import time
+from typing import Generator
+
+import numpy as np
+import torch
+
+from . import engine
+from .io import PIVDataset, ToTensor, natural_keys  # noqa: F401  (re-exported like the reference)
+
+
+# ----------------------------------------------------------------------------------------
+# device / mode maps (B:13-18, B:814-818)
+# ----------------------------------------------------------------------------------------
+class _DeviceDict(dict):
+    """name -> torch.device.  The reference keys CUDA devices by torch.cuda.get_device_name(i),
+    so eight identical MI355X collapse to one key (the last index wins).  That behaviour is
+    kept for those names; 'cuda', 'cuda:N' and plain integers are accepted as well."""
+
+    def __init__(self):
+        super().__init__()
+        self._filled = False
+
+    def _fill(self):
+        if not self._filled:
+            self._filled = True
+            for i in range(torch.cuda.device_count()):
+                try:
+                    dict.__setitem__(self, torch.cuda.get_device_name(i), torch.device("cuda", i))
+                except Exception:       # no usable GPU in this process
+                    break
+            dict.__setitem__(self, "cpu", torch.device("cpu"))
+
+    def __getitem__(self, key):
+        self._fill()
+        if dict.__contains__(self, key):
+            return dict.__getitem__(self, key)
+        if isinstance(key, torch.device):
+            return key
+        if isinstance(key, int) and 0 <= key < torch.cuda.device_count():
+            return torch.device("cuda", key)
+        if isinstance(key, str) and (key == "cuda" or key.startswith("cuda:")):
+            d = torch.device(key)
+            return torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+        raise KeyError(key)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def __contains__(self, key):
+        try:
+            self[key]
+            return True
+        except KeyError:
+            return False
+
+
+class DeviceMap:
+    devicies = _DeviceDict()          # (sic) the reference's attribute name
+
+
+def _require_gpu(device: torch.device) -> torch.device:
+    if device.type != "cuda":
+        raise RuntimeError("torchpiv_amd runs on MI355X only: device='cpu' has no compute path here "
+                           "(use the upstream TorchPIV for CPU runs)")
+    return device
+
+
+# ----------------------------------------------------------------------------------------
+# geometry (B:425-456, B:522-597, B:220-247)
+# ----------------------------------------------------------------------------------------
+def get_field_shape(image_size, search_area_size, overlap):
+    return (np.array(image_size) - search_area_size) // (search_area_size - overlap) + 1
+
+
+def get_coordinates(image_size, search_area_size, overlap):
+    """(x, y) meshgrid of window-centre coordinates, as the reference returns it."""
+    x, y = engine.coordinates_1d(int(image_size[-2]), int(image_size[-1]), int(search_area_size),
+                                 int(overlap))
+    return np.meshgrid(x, y)
+
+
+def moving_window_array(array: torch.Tensor, window_size, overlap) -> torch.Tensor:
+    """Overlapping windows [N, ws, ws] of a 2-D tensor (a strided view made contiguous).  The
+    kernels never materialise this; it is kept for callers that used the reference's helper."""
+    H, W = array.shape[-2], array.shape[-1]
+    st = window_size - overlap
+    n_r, n_c = (H - window_size) // st + 1, (W - window_size) // st + 1
+    return torch.as_strided(array, size=(n_r, n_c, window_size, window_size),
+                            stride=(W * st, st, W, 1)).reshape(-1, window_size, window_size)
+
+
+# ----------------------------------------------------------------------------------------
+# pass 1 (B:459-520)
+# ----------------------------------------------------------------------------------------
+def extended_search_area_piv(frame_a, frame_b, window_size=32, overlap=0, validate: bool = False,
+                             validation_ratio: float = 1.2):
+    """First-pass PIV of one pair.  frame_a / frame_b: uint8 tensors [H, W] on a ROCm device.
+    Returns (u, v, x, y, mask) as numpy arrays like the reference (mask None if not validate).
+    Raises ValueError for overlap >= window_size or a window larger than the image."""
+    H, W = frame_a.shape[-2], frame_a.shape[-1]
+    u, v, inv = engine.pass1(frame_a, frame_b, int(window_size), int(overlap),
+                             val_ratio=float(validation_ratio))
+    x, y = get_coordinates((H, W), window_size, overlap)
+    mask = inv[0].cpu().numpy().astype(bool) if validate else None
+    return u[0].cpu().numpy(), v[0].cpu().numpy(), x, y, mask
+
+
+# ----------------------------------------------------------------------------------------
+# multipass iterations (B:677-740, B:744-812)
+# ----------------------------------------------------------------------------------------
+class _piv_iteration:
+    mode = None
+
+    def __init__(self, frame_shape, wind_size, overlap, device) -> None:
+        self.frame_shape = (int(frame_shape[-2]), int(frame_shape[-1]))
+        self.wind_size, self.overlap = int(wind_size), int(overlap)
+        self.n_rows, self.n_cols = get_field_shape(self.frame_shape, self.wind_size, self.overlap)
+        self.device = _require_gpu(DeviceMap.devicies[device] if not isinstance(device, torch.device)
+                                   else device)
+        self.x, self.y = get_coordinates(self.frame_shape, self.wind_size, self.overlap)
+        self.slice_x, self.slice_y = self.x[0, :], self.y[:, 0]
+        self._ops = {}
+
+    def _operators(self, y0, x0):
+        key = (y0[:, 0].tobytes(), x0[0, :].tobytes())
+        if key not in self._ops:
+            Ay = torch.from_numpy(engine.spline_matrix(y0[:, 0], self.slice_y)).to(self.device)
+            Ax = torch.from_numpy(engine.spline_matrix(x0[0, :], self.slice_x)).to(self.device)
+            self._ops = {key: (Ay, Ax)}
+        return self._ops[key]
+
+    def __call__(self, frame_a, frame_b, x0, y0, u0, v0, validation_mask):
+        Ay, Ax = self._operators(np.asarray(y0, dtype=np.float64), np.asarray(x0, dtype=np.float64))
+        dev = self.device
+        validate = validation_mask is not None
+        inv_c = (torch.from_numpy(np.ascontiguousarray(validation_mask).astype(np.uint8)) if validate
+                 else torch.zeros(u0.shape, dtype=torch.uint8))
+        u_c = torch.from_numpy(np.ascontiguousarray(u0, dtype=np.float64)).to(dev)[None]
+        v_c = torch.from_numpy(np.ascontiguousarray(v0, dtype=np.float64)).to(dev)[None]
+        p_u0, p_v0, p_u2, p_v2 = engine.predict(self.mode, Ay, Ax, u_c, v_c, inv_c.to(dev)[None])
+        # validate=False: the reference skips the peak-ratio test (val stays None)
+        ratio = 1.2 if validate else float("-inf")
+        u, v, inv = engine.iterate(self.mode, frame_a.to(dev), frame_b.to(dev), self.wind_size,
+                                   self.overlap, p_u0, p_v0, p_u2, p_v2, val_ratio=ratio)
+        val = inv[0].cpu().numpy().astype(bool) if validate else None
+        return u[0].cpu().numpy(), v[0].cpu().numpy(), self.x, self.y, val
+
+
+class piv_iteration_CWS(_piv_iteration):
+    """Continuous (bilinear) window shift iteration, B:677-740."""
+    mode = "CWS"
+
+
+class piv_iteration_DWS(_piv_iteration):
+    """Discrete (integer) window shift iteration, B:744-812."""
+    mode = "DWS"
+
+
+class IterModMap:
+    functions = {"DWS": piv_iteration_DWS, "CWS": piv_iteration_CWS}
+
+
+# ----------------------------------------------------------------------------------------
+# post-validation on the host (B:266-344, B:884-892)
+# ----------------------------------------------------------------------------------------
+def nan_helper(y):
+    return np.isnan(y), lambda z: z.nonzero()[0]
+
+
+def interpolate_boarders(vec: np.ndarray) -> np.ndarray:
+    """Linear 1-D interpolation of NaNs along the four borders (an all-NaN border is left)."""
+    if not np.isnan(vec).any():
+        return vec
+    for line in (vec[0, :], vec[-1, :], vec[:, 0], vec[:, -1]):      # views: edits land in vec
+        nans = np.isnan(line)
+        if not nans.all():
+            idx = np.arange(line.size)
+            line[nans] = np.interp(idx[nans], idx[~nans], line[~nans])
+    return vec
+
+
+def getPixelsForInterp(img):
+    """(ring, invalid): ring = valid cells 4-adjacent to an invalid (NaN) cell.  The reference
+    dilates with OpenCV's 3x3 MORPH_ELLIPSE element, which is the 4-connected cross, with a
+    constant zero border (B:275-279)."""
+    invalid = np.isnan(img)
+    dil = invalid.copy()
+    dil[1:, :] |= invalid[:-1, :]
+    dil[:-1, :] |= invalid[1:, :]
+    dil[:, 1:] |= invalid[:, :-1]
+    dil[:, :-1] |= invalid[:, 1:]
+    return dil & ~invalid, invalid
+
+
+def fillMissingValues(target_for_interp, interpolator=None):
+    """Fill NaN holes by Delaunay-linear interpolation from the ring of valid neighbours.
+    Returns None when that fails -- including, as in the reference, when there is no invalid
+    vector at all (no points -> the interpolator raises -> bare except, B:300-304) -- or when
+    at least a quarter of the cells would be ring points ('too many false vectors')."""
+    if interpolator is None:
+        from scipy import interpolate
+        interpolator = interpolate.LinearNDInterpolator
+    ring, invalid = getPixelsForInterp(target_for_interp)
+    points = np.argwhere(ring)
+    values = target_for_interp[ring]
+    if points.size < ring.size / 2:
+        try:
+            interp = interpolator(points, values)
+            target_for_interp[invalid] = interp(np.argwhere(invalid))
+        except Exception:
+            return None
+    else:
+        print("Warning! to many false vectors")
+        return None
+    return target_for_interp
+
+
+def post_validate(u, v, val):
+    """B:884-892: NaN-out invalid vectors, interpolate borders, fill holes.  (None, None) when
+    the pair has to be dropped."""
+    if val is not None:
+        u[val] = np.nan
+        v[val] = np.nan
+        u = interpolate_boarders(u)
+        v = interpolate_boarders(v)
+        u = fillMissingValues(u)
+        v = fillMissingValues(v)
+        if u is None or v is None:
+            return None, None
+    return u, v
+
+
+def free_cuda_memory():
+    torch.cuda.empty_cache()
+
+
+# ----------------------------------------------------------------------------------------
+# the generator API (B:824-903)
+# ----------------------------------------------------------------------------------------
+class OfflinePIV:
+    """for x, y, u, v in OfflinePIV(folder, device, file_fmt, wind_size, overlap, ...)(): ...
+
+    Same constructor signature, defaults, __len__ and generator protocol as the reference:
+    yields float64 numpy arrays [n_rows, n_cols] of the last pass; u is flipped along axis 0
+    and v flipped and negated; u, v are scaled by scale/dt*1000 and x, y by scale; pairs that
+    cannot be decoded or whose hole fill fails are skipped silently.
+    """
+
+    verbose = False          # the reference prints timing lines to stdout; off by default here
+
+    def __init__(self, folder: str, device: str, file_fmt: str, wind_size: int, overlap: int,
+                 multipass: int = 1, multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.,
+                 multipass_scale: float = 2., folder_mode: str = "pairs") -> None:
+        self._wind_size = wind_size
+        self._overlap = overlap
+        self._dt = dt
+        self._iter = multipass
+        self._iter_scale = multipass_scale
+        self._scale = scale
+        self._device = DeviceMap.devicies[device]                       # KeyError like B:845
+        self._dataset = PIVDataset(folder, file_fmt, folder_mode, transform=ToTensor(dtype=torch.uint8))
+        self._iter_function = IterModMap.functions[multipass_mode]      # KeyError like B:850
+        self._mode = multipass_mode
+        self._plan = None
+        if not self:
+            return
+        _require_gpu(self._device)
+
+    def __len__(self) -> int:
+        return len(self._dataset)
+
+    def _get_plan(self, H, W, max_batch=1):
+        if (self._plan is None or (self._plan.H, self._plan.W) != (H, W)
+                or self._plan.max_batch < max_batch):
+            if self._plan is not None:
+                self._plan.close()
+            self._plan = engine.Plan(H, W, int(self._wind_size), int(self._overlap),
+                                     n_pass=max(1, int(self._iter)), mode=self._mode,
+                                     pass_scale=self._iter_scale, max_batch=max_batch,
+                                     device=self._device)
+        return self._plan
+
+    def _finish(self, u, v, val, x, y):
+        u, v = post_validate(u, v, val)
+        if u is None:
+            return None
+        u = np.flip(u, axis=0)
+        v = -np.flip(v, axis=0)
+        u = u * self._scale / self._dt * 1000
+        v = v * self._scale / self._dt * 1000
+        return x * self._scale, y * self._scale, u, v
+
+    def __call__(self) -> Generator:
+        end_time = time()
+        for i in range(len(self._dataset)):
+            a, b = self._dataset[i]
+            if a is None or b is None:
+                continue
+            if self.verbose:
+                print(f"Load time {(time() - end_time):.3f} sec", end=" ")
+            start = time()
+            a = a.to(self._device, non_blocking=True)
+            b = b.to(self._device, non_blocking=True)
+            plan = self._get_plan(a.shape[-2], a.shape[-1])
+            u, v, inv = plan.run(a, b)
+            w, o, _, _ = plan.geometry[-1]
+            x, y = get_coordinates(a.shape, w, o)
+            out = self._finish(u[0].cpu().numpy(), v[0].cpu().numpy(),
+                               inv[0].cpu().numpy().astype(bool), x, y)
+            if out is None:
+                continue
+            yield out
+            end_time = time()
+            if self.verbose:
+                print(f"Batch finished in {(end_time - start):.3f} sec")
+
+    # ---- extension: batched processing (same results, many pairs per launch) ------------
+    def batched(self, batch_size: int = 32, indices=None) -> Generator:
+        """Like __call__, but uploads and processes `batch_size` pairs per launch.  Yields
+        (pair_index, x, y, u, v); dropped pairs yield nothing."""
+        idx = list(range(len(self._dataset))) if indices is None else list(indices)
+        for s in range(0, len(idx), batch_size):
+            chunk, A, B = [], [], []
+            for i in idx[s:s + batch_size]:
+                a, b = self._dataset[i]
+                if a is None or b is None:
+                    continue
+                chunk.append(i)
+                A.append(a)
+                B.append(b)
+            if not chunk:
+                continue
+            A = torch.stack(A).pin_memory().to(self._device, non_blocking=True)
+            B = torch.stack(B).pin_memory().to(self._device, non_blocking=True)
+            plan = self._get_plan(A.shape[-2], A.shape[-1], max_batch=batch_size)
+            u, v, inv = plan.run(A, B)
+            w, o, _, _ = plan.geometry[-1]
+            x, y = get_coordinates(A.shape[-2:], w, o)
+            u, v, inv = u.cpu().numpy(), v.cpu().numpy(), inv.cpu().numpy().astype(bool)
+            for k, i in enumerate(chunk):
+                out = self._finish(u[k], v[k], inv[k], x, y)
+                if out is not None:
+                    yield (i,) + out

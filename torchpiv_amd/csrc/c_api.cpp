@@ -194,9 +194,27 @@ struct tpiv_plan {
     std::vector<double*> Ay, Ax;         // per pass p >= 1: operators from pass p-1 to p
     double *u0 = nullptr, *v0 = nullptr, *u2 = nullptr, *v2 = nullptr, *T = nullptr;
     std::vector<void*> allocs;
+    // optional per-kernel timing: events[run][2*slot + {0,1}]
+    bool timing = false;
+    std::vector<std::vector<hipEvent_t>> events;
+    size_t runs_recorded = 0;
 
     ~tpiv_plan() {
         for (void* p : allocs) (void)hipFree(p);
+        for (auto& r : events)
+            for (hipEvent_t e : r) (void)hipEventDestroy(e);
+    }
+    int n_slots() const { return 2 * n_pass - 1; }
+    // event for (current run, slot, begin/end); nullptr when timing is off or the record is full
+    hipEvent_t ev(int slot, int end) {
+        if (!timing || runs_recorded >= 512) return nullptr;
+        if (events.size() <= runs_recorded) {
+            std::vector<hipEvent_t> r(2 * n_slots(), nullptr);
+            for (auto& e : r)
+                if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            events.push_back(std::move(r));
+        }
+        return events[runs_recorded][2 * slot + end];
     }
     template <typename T_>
     int alloc(T_** out, size_t count) {
@@ -499,6 +517,11 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
     HIP_TRY(hipGetDevice(&dev));
     if (dev != plan->device) return fail(TPIV_EINVAL, "plan was created on another device");
     const int last = plan->n_pass - 1;
+    hipStream_t st = (hipStream_t)stream;
+    auto mark = [&](int slot, int end) {
+        hipEvent_t e = plan->ev(slot, end);
+        if (e) (void)hipEventRecord(e, st);
+    };
     for (int p = 0; p <= last; ++p) {
         const PassGeo& g = plan->geo[p];
         double* pu = p == last ? u : plan->u[p];
@@ -506,20 +529,53 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
         uint8_t* pval = p == last ? invalid : plan->val[p];
         int rc;
         if (p == 0) {
+            mark(0, 0);
             rc = tpiv_pass1(a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->val_ratio, plan->val_win, pu,
                             pv, pval, stream);
+            mark(0, 1);
         } else {
             const PassGeo& c = plan->geo[p - 1];
+            mark(2 * p - 1, 0);
             rc = tpiv_predict(plan->mode, batch, c.n_rows, c.n_cols, g.n_rows, g.n_cols, plan->Ay[p],
                               plan->Ax[p], plan->u[p - 1], plan->v[p - 1], plan->val[p - 1], plan->T,
                               plan->u0, plan->v0, plan->u2, plan->v2, stream);
+            mark(2 * p - 1, 1);
+            mark(2 * p, 0);
             if (!rc)
                 rc = tpiv_iter(plan->mode, a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->u0, plan->v0,
                                plan->u2, plan->v2, plan->val_ratio, plan->val_win, pu, pv, pval, nullptr,
                                nullptr, stream);
+            mark(2 * p, 1);
         }
         if (rc) return rc;
     }
+    if (plan->timing && plan->runs_recorded < 512) plan->runs_recorded++;
+    return TPIV_OK;
+}
+
+int tpiv_plan_set_timing(tpiv_plan* plan, int enable) {
+    if (!plan) return fail(TPIV_EINVAL, "null plan");
+    plan->timing = enable != 0;
+    plan->runs_recorded = 0;
+    return TPIV_OK;
+}
+
+int tpiv_plan_get_timing(tpiv_plan* plan, double* avg_ms, int n_slots, int* n_runs) {
+    if (!plan || !avg_ms || n_slots != plan->n_slots()) return fail(TPIV_EINVAL, "bad timing query");
+    for (int s = 0; s < n_slots; ++s) avg_ms[s] = 0.0;
+    const size_t n = plan->runs_recorded;
+    for (size_t r = 0; r < n; ++r) {
+        for (int s = 0; s < n_slots; ++s) {
+            float ms = 0.f;
+            HIP_TRY(hipEventSynchronize(plan->events[r][2 * s + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, plan->events[r][2 * s], plan->events[r][2 * s + 1]));
+            avg_ms[s] += ms;
+        }
+    }
+    if (n)
+        for (int s = 0; s < n_slots; ++s) avg_ms[s] /= (double)n;
+    if (n_runs) *n_runs = (int)n;
+    plan->runs_recorded = 0;
     return TPIV_OK;
 }
 

@@ -1,0 +1,104 @@
+"""Multi-GPU layer: image pairs are independent (PIVbackend.py:868-901 carries no state from
+one pair to the next), so they shard across ranks with no data-path collective; the only
+communication is ONE gather of the finished (u, v) fields at the end of the stream.
+
+One process per GPU, torch.distributed with backend "nccl" (= RCCL over xGMI on ROCm) on the
+GPU box and "gloo" in the CPU tests.  Dropped pairs (the reference's hole-fill quirk) make the
+shard sizes data dependent, so a small count exchange precedes the payload.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns
+    (rank, world, local_rank).  No-op for single-process runs."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_pairs: int, rank: int, world: int, policy: str = "block"):
+    """Pair indices owned by `rank`.  'block': contiguous ceil(n/world) runs (keeps file reads
+    sequential per rank); 'cyclic': i % world == rank (balances a stream of unknown length)."""
+    if policy == "cyclic":
+        return list(range(rank, n_pairs, world))
+    per = (n_pairs + world - 1) // world
+    return list(range(min(rank * per, n_pairs), min((rank + 1) * per, n_pairs)))
+
+
+def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=None):
+    """Gather variable-length shards onto rank `dst`.
+
+    ids    int64 [n_local]            dataset index of every field this rank produced
+    fields       [n_local, C, R, S]   e.g. C = 2 for (u, v); same dtype/shape tail on all ranks
+    Returns (ids_all, fields_all) sorted by dataset index on `dst`, (None, None) elsewhere.
+    One count all-gather (8 bytes per rank) + one padded payload all-gather: on xGMI's full mesh
+    every rank's shard goes out on all seven links at once instead of hopping round a ring.
+    """
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        order = torch.argsort(ids)
+        return ids[order], fields[order]
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = fields.device
+    n_local = torch.tensor([ids.numel()], dtype=torch.int64, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, n_local, group=group)
+    n_max = int(counts.max().item())
+    tail = tuple(fields.shape[1:])
+    pad_f = torch.zeros((n_max,) + tail, dtype=fields.dtype, device=dev)
+    pad_i = torch.full((n_max,), -1, dtype=torch.int64, device=dev)
+    pad_f[: ids.numel()] = fields
+    pad_i[: ids.numel()] = ids.to(dev)
+    all_f = torch.empty((world * n_max,) + tail, dtype=fields.dtype, device=dev)
+    all_i = torch.empty(world * n_max, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_f, pad_f, group=group)
+    dist.all_gather_into_tensor(all_i, pad_i, group=group)
+    if rank != dst:
+        return None, None
+    keep = all_i >= 0
+    all_i, all_f = all_i[keep], all_f[keep]
+    order = torch.argsort(all_i)
+    return all_i[order], all_f[order]
+
+
+def run_sharded(piv, batch_size: int = 32, policy: str = "block", group=None):
+    """Process an OfflinePIV dataset across all ranks.  Every rank runs its shard through
+    piv.batched(); rank 0 returns (ids, x, y, uv[n, 2, R, S]) for the pairs that survived,
+    in dataset order; other ranks return None."""
+    import numpy as np
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = shard_indices(len(piv), rank, world, policy)
+    ids, uv, xy = [], [], None
+    for i, x, y, u, v in piv.batched(batch_size, indices=mine):
+        ids.append(i)
+        uv.append(np.stack([u, v]))
+        xy = (x, y)
+    dev = piv._device
+    if uv:
+        f = torch.from_numpy(np.stack(uv)).to(dev)
+    else:
+        plan_shape = piv._plan.out_shape if piv._plan is not None else (0, 0)
+        f = torch.zeros((0, 2) + tuple(plan_shape), dtype=torch.float64, device=dev)
+    i_all, f_all = gather_fields(torch.tensor(ids, dtype=torch.int64, device=dev), f, group=group)
+    if rank != 0:
+        return None
+    return i_all.cpu().numpy(), xy, f_all.cpu().numpy()

@@ -201,6 +201,21 @@ class Plan:
                                     v.data_ptr(), inv.data_ptr(), _stream()))
         return u, v, inv
 
+    def set_timing(self, enable: bool):
+        """Bracket every kernel of run() with hipEvents on the launch stream (bench.py)."""
+        check(lib.tpiv_plan_set_timing(self._h, 1 if enable else 0))
+
+    def get_timing(self):
+        """({slot name: mean ms}, n_runs) for the runs since the last call; waits for them."""
+        n = 2 * self.n_pass - 1
+        arr = (C.c_double * n)()
+        runs = C.c_int()
+        check(lib.tpiv_plan_get_timing(self._h, arr, n, C.byref(runs)))
+        names = ["pass1_xcorr"]
+        for p in range(1, self.n_pass):
+            names += [f"pass{p + 1}_predict", f"pass{p + 1}_xcorr"]
+        return dict(zip(names, list(arr))), runs.value
+
     def pass_fields(self, p, batch):
         """Fields pass p (< n_pass-1) left in the workspace by the last run (copies)."""
         pu, pv, pi = C.c_void_p(), C.c_void_p(), C.c_void_p()
