@@ -17,6 +17,9 @@
 #else
 #define TPIV_HD inline
 #endif
+// the bodies handed to static_for must be inlined, or the register arrays they touch get
+// their address taken and end up in scratch memory
+#define TPIV_LAMBDA_INLINE __attribute__((always_inline))
 
 namespace tpiv {
 
@@ -37,6 +40,11 @@ constexpr int fft_pos(int k, int n) {
     if (radix2_first(n)) return (k % 2) * (n / 2) + fft_pos(k / 2, n / 2);
     return (k % 4) * (n / 4) + fft_pos(k / 4, n / 4);
 }
+
+// compile-time constant form: indexing a register array with fft_pos(k, n) directly would
+// leave a run-time call to the (recursive) function and push the array into scratch
+template <int K, int N>
+inline constexpr int FFT_POS = fft_pos(K, N);
 
 template <int J, int END, typename F>
 TPIV_HD void static_for(F&& f) {
@@ -73,7 +81,7 @@ struct FFTStage {
             x[OFF] = cadd(a, b);
             x[OFF + 1] = csub(a, b);
         } else if constexpr (radix2_first(N)) {
-            static_for<0, N / 2>([&](auto jc) {
+            static_for<0, N / 2>([&](auto jc) TPIV_LAMBDA_INLINE {
                 constexpr int j = decltype(jc)::value;
                 cf a = x[OFF + j], b = x[OFF + j + N / 2];
                 x[OFF + j] = cadd(a, b);
@@ -82,7 +90,7 @@ struct FFTStage {
             FFTStage<N / 2, OFF, DIR, TOTAL>::run(x);
             FFTStage<N / 2, OFF + N / 2, DIR, TOTAL>::run(x);
         } else if constexpr (N >= 4) {
-            static_for<0, N / 4>([&](auto jc) {
+            static_for<0, N / 4>([&](auto jc) TPIV_LAMBDA_INLINE {
                 constexpr int j = decltype(jc)::value;
                 cf a = x[OFF + j], b = x[OFF + j + N / 4], c = x[OFF + j + N / 2],
                    d = x[OFF + j + 3 * N / 4];

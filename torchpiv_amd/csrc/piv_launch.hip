@@ -6,21 +6,19 @@
 
 namespace tpiv {
 
-template <int WS>
-hipError_t launch_xcorr_ws(const PassParams& p, int mode, int n_cu, hipStream_t stream);
-extern template hipError_t launch_xcorr_ws<8>(const PassParams&, int, int, hipStream_t);
-extern template hipError_t launch_xcorr_ws<16>(const PassParams&, int, int, hipStream_t);
-extern template hipError_t launch_xcorr_ws<32>(const PassParams&, int, int, hipStream_t);
-extern template hipError_t launch_xcorr_ws<64>(const PassParams&, int, int, hipStream_t);
-extern template hipError_t launch_xcorr_ws<128>(const PassParams&, int, int, hipStream_t);
+hipError_t launch_xcorr_ws8(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+hipError_t launch_xcorr_ws16(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+hipError_t launch_xcorr_ws32(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+hipError_t launch_xcorr_ws64(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+hipError_t launch_xcorr_ws128(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream) {
     switch (p.ws) {
-        case 8: return launch_xcorr_ws<8>(p, mode, n_cu, stream);
-        case 16: return launch_xcorr_ws<16>(p, mode, n_cu, stream);
-        case 32: return launch_xcorr_ws<32>(p, mode, n_cu, stream);
-        case 64: return launch_xcorr_ws<64>(p, mode, n_cu, stream);
-        case 128: return launch_xcorr_ws<128>(p, mode, n_cu, stream);
+        case 8: return launch_xcorr_ws8(p, mode, n_cu, stream);
+        case 16: return launch_xcorr_ws16(p, mode, n_cu, stream);
+        case 32: return launch_xcorr_ws32(p, mode, n_cu, stream);
+        case 64: return launch_xcorr_ws64(p, mode, n_cu, stream);
+        case 128: return launch_xcorr_ws128(p, mode, n_cu, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -272,9 +272,9 @@ __global__ __launch_bounds__(Geo<WS>::TPB, (WS <= 32 ? 2 : 1)) void xcorr_kernel
         fft_inreg<WS, 1>(x);
         // transpose through LDS: tile[ky][kx-as-column c]
         __syncthreads();
-        static_for<0, WS>([&](auto kc) {
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
             constexpr int ky = decltype(kc)::value;
-            my_tile[ky * PITCH + c] = x[fft_pos(ky, WS)];
+            my_tile[ky * PITCH + c] = x[FFT_POS<ky, WS>];
         });
         __syncthreads();
         // lane now owns row ky = c
@@ -285,38 +285,38 @@ __global__ __launch_bounds__(Geo<WS>::TPB, (WS <= 32 ? 2 : 1)) void xcorr_kernel
         // ---- cross-spectrum.  With Z = FFT2(a + i b):  A = (Z(k) + conj Z(-k))/2,
         //      B = (Z(k) - conj Z(-k))/(2i),  P = conj(A) * B.  Z(-k) lives in lane (-c mod WS).
         __syncthreads();
-        static_for<0, WS>([&](auto kc) {
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
             constexpr int kx = decltype(kc)::value;
-            my_tile[c * PITCH + kx] = x[fft_pos(kx, WS)];
+            my_tile[c * PITCH + kx] = x[FFT_POS<kx, WS>];
         });
         __syncthreads();
         {
             const int nr = (WS - c) % WS;
             constexpr float scale = 0.25f / (float)(WS * WS);     // 1/4 of the split, 1/n^2 of irfft2
-            static_for<0, WS>([&](auto kc) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int kx = decltype(kc)::value;
                 constexpr int nkx = (WS - kx) % WS;
-                const cf zk = x[fft_pos(kx, WS)];
+                const cf zk = x[FFT_POS<kx, WS>];
                 const cf zm = my_tile[nr * PITCH + nkx];
                 const float a_ = zk.x, b_ = zk.y, c_ = zm.x, d_ = zm.y;
                 cf pr;
                 pr.x = ((a_ + c_) * (b_ + d_) + (b_ - d_) * (c_ - a_)) * scale;
                 pr.y = ((c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_)) * scale;
-                x[fft_pos(kx, WS)] = pr;
+                x[FFT_POS<kx, WS>] = pr;
             });
         }
         // ---- inverse: row IFFT needs natural order input -> permute in registers
         {
             cf t[WS];
-            static_for<0, WS>([&](auto kc) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int kx = decltype(kc)::value;
-                t[kx] = x[fft_pos(kx, WS)];
+                t[kx] = x[FFT_POS<kx, WS>];
             });
             fft_inreg<WS, -1>(t);         // over kx -> spatial x at t[fft_pos(xs)]
             __syncthreads();
-            static_for<0, WS>([&](auto kc) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int xs = decltype(kc)::value;
-                my_tile[c * PITCH + xs] = t[fft_pos(xs, WS)];     // tile[ky = c][x]
+                my_tile[c * PITCH + xs] = t[FFT_POS<xs, WS>];     // tile[ky = c][x]
             });
         }
         __syncthreads();
@@ -329,18 +329,18 @@ __global__ __launch_bounds__(Geo<WS>::TPB, (WS <= 32 ? 2 : 1)) void xcorr_kernel
         // ---- correlation map in fftshift coordinates: y' = (y + WS/2) % WS, x' = (c + WS/2) % WS
         const int xs = (c + WS / 2) % WS;
         float cmin = 3.4e38f;
-        static_for<0, WS>([&](auto kc) {
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
             constexpr int y = decltype(kc)::value;
-            cmin = fminf(cmin, x[fft_pos(y, WS)].x);
+            cmin = fminf(cmin, x[FFT_POS<y, WS>].x);
         });
         cmin = group_min<WS>(cmin, scratch);
         ArgMax best{-1.f, 0};
-        static_for<0, WS>([&](auto kc) {
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
             constexpr int ysft = decltype(kc)::value;           // shifted row, ascending
             constexpr int y = (ysft + WS / 2) % WS;
             // B:518 corr - min ; B:381 corr += eps (float32 in passes >= 2)
-            float v = __fadd_rn(__fsub_rn(x[fft_pos(y, WS)].x, cmin), 1e-7f);
-            x[fft_pos(y, WS)].x = v;
+            float v = __fadd_rn(__fsub_rn(x[FFT_POS<y, WS>].x, cmin), 1e-7f);
+            x[FFT_POS<y, WS>].x = v;
             my_map[ysft * WS + xs] = v;
             if (v > best.v) {
                 best.v = v;
@@ -376,14 +376,14 @@ __global__ __launch_bounds__(Geo<WS>::TPB, (WS <= 32 ? 2 : 1)) void xcorr_kernel
             const bool col_in = a_ <= 2 * wv;
             const bool zero_hit = (m - wv - wv * WS) <= 0;             // clamp sends some index to 0
             const bool last_hit = (m + wv + wv * WS) >= KD - 1;        // ... or to KD-1
-            static_for<0, WS>([&](auto kc) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int ysft = decltype(kc)::value;
                 constexpr int y = (ysft + WS / 2) % WS;
                 const int q = ysft * WS + xs;
                 const int jj = ysft - my_ + wv + jadj;
                 bool excl = col_in && (jj >= 0) && (jj <= 2 * wv);
                 excl = excl || (q == 0 && zero_hit) || (q == KD - 1 && last_hit);
-                const float v = x[fft_pos(y, WS)].x;
+                const float v = x[FFT_POS<y, WS>].x;
                 if (!excl && v > second.v) {
                     second.v = v;
                     second.idx = q;

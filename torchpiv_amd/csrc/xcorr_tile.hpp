@@ -1,0 +1,602 @@
+// Fused PIV tile kernel, second generation (tile sizes 8..64) for gfx950 (MI355X).
+//
+// Replaces the ATen kernel sequences of the reference's extended_search_area_piv
+// (PIVbackend.py:459-520), piv_iteration_DWS/CWS.__call__ (B:757-812 / B:690-740),
+// interpolation_DWS (B:197-216), biliniar_interpolation_CWS (B:147-194), correalte_fft
+// (B:249-257), correlation_to_displacement (B:360-422) and peak2peak_secondpeak (B:346-358)
+// with ONE launch per pass: uint8 frames in HBM -> (u, v, invalid) per window.
+//
+// Mapping (one 64-lane wavefront = one workgroup = 64/WS windows):
+//   * lane = one image ROW of one window.  The row (WS bytes per frame) is fetched with
+//     16-byte loads straight into VGPRs; overlapping windows re-read through L2 (the item order
+//     keeps neighbouring windows on one XCD).  Both frames are packed as a + i*b.
+//   * all 1-D FFTs (WS points) run per lane, entirely in registers (fft_inreg.hpp).
+//   * LDS is used only to transpose between the row and the column transform, in 32x33 (or
+//     WSx(WS+1)) complex tiles; a 64x64 tile is transposed as four 32x32 blocks after a
+//     v_permlane32_swap of the off-diagonal blocks, so a wavefront needs 16.9 KB of LDS
+//     instead of 33 KB and two wavefronts fit per SIMD.
+//   * the k <-> -k partner of the packed spectrum is fetched with ds_bpermute (no LDS memory).
+//   * peak search / validation reduce with wavefront shuffles; the map is parked in LDS for
+//     the five neighbour reads of the sub-pixel fit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft_inreg.hpp"
+#include "piv_kernels.h"
+
+namespace tpiv {
+
+template <int WS>
+struct TileGeo {
+    static constexpr int WPW = 64 / WS;                 // windows per wavefront
+    static constexpr int TS = WS > 32 ? 32 : WS;        // transposition tile edge
+    static constexpr int PITCH = TS + 1;                // complex elements per tile row
+    static constexpr int NT = 64 / TS;                  // tiles per wavefront
+    static constexpr int TILE = TS * PITCH;             // complex elements per tile
+    static constexpr int LDS_CF = NT * TILE;            // complex elements of LDS per wavefront
+    static constexpr int MAP_PITCH = WS + 1;            // floats per row of the correlation map
+    static constexpr int NDW = WS / 4;                  // dwords per window row
+};
+
+struct ArgMaxT {
+    float v;
+    int idx;
+};
+
+__device__ __forceinline__ ArgMaxT better_t(ArgMaxT a, ArgMaxT b) {
+    // larger value wins; equal values: smaller flat index (torch.argmax returns the first)
+    const bool takeb = (b.v > a.v) || (b.v == a.v && b.idx < a.idx);
+    return takeb ? b : a;
+}
+
+template <int WS>
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+    for (int off = WS / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int WS>
+__device__ __forceinline__ float grp_min(float v) {
+#pragma unroll
+    for (int off = WS / 2; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+template <int WS>
+__device__ __forceinline__ ArgMaxT grp_argmax(ArgMaxT a) {
+#pragma unroll
+    for (int off = WS / 2; off >= 1; off >>= 1) {
+        ArgMaxT o;
+        o.v = __shfl_xor(a.v, off, 64);
+        o.idx = __shfl_xor(a.idx, off, 64);
+        a = better_t(a, o);
+    }
+    return a;
+}
+
+__device__ __forceinline__ double nan_to_num_t(double x) {      // torch.nan_to_num_ defaults, B:418-419
+    if (x != x) return 0.0;
+    if (x > 1.7976931348623157e308) return 1.7976931348623157e308;
+    if (x < -1.7976931348623157e308) return -1.7976931348623157e308;
+    return x;
+}
+
+__device__ __forceinline__ float fetch_clamped_t(const uint8_t* __restrict__ f, long long q, int HW) {
+    q = q < 0 ? 0 : (q > (long long)(HW - 1) ? (long long)(HW - 1) : q);      // B:177-180, B:214
+    return (float)f[q];
+}
+
+__device__ __forceinline__ int f2i_sat_t(float v) {
+    v = fminf(fmaxf(v, -1073741824.f), 1073741824.f);
+    return (int)v;
+}
+
+// byte k of a row held as dwords (compile-time k -> v_cvt_f32_ubyteN)
+template <int K, int N>
+__device__ __forceinline__ float byte_f(const uint32_t (&d)[N]) {
+    return (float)((d[K >> 2] >> (8 * (K & 3))) & 0xffu);
+}
+
+// N dwords from a byte address of any alignment (global memory takes unaligned dword loads)
+template <int N>
+__device__ __forceinline__ void load_dwords(const uint8_t* __restrict__ p, uint32_t (&d)[N]) {
+    __builtin_memcpy(&d[0], p, 4 * N);
+}
+
+// One bilinear sample exactly as PIVbackend.py:187-193 evaluates it in float32: every product
+// and sum rounded separately, left to right -- FMA contraction must stay off in here.
+__device__ __forceinline__ float bilerp_ref(float f11, float f21, float f12, float f22, float wx_up,
+                                            float wx_dn, float wy_up, float wy_dn, bool degenerate) {
+#pragma clang fp contract(off)
+    float r = (f11 * wx_up) * wy_up;
+    r = r + (f21 * wx_dn) * wy_up;
+    r = r + (f12 * wx_up) * wy_dn;
+    r = r + (f22 * wx_dn) * wy_dn;
+    return degenerate ? f11 : r;          // B:170, B:193: either coordinate integral -> f(floor y, floor x)
+}
+
+// ---- transposition of the wavefront's tile(s) through LDS ---------------------------------
+// in:  lane (w, i) holds line i of its window, element k at in[POS(k)]  (POS = digit-reversed
+//      position when DIGITREV, else k)
+// out: lane (w, j) holds element j of every line: out[i] = element (line i, position j)
+template <int WS, bool DIGITREV>
+__device__ __forceinline__ void transpose_tile(cf (&a)[WS], cf* tile, int lane) {
+    using G = TileGeo<WS>;
+    constexpr int P = G::PITCH;
+    if constexpr (WS <= 32) {
+        cf* t = tile + (lane / WS) * G::TILE;
+        const int i = lane % WS;
+        __syncthreads();
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            constexpr int src = DIGITREV ? FFT_POS<k, WS> : k;
+            t[i * P + k] = a[src];
+        });
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < WS; ++r) a[r] = t[r * P + i];
+    } else {
+        // 64x64 = 2x2 blocks of 32x32: swap the off-diagonal blocks between the lane halves,
+        // then transpose the four blocks, two at a time, through the two 32x33 tiles
+        static_for<0, 32>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            constexpr int lo = DIGITREV ? FFT_POS<k, WS> : k;
+            constexpr int hi = DIGITREV ? FFT_POS<k + 32, WS> : k + 32;
+            auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[lo].x), __float_as_uint(a[hi].x),
+                                                       false, false);
+            auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[lo].y), __float_as_uint(a[hi].y),
+                                                       false, false);
+            a[lo].x = __uint_as_float(rx[0]);
+            a[hi].x = __uint_as_float(rx[1]);
+            a[lo].y = __uint_as_float(ry[0]);
+            a[hi].y = __uint_as_float(ry[1]);
+        });
+        cf* t = tile + (lane >> 5) * G::TILE;
+        const int i = lane & 31;
+        cf lowhalf[32];
+        __syncthreads();
+        static_for<0, 32>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            constexpr int src = DIGITREV ? FFT_POS<k, WS> : k;
+            t[i * P + k] = a[src];
+        });
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 32; ++r) lowhalf[r] = t[r * P + i];
+        __syncthreads();
+        static_for<0, 32>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            constexpr int src = DIGITREV ? FFT_POS<k + 32, WS> : k + 32;
+            t[i * P + k] = a[src];
+        });
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 32; ++r) a[32 + r] = t[r * P + i];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) a[r] = lowhalf[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int WS, int MODE>
+__global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
+    using G = TileGeo<WS>;
+    static_assert(WS == 8 || WS == 16 || WS == 32 || WS == 64, "tile sizes of this kernel");
+    __shared__ cf tile[G::LDS_CF];
+
+    const int lane = threadIdx.x;
+    const int w = lane / WS;          // window slot inside the wavefront
+    const int r = lane % WS;          // image row of the window held by this lane (then: column / line)
+    const int grp0 = lane - r;        // first lane of this window
+
+    const int N = p.n_rows * p.n_cols;
+    const int groups = (N + G::WPW - 1) / G::WPW;
+    const long long items = (long long)p.batch * groups;
+    const int HW = p.H * p.W;
+    const int st = p.ws - p.ov;
+
+    // XCD-aware item order: workgroups b, b+8, ... share an XCD (and its L2); give every XCD one
+    // contiguous run of windows so that overlapping windows re-read the frame from the same L2.
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int per_xcd = gridDim.x >> 3;                   // the host launches a multiple of 8
+    const long long chunk = (items + 7) / 8;
+    const long long lo = (long long)xcd * chunk;
+    const long long hi = (lo + chunk < items) ? lo + chunk : items;
+
+    for (long long item = lo + slot; item < hi; item += per_xcd) {
+        const int pair = (int)(item / groups);
+        const int g = (int)(item % groups);
+        const int win_raw = g * G::WPW + w;
+        const bool active = win_raw < N;
+        const int win = active ? win_raw : N - 1;
+        const int wr = win / p.n_cols, wc = win % p.n_cols;
+        const int y0 = wr * st, x0 = wc * st;
+        const uint8_t* __restrict__ fa = p.A + (size_t)pair * HW;
+        const uint8_t* __restrict__ fb = p.B + (size_t)pair * HW;
+        const size_t fidx = (size_t)pair * N + win;
+
+        cf x[WS];
+        float sa = 0.f, sb = 0.f;          // window sums (for the mean)
+
+        // ---- stage 0: this lane's window row -> registers --------------------------------
+        if constexpr (MODE == MODE_PASS1) {
+            uint32_t da[G::NDW], db[G::NDW];
+            const size_t off = (size_t)(y0 + r) * p.W + x0;
+            load_dwords<G::NDW>(fa + off, da);
+            load_dwords<G::NDW>(fb + off, db);
+            unsigned ia = 0, ib = 0;
+#pragma unroll
+            for (int q = 0; q < G::NDW; ++q) {
+                ia = __builtin_amdgcn_sad_u8(da[q], 0u, ia);
+                ib = __builtin_amdgcn_sad_u8(db[q], 0u, ib);
+            }
+            sa = (float)ia;
+            sb = (float)ib;
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                x[k].x = byte_f<k, G::NDW>(da);
+                x[k].y = byte_f<k, G::NDW>(db);
+            });
+        } else if constexpr (MODE == MODE_DWS) {
+            // integer shift on the FLAT index (B:213-215): a at idx - (vy*W + vx), b at idx + (...)
+            const long long sx = (long long)p.u2[fidx], sy = (long long)p.v2[fidx];
+            const long long sh = sy * p.W + sx;
+            const long long base = (long long)(y0 + r) * p.W + x0;
+            const long long qa = base - sh, qb = base + sh;
+            const bool reg = qa >= 0 && qa + WS <= HW && qb >= 0 && qb + WS <= HW;
+            if (__all(reg)) {
+                uint32_t da[G::NDW], db[G::NDW];
+                load_dwords<G::NDW>(fa + qa, da);
+                load_dwords<G::NDW>(fb + qb, db);
+                static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    x[k].x = byte_f<k, G::NDW>(da);
+                    x[k].y = byte_f<k, G::NDW>(db);
+                });
+            } else {          // a row touches the first/last pixel of the frame: per-pixel clamp.
+                // Rare: kept as a rolled loop that parks the row in LDS (no code blow-up).
+                float* rowbuf = reinterpret_cast<float*>(tile) + lane * WS;
+                __syncthreads();
+#pragma unroll 1
+                for (int k = 0; k < WS; ++k) rowbuf[k] = fetch_clamped_t(fa, qa + k, HW);
+#pragma unroll
+                for (int k = 0; k < WS; ++k) x[k].x = rowbuf[k];
+#pragma unroll 1
+                for (int k = 0; k < WS; ++k) rowbuf[k] = fetch_clamped_t(fb, qb + k, HW);
+#pragma unroll
+                for (int k = 0; k < WS; ++k) x[k].y = rowbuf[k];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < WS; ++k) {
+                sa += x[k].x;
+                sb += x[k].y;
+            }
+        } else {
+            // bilinear shift in float32 (B:162-193): frame a by -(vx, vy), frame b by +(vx, vy)
+            const float vx = (float)p.u2[fidx], vy = (float)p.v2[fidx];
+            const float gyf = (float)(y0 + r);
+            const float nya = gyf - vy, nyb = gyf + vy;
+            const float uya_f = ceilf(nya), dya_f = floorf(nya);
+            const float uyb_f = ceilf(nyb), dyb_f = floorf(nyb);
+            const int uya = f2i_sat_t(uya_f), dya = f2i_sat_t(dya_f);
+            const int uyb = f2i_sat_t(uyb_f), dyb = f2i_sat_t(dyb_f);
+            const float wya_up = uya_f - nya, wya_dn = nya - dya_f;
+            const float wyb_up = uyb_f - nyb, wyb_dn = nyb - dyb_f;
+            const bool ydeg_a = uya == dya, ydeg_b = uyb == dyb;
+            const float gx0f = (float)x0;
+            // Fast path: floor(float(gx) + vx) == gx + floor(vx) for every column (true unless
+            // frac(vx) is within float32 rounding of an integer) and all four source rows lie
+            // inside the frame, so that a row is WS+1 consecutive bytes.
+            const float fvx = floorf(vx);
+            const float frac = vx - fvx;
+            const float thr = (float)(p.W + 64) * 4.76837158e-07f;       // (W + 64) * 2^-21
+            const int ivx = f2i_sat_t(fvx);
+            // frame a uses -vx: floor(-vx) = -floor(vx) - 1 when frac != 0
+            const long long qa0 = (long long)dya * p.W + (x0 - ivx - 1);
+            const long long qa1 = (long long)uya * p.W + (x0 - ivx - 1);
+            const long long qb0 = (long long)dyb * p.W + (x0 + ivx);
+            const long long qb1 = (long long)uyb * p.W + (x0 + ivx);
+            constexpr int NB = WS / 4 + 1;                               // dwords covering WS+1 bytes
+            const bool inb = qa0 >= 0 && qa1 + 4 * NB <= HW && qb0 >= 0 && qb1 + 4 * NB <= HW &&
+                             qa1 >= 0 && qa0 + 4 * NB <= HW && qb1 >= 0 && qb0 + 4 * NB <= HW;
+            const bool reg = inb && frac > thr && frac < 1.0f - thr && fabsf(vx) < (float)p.W;
+            if (__all(reg)) {
+                uint32_t a0[NB], a1[NB], b0[NB], b1[NB];
+                load_dwords<NB>(fa + qa0, a0);
+                load_dwords<NB>(fa + qa1, a1);
+                load_dwords<NB>(fb + qb0, b0);
+                load_dwords<NB>(fb + qb1, b1);
+                static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    const float gxf = gx0f + (float)k;                   // exact: small integers
+                    const float nxa = gxf - vx, nxb = gxf + vx;
+                    const float uxa_f = ceilf(nxa), dxa_f = floorf(nxa);
+                    const float uxb_f = ceilf(nxb), dxb_f = floorf(nxb);
+                    x[k].x = bilerp_ref(byte_f<k, NB>(a0), byte_f<k + 1, NB>(a0), byte_f<k, NB>(a1),
+                                        byte_f<k + 1, NB>(a1), uxa_f - nxa, nxa - dxa_f, wya_up, wya_dn,
+                                        ydeg_a || (uxa_f == dxa_f));
+                    x[k].y = bilerp_ref(byte_f<k, NB>(b0), byte_f<k + 1, NB>(b0), byte_f<k, NB>(b1),
+                                        byte_f<k + 1, NB>(b1), uxb_f - nxb, nxb - dxb_f, wyb_up, wyb_dn,
+                                        ydeg_b || (uxb_f == dxb_f));
+                });
+            } else {          // generic per-pixel gather with the flat-index clamp (rare: rolled
+                              // loops that park the row in LDS)
+                float* rowbuf = reinterpret_cast<float*>(tile) + lane * WS;
+                __syncthreads();
+#pragma unroll 1
+                for (int k = 0; k < WS; ++k) {
+                    const float nxa = (gx0f + (float)k) - vx;
+                    const float uxa_f = ceilf(nxa), dxa_f = floorf(nxa);
+                    const int uxa = f2i_sat_t(uxa_f), dxa = f2i_sat_t(dxa_f);
+                    rowbuf[k] = bilerp_ref(fetch_clamped_t(fa, (long long)dya * p.W + dxa, HW),
+                                           fetch_clamped_t(fa, (long long)dya * p.W + uxa, HW),
+                                           fetch_clamped_t(fa, (long long)uya * p.W + dxa, HW),
+                                           fetch_clamped_t(fa, (long long)uya * p.W + uxa, HW), uxa_f - nxa,
+                                           nxa - dxa_f, wya_up, wya_dn, ydeg_a || (uxa == dxa));
+                }
+#pragma unroll
+                for (int k = 0; k < WS; ++k) x[k].x = rowbuf[k];
+#pragma unroll 1
+                for (int k = 0; k < WS; ++k) {
+                    const float nxb = (gx0f + (float)k) + vx;
+                    const float uxb_f = ceilf(nxb), dxb_f = floorf(nxb);
+                    const int uxb = f2i_sat_t(uxb_f), dxb = f2i_sat_t(dxb_f);
+                    rowbuf[k] = bilerp_ref(fetch_clamped_t(fb, (long long)dyb * p.W + dxb, HW),
+                                           fetch_clamped_t(fb, (long long)dyb * p.W + uxb, HW),
+                                           fetch_clamped_t(fb, (long long)uyb * p.W + dxb, HW),
+                                           fetch_clamped_t(fb, (long long)uyb * p.W + uxb, HW), uxb_f - nxb,
+                                           nxb - dxb_f, wyb_up, wyb_dn, ydeg_b || (uxb == dxb));
+                }
+#pragma unroll
+                for (int k = 0; k < WS; ++k) x[k].y = rowbuf[k];
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < WS; ++k) {
+                sa += x[k].x;
+                sb += x[k].y;
+            }
+        }
+
+        if (p.dbg_win != nullptr && active) {     // test hook: the staged (shifted) windows
+            float* d = p.dbg_win + fidx * 2 * WS * WS;
+#pragma unroll
+            for (int k = 0; k < WS; ++k) {
+                d[r * WS + k] = x[k].x;
+                d[WS * WS + r * WS + k] = x[k].y;
+            }
+        }
+
+        // ---- mean removal: any constant offset leaves corr - min(corr) unchanged and only
+        //      conditions the float32 transform.  Pass 1 also divides by the mean (B:513-514).
+        sa = grp_sum<WS>(sa);
+        sb = grp_sum<WS>(sb);
+        const float ma = sa * (1.0f / (WS * WS)), mb = sb * (1.0f / (WS * WS));
+        bool dead = false;        // pass 1: zero-mean window -> 0/0 = NaN map in the reference
+        float ka = 1.f, kb = 1.f;
+        if constexpr (MODE == MODE_PASS1) {
+            dead = (sa == 0.f) || (sb == 0.f);
+            ka = dead ? 0.f : 1.0f / ma;
+            kb = dead ? 0.f : 1.0f / mb;
+        }
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            x[k].x = (x[k].x - ma) * ka;
+            x[k].y = (x[k].y - mb) * kb;
+        }
+
+        // ---- forward 2-D transform of a + i*b: rows in registers, transpose, columns in registers
+        fft_inreg<WS, 1>(x);                              // over x; bin kx at x[FFT_POS<kx>]
+        transpose_tile<WS, true>(x, tile, lane);          // lane = kx, x[y] natural
+        fft_inreg<WS, 1>(x);                              // over y; Z(ky, kx = lane) at x[FFT_POS<ky>]
+
+        // ---- cross-spectrum.  A = (Z(k) + conj Z(-k))/2, B = (Z(k) - conj Z(-k))/(2i),
+        //      P = conj(A) * B / n^2.  Z(-ky, -kx) sits in lane (-kx mod WS), register (-ky mod WS).
+        {
+            const int partner = grp0 + ((WS - r) % WS);
+            constexpr float scale = 0.25f / (float)(WS * WS);
+            auto cross = [&](cf zk, cf zm) TPIV_LAMBDA_INLINE {
+                const float a_ = zk.x, b_ = zk.y, c_ = zm.x, d_ = zm.y;
+                cf pr;
+                pr.x = ((a_ + c_) * (b_ + d_) + (b_ - d_) * (c_ - a_)) * scale;
+                pr.y = ((c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_)) * scale;
+                return pr;
+            };
+            static_for<0, WS / 2 + 1>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int ky = decltype(kc)::value;
+                constexpr int nky = (WS - ky) % WS;
+                constexpr int p1 = FFT_POS<ky, WS>, p2 = FFT_POS<nky, WS>;
+                const cf z1 = x[p1];
+                if constexpr (ky == nky) {
+                    cf m1;
+                    m1.x = __shfl(z1.x, partner, 64);
+                    m1.y = __shfl(z1.y, partner, 64);
+                    x[p1] = cross(z1, m1);
+                } else {
+                    const cf z2 = x[p2];
+                    cf m1, m2;
+                    m1.x = __shfl(z2.x, partner, 64);     // Z(-ky, -kx)
+                    m1.y = __shfl(z2.y, partner, 64);
+                    m2.x = __shfl(z1.x, partner, 64);     // Z(+ky, -kx), the partner of bin -ky
+                    m2.y = __shfl(z1.y, partner, 64);
+                    x[p1] = cross(z1, m1);
+                    x[p2] = cross(z2, m2);
+                }
+            });
+        }
+
+        // ---- inverse: columns (natural-order input: rename registers), transpose, rows
+        cf t[WS];
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int ky = decltype(kc)::value;
+            t[ky] = x[FFT_POS<ky, WS>];
+        });
+        fft_inreg<WS, -1>(t);                             // over ky; row y at t[FFT_POS<y>]
+        transpose_tile<WS, true>(t, tile, lane);          // lane = y, t[kx] natural
+        fft_inreg<WS, -1>(t);                             // over kx; corr(y = lane, x) at t[FFT_POS<x>].x
+        __syncthreads();                                  // tile reads done: it becomes the map
+
+        // ---- correlation map in fftshift coordinates: y' = (r + WS/2) % WS, x' = (x + WS/2) % WS
+        float* my_map = reinterpret_cast<float*>(tile) + w * (WS * G::MAP_PITCH);
+        static_assert(G::WPW * WS * G::MAP_PITCH * 4 <= G::LDS_CF * 8, "map must fit the tile LDS");
+        const int ys = (r + WS / 2) % WS;
+        float cmin = 3.4e38f;
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            cmin = fminf(cmin, t[FFT_POS<k, WS>].x);
+        });
+        cmin = grp_min<WS>(cmin);
+        ArgMaxT best{-1.f, 0};
+        float c[WS];                                      // shifted row: c[x'] = corr - min + eps
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int xsft = decltype(kc)::value;     // ascending shifted column
+            constexpr int xo = (xsft + WS / 2) % WS;
+            // B:518 corr - min; B:381 corr += eps (float32 arithmetic in passes >= 2)
+            const float v = __fadd_rn(__fsub_rn(t[FFT_POS<xo, WS>].x, cmin), 1e-7f);
+            c[xsft] = v;
+            my_map[ys * G::MAP_PITCH + xsft] = v;
+            if (v > best.v) {
+                best.v = v;
+                best.idx = ys * WS + xsft;
+            }
+        });
+        best = grp_argmax<WS>(best);
+        __syncthreads();                                  // map complete
+
+        if (p.dbg_corr != nullptr && active) {
+            float* d = p.dbg_corr + fidx * WS * WS;
+#pragma unroll
+            for (int k = 0; k < WS; ++k) d[ys * WS + k] = c[k];
+        }
+
+        // ---- second peak: arg-max outside the (2*wv+1)^2 FLAT-index neighbourhood (B:346-358):
+        //      excluded q = clamp(m + i + WS*j), |i|,|j| <= wv, i.e. in row y' the columns
+        //      mx+i (j = y'-my), mx+i+WS (j = y'-my+1) and mx+i-WS (j = y'-my-1), plus the clamps.
+        const int m = best.idx;
+        const int KD = WS * WS;
+        const int wv = p.val_win;
+        const int my_ = m / WS, mx_ = m % WS;
+        ArgMaxT second{-1.f, KD};
+        {
+            const int dj = ys - my_;
+            unsigned long long ex = 0ull;                 // bit x' set = excluded in this lane's row
+            auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {     // bits lo_..hi_ clipped to the row
+                lo_ = lo_ < 0 ? 0 : lo_;
+                hi_ = hi_ > WS - 1 ? WS - 1 : hi_;
+                if (lo_ > hi_) return 0ull;
+                const unsigned long long ones = (hi_ - lo_ + 1) >= 64 ? ~0ull : ((1ull << (hi_ - lo_ + 1)) - 1ull);
+                return ones << lo_;
+            };
+            if (dj >= -wv && dj <= wv) ex |= span(mx_ - wv, mx_ + wv);
+            if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(mx_ - wv + WS, mx_ + wv + WS);
+            if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx_ - wv - WS, mx_ + wv - WS);
+            if (ys == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;                       // clamp to 0
+            if (ys == WS - 1 && (m + wv + wv * WS) >= KD - 1) ex |= 1ull << (WS - 1);  // clamp to KD-1
+            const unsigned exl = (unsigned)ex, exh = (unsigned)(ex >> 32);
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int xsft = decltype(kc)::value;
+                const bool excl = ((xsft < 32 ? exl : exh) >> (xsft & 31)) & 1u;
+                const float v = c[xsft];
+                if (!excl && v > second.v) {
+                    second.v = v;
+                    second.idx = ys * WS + xsft;
+                }
+            });
+        }
+        second = grp_argmax<WS>(second);
+
+        // ---- sub-pixel fit (B:385-407): lanes 0..5 of the window take one logarithm each
+        {
+            int left = m + 1, right = m - 1, top = m + WS, bot = m - WS;
+            if (left >= KD - 1) left = m;
+            if (right <= 0) right = m;
+            if (top >= KD - 1) top = m;
+            if (bot <= 0) bot = m;
+            int q = m;
+            q = (r == 1) ? left : q;
+            q = (r == 2) ? right : q;
+            q = (r == 3) ? top : q;
+            q = (r == 4) ? bot : q;
+            q = (r == 5) ? (second.idx < KD ? second.idx : m) : q;
+            const double val = (double)my_map[(q / WS) * G::MAP_PITCH + (q % WS)];
+            const double lg = log(val);
+            const double lm = __shfl(lg, grp0 + 0, 64);
+            const double ll = __shfl(lg, grp0 + 1, 64);
+            const double lr = __shfl(lg, grp0 + 2, 64);
+            const double lt = __shfl(lg, grp0 + 3, 64);
+            const double lb = __shfl(lg, grp0 + 4, 64);
+            const double cm = __shfl(val, grp0 + 0, 64);
+            const double c2 = __shfl(val, grp0 + 5, 64);
+            if (r == 0 && active) {
+                const double nom1 = lr - ll;
+                const double den1 = 2 * (ll + lr) - 4 * lm;
+                const double nom2 = lb - lt;
+                const double den2 = 2 * (lb + lt) - 4 * lm;
+                double du = (double)mx_ + nom1 / den1 - (double)(WS / 2);
+                double dv = (double)my_ + nom2 / den2 - (double)(WS / 2);
+                du = nan_to_num_t(du);
+                dv = nan_to_num_t(dv);
+                bool invalid = (cm / c2) < p.val_ratio;                  // B:411
+                if constexpr (MODE == MODE_PASS1) {
+                    if (dead) {             // all-NaN map in the reference: u = v = 0, "valid"
+                        du = 0.0;
+                        dv = 0.0;
+                        invalid = false;
+                    }
+                    p.u[fidx] = du;
+                    p.v[fidx] = dv;
+                    p.val[fidx] = invalid ? 1 : 0;
+                } else {
+                    // multipass combine (B:728-738 / B:800-810)
+                    const double u0 = p.u0[fidx], v0 = p.v0[fidx];
+                    const double u2 = p.u2[fidx], v2 = p.v2[fidx];
+                    double u = 2 * u2 + du;
+                    double v = 2 * v2 + dv;
+                    const bool mask_u = ((du > u0) && (rint(u0) > 0)) || invalid;
+                    const bool mask_v = ((dv > v0) && (rint(v0) > 0)) || invalid;
+                    if (mask_u) u = u0;
+                    if (mask_v) v = v0;
+                    p.u[fidx] = u;
+                    p.v[fidx] = v;
+                    p.val[fidx] = invalid ? 1 : 0;
+                    if (p.du != nullptr) {
+                        p.du[fidx] = du;
+                        p.dv[fidx] = dv;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int WS, int MODE>
+static hipError_t launch_tile(const PassParams& p, int n_cu, hipStream_t stream) {
+    using G = TileGeo<WS>;
+    const int N = p.n_rows * p.n_cols;
+    const long long groups = (N + G::WPW - 1) / G::WPW;
+    const long long items = (long long)p.batch * groups;
+    long long blocks = items;
+    const long long cap = (long long)n_cu * 64;     // a few waves of workgroups per CU, grid-stride above
+    if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) / 8 * 8;                  // the XCD remap needs a multiple of 8
+    hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+// one translation unit per tile size instantiates this (xcorr_ws*.hip)
+template <int WS>
+hipError_t launch_xcorr_tile_ws(const PassParams& p, int mode, int n_cu, hipStream_t stream) {
+    switch (mode) {
+        case MODE_PASS1: return launch_tile<WS, MODE_PASS1>(p, n_cu, stream);
+        case MODE_DWS: return launch_tile<WS, MODE_DWS>(p, n_cu, stream);
+        case MODE_CWS: return launch_tile<WS, MODE_CWS>(p, n_cu, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace tpiv

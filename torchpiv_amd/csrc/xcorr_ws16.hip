@@ -1,5 +1,7 @@
-// Tile kernels for 16x16 interrogation windows (see xcorr_kernel.hpp).
-#include "xcorr_kernel.hpp"
+// Tile kernels for 16x16 interrogation windows (see xcorr_tile.hpp).
+#include "xcorr_tile.hpp"
 namespace tpiv {
-template hipError_t launch_xcorr_ws<16>(const PassParams&, int, int, hipStream_t);
+hipError_t launch_xcorr_ws16(const PassParams& p, int mode, int n_cu, hipStream_t stream) {
+    return launch_xcorr_tile_ws<16>(p, mode, n_cu, stream);
 }
+}  // namespace tpiv
