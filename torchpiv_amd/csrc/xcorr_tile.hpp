@@ -117,6 +117,15 @@ __device__ __forceinline__ float bilerp_ref(float f11, float f21, float f12, flo
     return degenerate ? f11 : r;          // B:170, B:193: either coordinate integral -> f(floor y, floor x)
 }
 
+// A workgroup is ONE wavefront, and the LDS executes one wavefront's DS instructions in order,
+// so exchanging data between lanes through LDS needs no s_barrier and no s_waitcnt: only the
+// compiler must keep the program order of the LDS accesses.  (A real __syncthreads() would also
+// emit vmcnt(0) and drain the next item's prefetch loads.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---- transposition of the wavefront's tile(s) through LDS ---------------------------------
 // in:  lane (w, i) holds line i of its window, element k at in[POS(k)]  (POS = digit-reversed
 //      position when DIGITREV, else k)
@@ -128,13 +137,13 @@ __device__ __forceinline__ void transpose_tile(cf (&a)[WS], cf* tile, int lane) 
     if constexpr (WS <= 32) {
         cf* t = tile + (lane / WS) * G::TILE;
         const int i = lane % WS;
-        __syncthreads();
+        wave_sync();
         static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
             constexpr int k = decltype(kc)::value;
             constexpr int src = DIGITREV ? FFT_POS<k, WS> : k;
             t[i * P + k] = a[src];
         });
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int r = 0; r < WS; ++r) a[r] = t[r * P + i];
     } else {
@@ -156,26 +165,234 @@ __device__ __forceinline__ void transpose_tile(cf (&a)[WS], cf* tile, int lane) 
         cf* t = tile + (lane >> 5) * G::TILE;
         const int i = lane & 31;
         cf lowhalf[32];
-        __syncthreads();
+        wave_sync();
         static_for<0, 32>([&](auto kc) TPIV_LAMBDA_INLINE {
             constexpr int k = decltype(kc)::value;
             constexpr int src = DIGITREV ? FFT_POS<k, WS> : k;
             t[i * P + k] = a[src];
         });
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int r = 0; r < 32; ++r) lowhalf[r] = t[r * P + i];
-        __syncthreads();
+        wave_sync();
         static_for<0, 32>([&](auto kc) TPIV_LAMBDA_INLINE {
             constexpr int k = decltype(kc)::value;
             constexpr int src = DIGITREV ? FFT_POS<k + 32, WS> : k + 32;
             t[i * P + k] = a[src];
         });
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int r = 0; r < 32; ++r) a[32 + r] = t[r * P + i];
 #pragma unroll
         for (int r = 0; r < 32; ++r) a[r] = lowhalf[r];
+    }
+}
+
+// ---- stage 0: window rows, split into "issue the loads" and "turn them into samples" so that
+//      the loads of item i+1 can be in flight while item i is transformed (software prefetch)
+struct ItemGeom {
+    int pair, win, y0, x0;
+    bool active;
+    size_t fidx;
+};
+
+template <int WS, int MODE>
+struct RawRows;
+template <int WS>
+struct RawRows<WS, MODE_PASS1> {
+    uint32_t a[WS / 4], b[WS / 4];
+};
+template <int WS>
+struct RawRows<WS, MODE_DWS> {
+    uint32_t a[WS / 4], b[WS / 4];
+    long long qa, qb;
+    bool reg;
+};
+template <int WS>
+struct RawRows<WS, MODE_CWS> {
+    uint32_t a0[WS / 4 + 1], a1[WS / 4 + 1], b0[WS / 4 + 1], b1[WS / 4 + 1];    // WS+1 bytes per row
+    bool reg;
+};
+
+// per-lane row geometry of the bilinear (CWS) shift, exactly as PIVbackend.py:162-172 computes it
+struct CwsRow {
+    float wya_up, wya_dn, wyb_up, wyb_dn;
+    int dya, uya, dyb, uyb;
+    bool ydeg_a, ydeg_b;
+};
+__device__ __forceinline__ CwsRow cws_row(int gy, float vy) {
+    CwsRow c;
+    const float gyf = (float)gy;
+    const float nya = gyf - vy, nyb = gyf + vy;          // frame a by -(vx, vy), frame b by +(vx, vy)
+    const float uya_f = ceilf(nya), dya_f = floorf(nya);
+    const float uyb_f = ceilf(nyb), dyb_f = floorf(nyb);
+    c.uya = f2i_sat_t(uya_f);
+    c.dya = f2i_sat_t(dya_f);
+    c.uyb = f2i_sat_t(uyb_f);
+    c.dyb = f2i_sat_t(dyb_f);
+    c.wya_up = uya_f - nya;
+    c.wya_dn = nya - dya_f;
+    c.wyb_up = uyb_f - nyb;
+    c.wyb_dn = nyb - dyb_f;
+    c.ydeg_a = c.uya == c.dya;
+    c.ydeg_b = c.uyb == c.dyb;
+    return c;
+}
+
+template <int WS, int MODE>
+__device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& g, int r, float vx, float vy,
+                                           RawRows<WS, MODE>& raw) {
+    const int HW = p.H * p.W;
+    const uint8_t* __restrict__ fa = p.A + (size_t)g.pair * HW;
+    const uint8_t* __restrict__ fb = p.B + (size_t)g.pair * HW;
+    if constexpr (MODE == MODE_PASS1) {
+        const size_t off = (size_t)(g.y0 + r) * p.W + g.x0;
+        load_dwords<WS / 4>(fa + off, raw.a);
+        load_dwords<WS / 4>(fb + off, raw.b);
+    } else if constexpr (MODE == MODE_DWS) {
+        // integer shift on the FLAT index (B:213-215): a at idx - (vy*W + vx), b at idx + (...)
+        const long long sh = (long long)vy * p.W + (long long)vx;
+        const long long base = (long long)(g.y0 + r) * p.W + g.x0;
+        raw.qa = base - sh;
+        raw.qb = base + sh;
+        raw.reg = raw.qa >= 0 && raw.qa + WS <= HW && raw.qb >= 0 && raw.qb + WS <= HW;
+        if (__all(raw.reg)) {
+            load_dwords<WS / 4>(fa + raw.qa, raw.a);
+            load_dwords<WS / 4>(fb + raw.qb, raw.b);
+        }
+    } else {
+        constexpr int NB = WS / 4 + 1;
+        const CwsRow c = cws_row(g.y0 + r, vy);
+        // Fast path: floor(float(gx) + vx) == gx + floor(vx) for every column (true unless
+        // frac(vx) is within float32 rounding of an integer) and all four source rows lie
+        // inside the frame, so that a row is WS+1 consecutive bytes.
+        const float fvx = floorf(vx);
+        const float frac = vx - fvx;
+        const float thr = (float)(p.W + 64) * 4.76837158e-07f;       // (W + 64) * 2^-21
+        const int ivx = f2i_sat_t(fvx);
+        // frame a uses -vx: floor(-vx) = -floor(vx) - 1 when frac != 0
+        const long long qa0 = (long long)c.dya * p.W + (g.x0 - ivx - 1);
+        const long long qa1 = (long long)c.uya * p.W + (g.x0 - ivx - 1);
+        const long long qb0 = (long long)c.dyb * p.W + (g.x0 + ivx);
+        const long long qb1 = (long long)c.uyb * p.W + (g.x0 + ivx);
+        const bool inb = qa0 >= 0 && qa1 + 4 * NB <= HW && qb0 >= 0 && qb1 + 4 * NB <= HW &&
+                         qa1 >= 0 && qa0 + 4 * NB <= HW && qb1 >= 0 && qb0 + 4 * NB <= HW;
+        raw.reg = inb && frac > thr && frac < 1.0f - thr && fabsf(vx) < (float)p.W;
+        if (__all(raw.reg)) {
+            load_dwords<NB>(fa + qa0, raw.a0);
+            load_dwords<NB>(fa + qa1, raw.a1);
+            load_dwords<NB>(fb + qb0, raw.b0);
+            load_dwords<NB>(fb + qb1, raw.b1);
+        }
+    }
+}
+
+// raw rows -> float samples x[k] = (a, b) and the lane's partial sums
+template <int WS, int MODE>
+__device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom& g, int r, int lane, float vx,
+                                             float vy, const RawRows<WS, MODE>& raw, cf (&x)[WS], float& sa,
+                                             float& sb, cf* tile) {
+    const int HW = p.H * p.W;
+    const uint8_t* __restrict__ fa = p.A + (size_t)g.pair * HW;
+    const uint8_t* __restrict__ fb = p.B + (size_t)g.pair * HW;
+    float* rowbuf = reinterpret_cast<float*>(tile) + lane * (WS + 1);     // slow paths only
+    if constexpr (MODE == MODE_PASS1) {
+        unsigned ia = 0, ib = 0;
+#pragma unroll
+        for (int q = 0; q < WS / 4; ++q) {
+            ia = __builtin_amdgcn_sad_u8(raw.a[q], 0u, ia);
+            ib = __builtin_amdgcn_sad_u8(raw.b[q], 0u, ib);
+        }
+        sa = (float)ia;
+        sb = (float)ib;
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            x[k].x = byte_f<k, WS / 4>(raw.a);
+            x[k].y = byte_f<k, WS / 4>(raw.b);
+        });
+    } else if constexpr (MODE == MODE_DWS) {
+        if (__all(raw.reg)) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                x[k].x = byte_f<k, WS / 4>(raw.a);
+                x[k].y = byte_f<k, WS / 4>(raw.b);
+            });
+        } else {          // a row touches the first/last pixel of the frame: per-pixel clamp.
+            // Rare: kept as a rolled loop that parks the row in LDS (no code blow-up).
+            wave_sync();
+#pragma unroll 4
+            for (int k = 0; k < WS; ++k) rowbuf[k] = fetch_clamped_t(fa, raw.qa + k, HW);
+#pragma unroll
+            for (int k = 0; k < WS; ++k) x[k].x = rowbuf[k];
+#pragma unroll 4
+            for (int k = 0; k < WS; ++k) rowbuf[k] = fetch_clamped_t(fb, raw.qb + k, HW);
+#pragma unroll
+            for (int k = 0; k < WS; ++k) x[k].y = rowbuf[k];
+            wave_sync();
+        }
+        sa = 0.f;
+        sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            sa += x[k].x;
+            sb += x[k].y;
+        }
+    } else {
+        constexpr int NB = WS / 4 + 1;
+        const CwsRow c = cws_row(g.y0 + r, vy);
+        const float gx0f = (float)g.x0;
+        if (__all(raw.reg)) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                const float gxf = gx0f + (float)k;                   // exact: small integers
+                const float nxa = gxf - vx, nxb = gxf + vx;
+                const float uxa_f = ceilf(nxa), dxa_f = floorf(nxa);
+                const float uxb_f = ceilf(nxb), dxb_f = floorf(nxb);
+                x[k].x = bilerp_ref(byte_f<k, NB>(raw.a0), byte_f<k + 1, NB>(raw.a0), byte_f<k, NB>(raw.a1),
+                                    byte_f<k + 1, NB>(raw.a1), uxa_f - nxa, nxa - dxa_f, c.wya_up, c.wya_dn,
+                                    c.ydeg_a || (uxa_f == dxa_f));
+                x[k].y = bilerp_ref(byte_f<k, NB>(raw.b0), byte_f<k + 1, NB>(raw.b0), byte_f<k, NB>(raw.b1),
+                                    byte_f<k + 1, NB>(raw.b1), uxb_f - nxb, nxb - dxb_f, c.wyb_up, c.wyb_dn,
+                                    c.ydeg_b || (uxb_f == dxb_f));
+            });
+        } else {          // generic per-pixel gather with the flat-index clamp (rare: rolled loops
+                          // that park the row in LDS)
+            wave_sync();
+#pragma unroll 2
+            for (int k = 0; k < WS; ++k) {
+                const float nxa = (gx0f + (float)k) - vx;
+                const float uxa_f = ceilf(nxa), dxa_f = floorf(nxa);
+                const int uxa = f2i_sat_t(uxa_f), dxa = f2i_sat_t(dxa_f);
+                rowbuf[k] = bilerp_ref(fetch_clamped_t(fa, (long long)c.dya * p.W + dxa, HW),
+                                       fetch_clamped_t(fa, (long long)c.dya * p.W + uxa, HW),
+                                       fetch_clamped_t(fa, (long long)c.uya * p.W + dxa, HW),
+                                       fetch_clamped_t(fa, (long long)c.uya * p.W + uxa, HW), uxa_f - nxa,
+                                       nxa - dxa_f, c.wya_up, c.wya_dn, c.ydeg_a || (uxa == dxa));
+            }
+#pragma unroll
+            for (int k = 0; k < WS; ++k) x[k].x = rowbuf[k];
+#pragma unroll 2
+            for (int k = 0; k < WS; ++k) {
+                const float nxb = (gx0f + (float)k) + vx;
+                const float uxb_f = ceilf(nxb), dxb_f = floorf(nxb);
+                const int uxb = f2i_sat_t(uxb_f), dxb = f2i_sat_t(dxb_f);
+                rowbuf[k] = bilerp_ref(fetch_clamped_t(fb, (long long)c.dyb * p.W + dxb, HW),
+                                       fetch_clamped_t(fb, (long long)c.dyb * p.W + uxb, HW),
+                                       fetch_clamped_t(fb, (long long)c.uyb * p.W + dxb, HW),
+                                       fetch_clamped_t(fb, (long long)c.uyb * p.W + uxb, HW), uxb_f - nxb,
+                                       nxb - dxb_f, c.wyb_up, c.wyb_dn, c.ydeg_b || (uxb == dxb));
+            }
+#pragma unroll
+            for (int k = 0; k < WS; ++k) x[k].y = rowbuf[k];
+            wave_sync();
+        }
+        sa = 0.f;
+        sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < WS; ++k) {
+            sa += x[k].x;
+            sb += x[k].y;
+        }
     }
 }
 
@@ -184,6 +401,7 @@ template <int WS, int MODE>
 __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
     using G = TileGeo<WS>;
     static_assert(WS == 8 || WS == 16 || WS == 32 || WS == 64, "tile sizes of this kernel");
+    static_assert(64 * (WS + 1) * 4 <= G::LDS_CF * 8, "slow-path row buffer must fit the tile LDS");
     __shared__ cf tile[G::LDS_CF];
 
     const int lane = threadIdx.x;
@@ -194,7 +412,6 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
     const int N = p.n_rows * p.n_cols;
     const int groups = (N + G::WPW - 1) / G::WPW;
     const long long items = (long long)p.batch * groups;
-    const int HW = p.H * p.W;
     const int st = p.ws - p.ov;
 
     // XCD-aware item order: workgroups b, b+8, ... share an XCD (and its L2); give every XCD one
@@ -206,161 +423,52 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
     const long long lo = (long long)xcd * chunk;
     const long long hi = (lo + chunk < items) ? lo + chunk : items;
 
-    for (long long item = lo + slot; item < hi; item += per_xcd) {
-        const int pair = (int)(item / groups);
-        const int g = (int)(item % groups);
-        const int win_raw = g * G::WPW + w;
-        const bool active = win_raw < N;
-        const int win = active ? win_raw : N - 1;
-        const int wr = win / p.n_cols, wc = win % p.n_cols;
-        const int y0 = wr * st, x0 = wc * st;
-        const uint8_t* __restrict__ fa = p.A + (size_t)pair * HW;
-        const uint8_t* __restrict__ fb = p.B + (size_t)pair * HW;
-        const size_t fidx = (size_t)pair * N + win;
+    auto geom_of = [&](long long item) TPIV_LAMBDA_INLINE {
+        ItemGeom g;
+        g.pair = (int)(item / groups);
+        const int gi = (int)(item % groups);
+        const int win_raw = gi * G::WPW + w;
+        g.active = win_raw < N;
+        g.win = g.active ? win_raw : N - 1;
+        g.y0 = (g.win / p.n_cols) * st;
+        g.x0 = (g.win % p.n_cols) * st;
+        g.fidx = (size_t)g.pair * N + g.win;
+        return g;
+    };
+    auto shift_of = [&](const ItemGeom& g, float& vx, float& vy) TPIV_LAMBDA_INLINE {
+        if constexpr (MODE == MODE_PASS1) {
+            vx = 0.f;
+            vy = 0.f;
+        } else {      // DWS: exact small integers; CWS: the float32 cast of B:714-715
+            vx = (float)p.u2[g.fidx];
+            vy = (float)p.v2[g.fidx];
+        }
+    };
+
+    long long item = lo + slot;
+    if (item >= hi) return;
+    ItemGeom gcur = geom_of(item);
+    float vx, vy;
+    shift_of(gcur, vx, vy);
+    RawRows<WS, MODE> raw;
+    issue_rows<WS, MODE>(p, gcur, r, vx, vy, raw);
+
+    for (; item < hi; item += per_xcd) {
+        const ItemGeom g = gcur;
+        const bool active = g.active;
+        const size_t fidx = g.fidx;
+        // shifts of the NEXT item: fetched now, needed when its row loads are issued further down
+        const bool has_next = item + per_xcd < hi;
+        ItemGeom gnext = g;
+        float nvx = 0.f, nvy = 0.f;
+        if (has_next) {
+            gnext = geom_of(item + per_xcd);
+            shift_of(gnext, nvx, nvy);
+        }
 
         cf x[WS];
-        float sa = 0.f, sb = 0.f;          // window sums (for the mean)
-
-        // ---- stage 0: this lane's window row -> registers --------------------------------
-        if constexpr (MODE == MODE_PASS1) {
-            uint32_t da[G::NDW], db[G::NDW];
-            const size_t off = (size_t)(y0 + r) * p.W + x0;
-            load_dwords<G::NDW>(fa + off, da);
-            load_dwords<G::NDW>(fb + off, db);
-            unsigned ia = 0, ib = 0;
-#pragma unroll
-            for (int q = 0; q < G::NDW; ++q) {
-                ia = __builtin_amdgcn_sad_u8(da[q], 0u, ia);
-                ib = __builtin_amdgcn_sad_u8(db[q], 0u, ib);
-            }
-            sa = (float)ia;
-            sb = (float)ib;
-            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-                constexpr int k = decltype(kc)::value;
-                x[k].x = byte_f<k, G::NDW>(da);
-                x[k].y = byte_f<k, G::NDW>(db);
-            });
-        } else if constexpr (MODE == MODE_DWS) {
-            // integer shift on the FLAT index (B:213-215): a at idx - (vy*W + vx), b at idx + (...)
-            const long long sx = (long long)p.u2[fidx], sy = (long long)p.v2[fidx];
-            const long long sh = sy * p.W + sx;
-            const long long base = (long long)(y0 + r) * p.W + x0;
-            const long long qa = base - sh, qb = base + sh;
-            const bool reg = qa >= 0 && qa + WS <= HW && qb >= 0 && qb + WS <= HW;
-            if (__all(reg)) {
-                uint32_t da[G::NDW], db[G::NDW];
-                load_dwords<G::NDW>(fa + qa, da);
-                load_dwords<G::NDW>(fb + qb, db);
-                static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-                    constexpr int k = decltype(kc)::value;
-                    x[k].x = byte_f<k, G::NDW>(da);
-                    x[k].y = byte_f<k, G::NDW>(db);
-                });
-            } else {          // a row touches the first/last pixel of the frame: per-pixel clamp.
-                // Rare: kept as a rolled loop that parks the row in LDS (no code blow-up).
-                float* rowbuf = reinterpret_cast<float*>(tile) + lane * WS;
-                __syncthreads();
-#pragma unroll 1
-                for (int k = 0; k < WS; ++k) rowbuf[k] = fetch_clamped_t(fa, qa + k, HW);
-#pragma unroll
-                for (int k = 0; k < WS; ++k) x[k].x = rowbuf[k];
-#pragma unroll 1
-                for (int k = 0; k < WS; ++k) rowbuf[k] = fetch_clamped_t(fb, qb + k, HW);
-#pragma unroll
-                for (int k = 0; k < WS; ++k) x[k].y = rowbuf[k];
-                __syncthreads();
-            }
-#pragma unroll
-            for (int k = 0; k < WS; ++k) {
-                sa += x[k].x;
-                sb += x[k].y;
-            }
-        } else {
-            // bilinear shift in float32 (B:162-193): frame a by -(vx, vy), frame b by +(vx, vy)
-            const float vx = (float)p.u2[fidx], vy = (float)p.v2[fidx];
-            const float gyf = (float)(y0 + r);
-            const float nya = gyf - vy, nyb = gyf + vy;
-            const float uya_f = ceilf(nya), dya_f = floorf(nya);
-            const float uyb_f = ceilf(nyb), dyb_f = floorf(nyb);
-            const int uya = f2i_sat_t(uya_f), dya = f2i_sat_t(dya_f);
-            const int uyb = f2i_sat_t(uyb_f), dyb = f2i_sat_t(dyb_f);
-            const float wya_up = uya_f - nya, wya_dn = nya - dya_f;
-            const float wyb_up = uyb_f - nyb, wyb_dn = nyb - dyb_f;
-            const bool ydeg_a = uya == dya, ydeg_b = uyb == dyb;
-            const float gx0f = (float)x0;
-            // Fast path: floor(float(gx) + vx) == gx + floor(vx) for every column (true unless
-            // frac(vx) is within float32 rounding of an integer) and all four source rows lie
-            // inside the frame, so that a row is WS+1 consecutive bytes.
-            const float fvx = floorf(vx);
-            const float frac = vx - fvx;
-            const float thr = (float)(p.W + 64) * 4.76837158e-07f;       // (W + 64) * 2^-21
-            const int ivx = f2i_sat_t(fvx);
-            // frame a uses -vx: floor(-vx) = -floor(vx) - 1 when frac != 0
-            const long long qa0 = (long long)dya * p.W + (x0 - ivx - 1);
-            const long long qa1 = (long long)uya * p.W + (x0 - ivx - 1);
-            const long long qb0 = (long long)dyb * p.W + (x0 + ivx);
-            const long long qb1 = (long long)uyb * p.W + (x0 + ivx);
-            constexpr int NB = WS / 4 + 1;                               // dwords covering WS+1 bytes
-            const bool inb = qa0 >= 0 && qa1 + 4 * NB <= HW && qb0 >= 0 && qb1 + 4 * NB <= HW &&
-                             qa1 >= 0 && qa0 + 4 * NB <= HW && qb1 >= 0 && qb0 + 4 * NB <= HW;
-            const bool reg = inb && frac > thr && frac < 1.0f - thr && fabsf(vx) < (float)p.W;
-            if (__all(reg)) {
-                uint32_t a0[NB], a1[NB], b0[NB], b1[NB];
-                load_dwords<NB>(fa + qa0, a0);
-                load_dwords<NB>(fa + qa1, a1);
-                load_dwords<NB>(fb + qb0, b0);
-                load_dwords<NB>(fb + qb1, b1);
-                static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-                    constexpr int k = decltype(kc)::value;
-                    const float gxf = gx0f + (float)k;                   // exact: small integers
-                    const float nxa = gxf - vx, nxb = gxf + vx;
-                    const float uxa_f = ceilf(nxa), dxa_f = floorf(nxa);
-                    const float uxb_f = ceilf(nxb), dxb_f = floorf(nxb);
-                    x[k].x = bilerp_ref(byte_f<k, NB>(a0), byte_f<k + 1, NB>(a0), byte_f<k, NB>(a1),
-                                        byte_f<k + 1, NB>(a1), uxa_f - nxa, nxa - dxa_f, wya_up, wya_dn,
-                                        ydeg_a || (uxa_f == dxa_f));
-                    x[k].y = bilerp_ref(byte_f<k, NB>(b0), byte_f<k + 1, NB>(b0), byte_f<k, NB>(b1),
-                                        byte_f<k + 1, NB>(b1), uxb_f - nxb, nxb - dxb_f, wyb_up, wyb_dn,
-                                        ydeg_b || (uxb_f == dxb_f));
-                });
-            } else {          // generic per-pixel gather with the flat-index clamp (rare: rolled
-                              // loops that park the row in LDS)
-                float* rowbuf = reinterpret_cast<float*>(tile) + lane * WS;
-                __syncthreads();
-#pragma unroll 1
-                for (int k = 0; k < WS; ++k) {
-                    const float nxa = (gx0f + (float)k) - vx;
-                    const float uxa_f = ceilf(nxa), dxa_f = floorf(nxa);
-                    const int uxa = f2i_sat_t(uxa_f), dxa = f2i_sat_t(dxa_f);
-                    rowbuf[k] = bilerp_ref(fetch_clamped_t(fa, (long long)dya * p.W + dxa, HW),
-                                           fetch_clamped_t(fa, (long long)dya * p.W + uxa, HW),
-                                           fetch_clamped_t(fa, (long long)uya * p.W + dxa, HW),
-                                           fetch_clamped_t(fa, (long long)uya * p.W + uxa, HW), uxa_f - nxa,
-                                           nxa - dxa_f, wya_up, wya_dn, ydeg_a || (uxa == dxa));
-                }
-#pragma unroll
-                for (int k = 0; k < WS; ++k) x[k].x = rowbuf[k];
-#pragma unroll 1
-                for (int k = 0; k < WS; ++k) {
-                    const float nxb = (gx0f + (float)k) + vx;
-                    const float uxb_f = ceilf(nxb), dxb_f = floorf(nxb);
-                    const int uxb = f2i_sat_t(uxb_f), dxb = f2i_sat_t(dxb_f);
-                    rowbuf[k] = bilerp_ref(fetch_clamped_t(fb, (long long)dyb * p.W + dxb, HW),
-                                           fetch_clamped_t(fb, (long long)dyb * p.W + uxb, HW),
-                                           fetch_clamped_t(fb, (long long)uyb * p.W + dxb, HW),
-                                           fetch_clamped_t(fb, (long long)uyb * p.W + uxb, HW), uxb_f - nxb,
-                                           nxb - dxb_f, wyb_up, wyb_dn, ydeg_b || (uxb == dxb));
-                }
-#pragma unroll
-                for (int k = 0; k < WS; ++k) x[k].y = rowbuf[k];
-                __syncthreads();
-            }
-#pragma unroll
-            for (int k = 0; k < WS; ++k) {
-                sa += x[k].x;
-                sb += x[k].y;
-            }
-        }
+        float sa, sb;                      // window sums (for the mean)
+        convert_rows<WS, MODE>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile);
 
         if (p.dbg_win != nullptr && active) {     // test hook: the staged (shifted) windows
             float* d = p.dbg_win + fidx * 2 * WS * WS;
@@ -438,7 +546,15 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
         fft_inreg<WS, -1>(t);                             // over ky; row y at t[FFT_POS<y>]
         transpose_tile<WS, true>(t, tile, lane);          // lane = y, t[kx] natural
         fft_inreg<WS, -1>(t);                             // over kx; corr(y = lane, x) at t[FFT_POS<x>].x
-        __syncthreads();                                  // tile reads done: it becomes the map
+        wave_sync();                                  // tile reads done: it becomes the map
+
+        // ---- prefetch: the next item's row loads fly while this item's peak search runs
+        if (has_next) {
+            issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
+            gcur = gnext;
+            vx = nvx;
+            vy = nvy;
+        }
 
         // ---- correlation map in fftshift coordinates: y' = (r + WS/2) % WS, x' = (x + WS/2) % WS
         float* my_map = reinterpret_cast<float*>(tile) + w * (WS * G::MAP_PITCH);
@@ -465,7 +581,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
             }
         });
         best = grp_argmax<WS>(best);
-        __syncthreads();                                  // map complete
+        wave_sync();                                  // map complete
 
         if (p.dbg_corr != nullptr && active) {
             float* d = p.dbg_corr + fidx * WS * WS;
@@ -570,7 +686,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
