@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtorchpiv_hip.so")
+# TPIV_LIB: development override (e.g. the stamped diagnostic build); the default is the in-tree library
+LIB_PATH = os.environ.get("TPIV_LIB") or os.path.join(_HERE, "libtorchpiv_hip.so")
 
 OK, EINVAL, EKEY, EHIP, ENOMEM, EUNSUPPORTED = 0, 1, 2, 3, 4, 5
 MODE_DWS, MODE_CWS = 1, 2

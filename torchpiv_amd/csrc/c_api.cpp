@@ -16,6 +16,7 @@
 namespace {
 
 thread_local std::string g_err;
+unsigned long long* g_stamps = nullptr;      // diagnostic builds: device buffer for phase stamps
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -272,6 +273,7 @@ int tpiv_pass1(const uint8_t* a, const uint8_t* b, int batch, int H, int W, int 
     p.val = invalid;
     p.val_ratio = val_ratio;
     p.val_win = val_win;
+    p.stamps = g_stamps;
     int n_cu;
     rc = n_cu_of_current_device(&n_cu);
     if (rc) return rc;
@@ -335,6 +337,7 @@ static int run_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int
     p.val_win = val_win;
     p.dbg_win = dbg_win;
     p.dbg_corr = dbg_corr;
+    p.stamps = g_stamps;
     int n_cu;
     rc = n_cu_of_current_device(&n_cu);
     if (rc) return rc;
@@ -550,6 +553,14 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
         if (rc) return rc;
     }
     if (plan->timing && plan->runs_recorded < 512) plan->runs_recorded++;
+    return TPIV_OK;
+}
+
+// Diagnostic builds (make stamps): device buffer of 32 uint64 that the tile kernels add their
+// per-phase s_memtime deltas to.  Not declared in the public header: the production library
+// ignores it (the stamp code is compiled out).
+int tpiv_debug_set_stamps(void* dev_buffer) {
+    g_stamps = static_cast<unsigned long long*>(dev_buffer);
     return TPIV_OK;
 }
 

@@ -29,6 +29,7 @@ struct PassParams {
     // test hooks (nullptr in production)
     float* dbg_win;        // [batch, N, 2, ws, ws] staged windows (after the shift)
     float* dbg_corr;       // [batch, N, ws, ws] corr - min + eps, fftshift layout
+    unsigned long long* stamps;   // diagnostic build (-DTPIV_STAMPS) only: per-phase cycle sums
 };
 
 struct PredictParams {

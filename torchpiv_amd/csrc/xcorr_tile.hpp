@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fft_inreg.hpp"
 #include "piv_kernels.h"
@@ -34,7 +35,7 @@ struct TileGeo {
     static constexpr int PITCH = TS + 1;                // complex elements per tile row
     static constexpr int NT = 64 / TS;                  // tiles per wavefront
     static constexpr int TILE = TS * PITCH;             // complex elements per tile
-    static constexpr int LDS_CF = NT * TILE;            // complex elements of LDS per wavefront
+    static constexpr int LDS_FLOATS = NT * TILE * 2;    // floats of LDS per wavefront (complex tiles)
     static constexpr int MAP_PITCH = WS + 1;            // floats per row of the correlation map
     static constexpr int NDW = WS / 4;                  // dwords per window row
 };
@@ -50,30 +51,88 @@ __device__ __forceinline__ ArgMaxT better_t(ArgMaxT a, ArgMaxT b) {
     return takeb ? b : a;
 }
 
+// ---- reductions over the WS lanes of one window, all lanes receive the result.
+// Cross-lane steps stay in the VALU (DPP quad/row permutes, v_permlane16/32_swap): the usual
+// __shfl_xor goes through ds_bpermute, i.e. one LDS round trip per step, and five dependent
+// round trips per reduction dominated the latency of the peak search.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(dpp_i<CTRL>(__float_as_int(v)));
+}
+constexpr int DPP_XOR1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;  // lane i <-> 7-i inside each 8
+constexpr int DPP_ROW_MIRROR = 0x140;   // lane i <-> 15-i inside each 16
+
+// partner values for the reduction step that spans 2*HALF lanes (any pairing of the two halves works)
+template <int HALF>
+__device__ __forceinline__ void partner2(int a, int& pa) {
+    if constexpr (HALF == 1) pa = dpp_i<DPP_XOR1>(a);
+    else if constexpr (HALF == 2) pa = dpp_i<DPP_XOR2>(a);
+    else if constexpr (HALF == 4) pa = dpp_i<DPP_HALF_MIRROR>(a);
+    else if constexpr (HALF == 8) pa = dpp_i<DPP_ROW_MIRROR>(a);
+}
+
+template <int WS, typename T, typename OP>
+__device__ __forceinline__ T grp_reduce(T v, OP op) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "one or two dwords");
+    constexpr int NW = sizeof(T) / 4;
+    union U {
+        T t;
+        int w[NW];
+    };
+    static_for<0, 4>([&](auto sc) TPIV_LAMBDA_INLINE {
+        constexpr int half = 1 << decltype(sc)::value;
+        if constexpr (half < WS) {
+            U a, b;
+            a.t = v;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) partner2<half>(a.w[q], b.w[q]);
+            v = op(v, b.t);
+        }
+    });
+    if constexpr (WS >= 32) {           // rows of 16 lanes: {R0,R1,R2,R3} -> {R0,R0,R2,R2} (+) {R1,R1,R3,R3}
+        U a, x, y;
+        a.t = v;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            auto r = __builtin_amdgcn_permlane16_swap((unsigned)a.w[q], (unsigned)a.w[q], false, false);
+            x.w[q] = (int)r[0];
+            y.w[q] = (int)r[1];
+        }
+        v = op(x.t, y.t);
+    }
+    if constexpr (WS >= 64) {           // halves of 32 lanes
+        U a, x, y;
+        a.t = v;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            auto r = __builtin_amdgcn_permlane32_swap((unsigned)a.w[q], (unsigned)a.w[q], false, false);
+            x.w[q] = (int)r[0];
+            y.w[q] = (int)r[1];
+        }
+        v = op(x.t, y.t);
+    }
+    return v;
+}
+
 template <int WS>
 __device__ __forceinline__ float grp_sum(float v) {
-#pragma unroll
-    for (int off = WS / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    return grp_reduce<WS>(v, [](float a, float b) TPIV_LAMBDA_INLINE { return a + b; });
 }
 
 template <int WS>
 __device__ __forceinline__ float grp_min(float v) {
-#pragma unroll
-    for (int off = WS / 2; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-    return v;
+    return grp_reduce<WS>(v, [](float a, float b) TPIV_LAMBDA_INLINE { return fminf(a, b); });
 }
 
 template <int WS>
 __device__ __forceinline__ ArgMaxT grp_argmax(ArgMaxT a) {
-#pragma unroll
-    for (int off = WS / 2; off >= 1; off >>= 1) {
-        ArgMaxT o;
-        o.v = __shfl_xor(a.v, off, 64);
-        o.idx = __shfl_xor(a.idx, off, 64);
-        a = better_t(a, o);
-    }
-    return a;
+    return grp_reduce<WS>(a, [](ArgMaxT p, ArgMaxT q) TPIV_LAMBDA_INLINE { return better_t(p, q); });
 }
 
 __device__ __forceinline__ double nan_to_num_t(double x) {      // torch.nan_to_num_ defaults, B:418-419
@@ -117,6 +176,39 @@ __device__ __forceinline__ float bilerp_ref(float f11, float f21, float f12, flo
     return degenerate ? f11 : r;          // B:170, B:193: either coordinate integral -> f(floor y, floor x)
 }
 
+// ---- diagnostic build only: in-kernel phase stamps (s_memtime), summed per wavefront in scalar
+// registers and added to p.stamps at the end.  Compiled out of the production library.
+#ifdef TPIV_STAMPS
+#define TPIV_STAMP_DECL unsigned long long st_acc[16] = {}; unsigned long long st_prev = 0; unsigned st_iter = 0;
+#define TPIV_STAMP_START                                                                  \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");    \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
+#define TPIV_STAMP(i)                                                                     \
+    do {                                                                                  \
+        unsigned long long st_t;                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        st_acc[i] += st_t - st_prev;                                                      \
+        st_prev = st_t;                                                                   \
+    } while (0)
+#define TPIV_STAMP_FLUSH(pp)                                                              \
+    do {                                                                                  \
+        if ((pp).stamps != nullptr && threadIdx.x == 0) {                                 \
+            for (int q_ = 0; q_ < 16; ++q_) atomicAdd(&(pp).stamps[q_], st_acc[q_]);      \
+            atomicAdd(&(pp).stamps[16], (unsigned long long)st_iter);                     \
+        }                                                                                 \
+    } while (0)
+#else
+#define TPIV_STAMP_DECL
+#define TPIV_STAMP_START
+#define TPIV_STAMP(i)
+#define TPIV_STAMP_FLUSH(pp)
+#endif
+
 // A workgroup is ONE wavefront, and the LDS executes one wavefront's DS instructions in order,
 // so exchanging data between lanes through LDS needs no s_barrier and no s_waitcnt: only the
 // compiler must keep the program order of the LDS accesses.  (A real __syncthreads() would also
@@ -131,9 +223,10 @@ __device__ __forceinline__ void wave_sync() {
 //      position when DIGITREV, else k)
 // out: lane (w, j) holds element j of every line: out[i] = element (line i, position j)
 template <int WS, bool DIGITREV>
-__device__ __forceinline__ void transpose_tile(cf (&a)[WS], cf* tile, int lane) {
+__device__ __forceinline__ void transpose_tile(cf (&a)[WS], float* lds, int lane) {
     using G = TileGeo<WS>;
     constexpr int P = G::PITCH;
+    cf* tile = reinterpret_cast<cf*>(lds);
     if constexpr (WS <= 32) {
         cf* t = tile + (lane / WS) * G::TILE;
         const int i = lane % WS;
@@ -192,7 +285,7 @@ __device__ __forceinline__ void transpose_tile(cf (&a)[WS], cf* tile, int lane) 
 //      the loads of item i+1 can be in flight while item i is transformed (software prefetch)
 struct ItemGeom {
     int pair, win, y0, x0;
-    bool active;
+    int active;          // int, not bool: byte members of loop-carried structs get copied through scratch
     size_t fidx;
 };
 
@@ -206,19 +299,19 @@ template <int WS>
 struct RawRows<WS, MODE_DWS> {
     uint32_t a[WS / 4], b[WS / 4];
     long long qa, qb;
-    bool reg;
+    int reg;             // wave-uniform: every lane's row is a plain in-frame byte run
 };
 template <int WS>
 struct RawRows<WS, MODE_CWS> {
     uint32_t a0[WS / 4 + 1], a1[WS / 4 + 1], b0[WS / 4 + 1], b1[WS / 4 + 1];    // WS+1 bytes per row
-    bool reg;
+    int reg;
 };
 
 // per-lane row geometry of the bilinear (CWS) shift, exactly as PIVbackend.py:162-172 computes it
 struct CwsRow {
     float wya_up, wya_dn, wyb_up, wyb_dn;
     int dya, uya, dyb, uyb;
-    bool ydeg_a, ydeg_b;
+    int ydeg_a, ydeg_b;
 };
 __device__ __forceinline__ CwsRow cws_row(int gy, float vy) {
     CwsRow c;
@@ -239,27 +332,29 @@ __device__ __forceinline__ CwsRow cws_row(int gy, float vy) {
     return c;
 }
 
+// The loads are issued UNCONDITIONALLY: a load under `if` makes the loaded registers the target of
+// a PHI copy, and the compiler then waits for the data right behind the load -- which would
+// cancel the prefetch.  Rows that need the slow path (frame border / rounding corner cases) load
+// from the un-shifted row instead (always inside the frame) and ignore the data.
 template <int WS, int MODE>
 __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& g, int r, float vx, float vy,
                                            RawRows<WS, MODE>& raw) {
     const int HW = p.H * p.W;
     const uint8_t* __restrict__ fa = p.A + (size_t)g.pair * HW;
     const uint8_t* __restrict__ fb = p.B + (size_t)g.pair * HW;
+    const long long base = (long long)(g.y0 + r) * p.W + g.x0;
     if constexpr (MODE == MODE_PASS1) {
-        const size_t off = (size_t)(g.y0 + r) * p.W + g.x0;
-        load_dwords<WS / 4>(fa + off, raw.a);
-        load_dwords<WS / 4>(fb + off, raw.b);
+        load_dwords<WS / 4>(fa + base, raw.a);
+        load_dwords<WS / 4>(fb + base, raw.b);
     } else if constexpr (MODE == MODE_DWS) {
         // integer shift on the FLAT index (B:213-215): a at idx - (vy*W + vx), b at idx + (...)
         const long long sh = (long long)vy * p.W + (long long)vx;
-        const long long base = (long long)(g.y0 + r) * p.W + g.x0;
         raw.qa = base - sh;
         raw.qb = base + sh;
-        raw.reg = raw.qa >= 0 && raw.qa + WS <= HW && raw.qb >= 0 && raw.qb + WS <= HW;
-        if (__all(raw.reg)) {
-            load_dwords<WS / 4>(fa + raw.qa, raw.a);
-            load_dwords<WS / 4>(fb + raw.qb, raw.b);
-        }
+        const bool reg = raw.qa >= 0 && raw.qa + WS <= HW && raw.qb >= 0 && raw.qb + WS <= HW;
+        raw.reg = __all(reg) ? 1 : 0;
+        load_dwords<WS / 4>(fa + (raw.reg ? raw.qa : base), raw.a);
+        load_dwords<WS / 4>(fb + (raw.reg ? raw.qb : base), raw.b);
     } else {
         constexpr int NB = WS / 4 + 1;
         const CwsRow c = cws_row(g.y0 + r, vy);
@@ -275,15 +370,16 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         const long long qa1 = (long long)c.uya * p.W + (g.x0 - ivx - 1);
         const long long qb0 = (long long)c.dyb * p.W + (g.x0 + ivx);
         const long long qb1 = (long long)c.uyb * p.W + (g.x0 + ivx);
-        const bool inb = qa0 >= 0 && qa1 + 4 * NB <= HW && qb0 >= 0 && qb1 + 4 * NB <= HW &&
-                         qa1 >= 0 && qa0 + 4 * NB <= HW && qb1 >= 0 && qb0 + 4 * NB <= HW;
-        raw.reg = inb && frac > thr && frac < 1.0f - thr && fabsf(vx) < (float)p.W;
-        if (__all(raw.reg)) {
-            load_dwords<NB>(fa + qa0, raw.a0);
-            load_dwords<NB>(fa + qa1, raw.a1);
-            load_dwords<NB>(fb + qb0, raw.b0);
-            load_dwords<NB>(fb + qb1, raw.b1);
-        }
+        const long long lim = (long long)HW - 4 * NB;
+        const bool inb = qa0 >= 0 && qa0 <= lim && qa1 >= 0 && qa1 <= lim && qb0 >= 0 && qb0 <= lim &&
+                         qb1 >= 0 && qb1 <= lim;
+        const bool reg = inb && frac > thr && frac < 1.0f - thr && fabsf(vx) < (float)p.W;
+        raw.reg = __all(reg) ? 1 : 0;
+        const long long safe = base < lim ? base : lim;
+        load_dwords<NB>(fa + (raw.reg ? qa0 : safe), raw.a0);
+        load_dwords<NB>(fa + (raw.reg ? qa1 : safe), raw.a1);
+        load_dwords<NB>(fb + (raw.reg ? qb0 : safe), raw.b0);
+        load_dwords<NB>(fb + (raw.reg ? qb1 : safe), raw.b1);
     }
 }
 
@@ -291,11 +387,11 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
 template <int WS, int MODE>
 __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom& g, int r, int lane, float vx,
                                              float vy, const RawRows<WS, MODE>& raw, cf (&x)[WS], float& sa,
-                                             float& sb, cf* tile) {
+                                             float& sb, float* lds) {
     const int HW = p.H * p.W;
     const uint8_t* __restrict__ fa = p.A + (size_t)g.pair * HW;
     const uint8_t* __restrict__ fb = p.B + (size_t)g.pair * HW;
-    float* rowbuf = reinterpret_cast<float*>(tile) + lane * (WS + 1);     // slow paths only
+    float* rowbuf = lds + lane * (WS + 1);     // slow paths only
     if constexpr (MODE == MODE_PASS1) {
         unsigned ia = 0, ib = 0;
 #pragma unroll
@@ -311,7 +407,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
             x[k].y = byte_f<k, WS / 4>(raw.b);
         });
     } else if constexpr (MODE == MODE_DWS) {
-        if (__all(raw.reg)) {
+        if (raw.reg) {
             static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int k = decltype(kc)::value;
                 x[k].x = byte_f<k, WS / 4>(raw.a);
@@ -341,7 +437,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         constexpr int NB = WS / 4 + 1;
         const CwsRow c = cws_row(g.y0 + r, vy);
         const float gx0f = (float)g.x0;
-        if (__all(raw.reg)) {
+        if (raw.reg) {
             static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int k = decltype(kc)::value;
                 const float gxf = gx0f + (float)k;                   // exact: small integers
@@ -397,12 +493,12 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int WS, int MODE>
-__global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
+template <int WS, int MODE, int OCC>
+__global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
     using G = TileGeo<WS>;
     static_assert(WS == 8 || WS == 16 || WS == 32 || WS == 64, "tile sizes of this kernel");
-    static_assert(64 * (WS + 1) * 4 <= G::LDS_CF * 8, "slow-path row buffer must fit the tile LDS");
-    __shared__ cf tile[G::LDS_CF];
+    static_assert(64 * (WS + 1) <= G::LDS_FLOATS, "slow-path row buffer must fit the tile LDS");
+    __shared__ float tile[G::LDS_FLOATS];
 
     const int lane = threadIdx.x;
     const int w = lane / WS;          // window slot inside the wavefront
@@ -428,7 +524,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
         g.pair = (int)(item / groups);
         const int gi = (int)(item % groups);
         const int win_raw = gi * G::WPW + w;
-        g.active = win_raw < N;
+        g.active = win_raw < N ? 1 : 0;
         g.win = g.active ? win_raw : N - 1;
         g.y0 = (g.win / p.n_cols) * st;
         g.x0 = (g.win % p.n_cols) * st;
@@ -453,22 +549,37 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
     RawRows<WS, MODE> raw;
     issue_rows<WS, MODE>(p, gcur, r, vx, vy, raw);
 
+    TPIV_STAMP_DECL
+    TPIV_STAMP_START;
     for (; item < hi; item += per_xcd) {
+#ifdef TPIV_STAMPS
+        ++st_iter;
+#endif
         const ItemGeom g = gcur;
-        const bool active = g.active;
+        const bool active = g.active != 0;
         const size_t fidx = g.fidx;
         // shifts of the NEXT item: fetched now, needed when its row loads are issued further down
-        const bool has_next = item + per_xcd < hi;
-        ItemGeom gnext = g;
-        float nvx = 0.f, nvy = 0.f;
-        if (has_next) {
-            gnext = geom_of(item + per_xcd);
-            shift_of(gnext, nvx, nvy);
+        // (the last iteration simply re-loads its own item: no branch around the prefetch)
+        const long long nitem = item + per_xcd < hi ? item + per_xcd : item;
+        const ItemGeom gnext = geom_of(nitem);
+        float nvx, nvy;
+        shift_of(gnext, nvx, nvy);
+
+        // predictor values of the combine step: loaded here, ahead of the row prefetch in the
+        // memory queue (vmcnt retires in order, so a later load would also wait for the prefetch)
+        double cu0 = 0.0, cv0 = 0.0, cu2 = 0.0, cv2 = 0.0;
+        if constexpr (MODE != MODE_PASS1) {
+            cu0 = p.u0[fidx];
+            cv0 = p.v0[fidx];
+            cu2 = p.u2[fidx];
+            cv2 = p.v2[fidx];
         }
 
         cf x[WS];
         float sa, sb;                      // window sums (for the mean)
+        TPIV_STAMP(0);      // loop head: geometry, next shifts, combine loads
         convert_rows<WS, MODE>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile);
+        TPIV_STAMP(1);      // wait for the rows + conversion / bilinear sampling
 
         if (p.dbg_win != nullptr && active) {     // test hook: the staged (shifted) windows
             float* d = p.dbg_win + fidx * 2 * WS * WS;
@@ -497,10 +608,14 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
             x[k].y = (x[k].y - mb) * kb;
         }
 
+        TPIV_STAMP(2);      // mean reduction + normalisation
         // ---- forward 2-D transform of a + i*b: rows in registers, transpose, columns in registers
         fft_inreg<WS, 1>(x);                              // over x; bin kx at x[FFT_POS<kx>]
+        TPIV_STAMP(3);      // forward row FFT
         transpose_tile<WS, true>(x, tile, lane);          // lane = kx, x[y] natural
+        TPIV_STAMP(4);      // transposition 1
         fft_inreg<WS, 1>(x);                              // over y; Z(ky, kx = lane) at x[FFT_POS<ky>]
+        TPIV_STAMP(5);      // forward column FFT
 
         // ---- cross-spectrum.  A = (Z(k) + conj Z(-k))/2, B = (Z(k) - conj Z(-k))/(2i),
         //      P = conj(A) * B / n^2.  Z(-ky, -kx) sits in lane (-kx mod WS), register (-ky mod WS).
@@ -537,6 +652,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
             });
         }
 
+        TPIV_STAMP(6);      // cross-spectrum incl. the bpermute exchange
         // ---- inverse: columns (natural-order input: rename registers), transpose, rows
         cf t[WS];
         static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
@@ -544,21 +660,23 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
             t[ky] = x[FFT_POS<ky, WS>];
         });
         fft_inreg<WS, -1>(t);                             // over ky; row y at t[FFT_POS<y>]
+        TPIV_STAMP(7);      // inverse column FFT
         transpose_tile<WS, true>(t, tile, lane);          // lane = y, t[kx] natural
+        TPIV_STAMP(8);      // transposition 2
         fft_inreg<WS, -1>(t);                             // over kx; corr(y = lane, x) at t[FFT_POS<x>].x
         wave_sync();                                  // tile reads done: it becomes the map
+        TPIV_STAMP(9);      // inverse row FFT
 
         // ---- prefetch: the next item's row loads fly while this item's peak search runs
-        if (has_next) {
-            issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
-            gcur = gnext;
-            vx = nvx;
-            vy = nvy;
-        }
+        issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
+        gcur = gnext;
+        vx = nvx;
+        vy = nvy;
 
+        TPIV_STAMP(10);     // issue of the next item's row loads
         // ---- correlation map in fftshift coordinates: y' = (r + WS/2) % WS, x' = (x + WS/2) % WS
-        float* my_map = reinterpret_cast<float*>(tile) + w * (WS * G::MAP_PITCH);
-        static_assert(G::WPW * WS * G::MAP_PITCH * 4 <= G::LDS_CF * 8, "map must fit the tile LDS");
+        float* my_map = tile + w * (WS * G::MAP_PITCH);
+        static_assert(G::WPW * WS * G::MAP_PITCH <= G::LDS_FLOATS, "map must fit the tile LDS");
         const int ys = (r + WS / 2) % WS;
         float cmin = 3.4e38f;
         static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
@@ -589,6 +707,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
             for (int k = 0; k < WS; ++k) d[ys * WS + k] = c[k];
         }
 
+        TPIV_STAMP(11);     // min, map, first peak
         // ---- second peak: arg-max outside the (2*wv+1)^2 FLAT-index neighbourhood (B:346-358):
         //      excluded q = clamp(m + i + WS*j), |i|,|j| <= wv, i.e. in row y' the columns
         //      mx+i (j = y'-my), mx+i+WS (j = y'-my+1) and mx+i-WS (j = y'-my-1), plus the clamps.
@@ -625,6 +744,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
         }
         second = grp_argmax<WS>(second);
 
+        TPIV_STAMP(12);     // second peak
         // ---- sub-pixel fit (B:385-407): lanes 0..5 of the window take one logarithm each
         {
             int left = m + 1, right = m - 1, top = m + WS, bot = m - WS;
@@ -668,8 +788,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
                     p.val[fidx] = invalid ? 1 : 0;
                 } else {
                     // multipass combine (B:728-738 / B:800-810)
-                    const double u0 = p.u0[fidx], v0 = p.v0[fidx];
-                    const double u2 = p.u2[fidx], v2 = p.v2[fidx];
+                    const double u0 = cu0, v0 = cv0, u2 = cu2, v2 = cv2;
                     double u = 2 * u2 + du;
                     double v = 2 * v2 + dv;
                     const bool mask_u = ((du > u0) && (rint(u0) > 0)) || invalid;
@@ -687,7 +806,9 @@ __global__ __launch_bounds__(64, 2) void xcorr_tile_kernel(PassParams p) {
             }
         }
         wave_sync();
+        TPIV_STAMP(13);     // sub-pixel fit, combine, stores
     }
+    TPIV_STAMP_FLUSH(p);
 }
 
 template <int WS, int MODE>
@@ -700,7 +821,20 @@ static hipError_t launch_tile(const PassParams& p, int n_cu, hipStream_t stream)
     const long long cap = (long long)n_cu * 64;     // a few waves of workgroups per CU, grid-stride above
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;                  // the XCD remap needs a multiple of 8
-    hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    // experiment switch: TPIV_OCC selects the register budget (wavefronts per SIMD) of the
+    // WS <= 32 kernels: 2 (256 VGPRs), 3 (168) or 4 (128)
+    static const int occ = [] {
+        const char* e = getenv("TPIV_OCC");
+        return e ? atoi(e) : 2;
+    }();
+    if (WS <= 32 && occ == 3)
+        hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, (WS <= 32 ? 3 : 2)>), dim3((unsigned)blocks), dim3(64), 0,
+                           stream, p);
+    else if (WS <= 32 && occ == 4)
+        hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, (WS <= 32 ? 4 : 2)>), dim3((unsigned)blocks), dim3(64), 0,
+                           stream, p);
+    else
+        hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 
