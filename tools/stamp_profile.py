@@ -32,6 +32,7 @@ for label, run in (("pass 1 (64x64)", "p1"), (f"pass 2 (32x32 {mode})", "p2")):
     s = stamps.cpu().numpy().astype(float)
     iters = s[16]
     tot = s[:14].sum()
-    print(f"{label}: {int(iters)} wave-iterations, {tot / iters:.0f} cycles per iteration")
+    print(f"{label}: {int(iters)} wave-iterations, {tot / iters:.0f} cycles per iteration; "
+          f"shader clock {s[17] / s[18] * 100:.0f} MHz (s_memtime / s_memrealtime)")
     for n, v in zip(NAMES, s[:14]):
         print(f"   {n:22s} {v / iters:9.0f} cyc  {100 * v / tot:5.1f} %")

@@ -28,14 +28,17 @@
 
 namespace tpiv {
 
-template <int WS>
+template <int WS, bool PLANAR_ = false>
 struct TileGeo {
     static constexpr int WPW = 64 / WS;                 // windows per wavefront
     static constexpr int TS = WS > 32 ? 32 : WS;        // transposition tile edge
     static constexpr int PITCH = TS + 1;                // complex elements per tile row
     static constexpr int NT = 64 / TS;                  // tiles per wavefront
     static constexpr int TILE = TS * PITCH;             // complex elements per tile
-    static constexpr int LDS_FLOATS = NT * TILE * 2;    // floats of LDS per wavefront (complex tiles)
+    // PLANAR: the real and the imaginary plane pass through the tile one after the other -- half
+    // the LDS per wavefront (8.4 KB), which is what lets a third wavefront fit per SIMD.
+    static constexpr bool PLANAR = PLANAR_;
+    static constexpr int LDS_FLOATS = NT * TILE * (PLANAR ? 1 : 2);
     static constexpr int MAP_PITCH = WS + 1;            // floats per row of the correlation map
     static constexpr int NDW = WS / 4;                  // dwords per window row
 };
@@ -179,7 +182,8 @@ __device__ __forceinline__ float bilerp_ref(float f11, float f21, float f12, flo
 // ---- diagnostic build only: in-kernel phase stamps (s_memtime), summed per wavefront in scalar
 // registers and added to p.stamps at the end.  Compiled out of the production library.
 #ifdef TPIV_STAMPS
-#define TPIV_STAMP_DECL unsigned long long st_acc[16] = {}; unsigned long long st_prev = 0; unsigned st_iter = 0;
+#define TPIV_STAMP_DECL unsigned long long st_acc[16] = {}; unsigned long long st_prev = 0; unsigned st_iter = 0; \
+    unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #define TPIV_STAMP_START                                                                  \
     do {                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                \
@@ -200,6 +204,8 @@ __device__ __forceinline__ float bilerp_ref(float f11, float f21, float f12, flo
         if ((pp).stamps != nullptr && threadIdx.x == 0) {                                 \
             for (int q_ = 0; q_ < 16; ++q_) atomicAdd(&(pp).stamps[q_], st_acc[q_]);      \
             atomicAdd(&(pp).stamps[16], (unsigned long long)st_iter);                     \
+            atomicAdd(&(pp).stamps[17], __builtin_amdgcn_s_memtime() - st_t0);            \
+            atomicAdd(&(pp).stamps[18], __builtin_amdgcn_s_memrealtime() - st_r0);        \
         }                                                                                 \
     } while (0)
 #else
@@ -222,12 +228,34 @@ __device__ __forceinline__ void wave_sync() {
 // in:  lane (w, i) holds line i of its window, element k at in[POS(k)]  (POS = digit-reversed
 //      position when DIGITREV, else k)
 // out: lane (w, j) holds element j of every line: out[i] = element (line i, position j)
-template <int WS, bool DIGITREV>
+template <int WS, bool DIGITREV, bool PLANAR>
 __device__ __forceinline__ void transpose_tile(cf (&a)[WS], float* lds, int lane) {
-    using G = TileGeo<WS>;
+    using G = TileGeo<WS, PLANAR>;
     constexpr int P = G::PITCH;
     cf* tile = reinterpret_cast<cf*>(lds);
-    if constexpr (WS <= 32) {
+    if constexpr (PLANAR) {
+        static_assert(WS <= 32, "planar tiles are for WS <= 32");
+        float* t = lds + (lane / WS) * G::TILE;
+        const int i = lane % WS;
+        wave_sync();
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            constexpr int src = DIGITREV ? FFT_POS<k, WS> : k;
+            t[i * P + k] = a[src].x;
+        });
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < WS; ++r) a[r].x = t[r * P + i];
+        wave_sync();
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            constexpr int src = DIGITREV ? FFT_POS<k, WS> : k;
+            t[i * P + k] = a[src].y;
+        });
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < WS; ++r) a[r].y = t[r * P + i];
+    } else if constexpr (WS <= 32) {
         cf* t = tile + (lane / WS) * G::TILE;
         const int i = lane % WS;
         wave_sync();
@@ -495,7 +523,8 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
 // ---------------------------------------------------------------------------------------------
 template <int WS, int MODE, int OCC>
 __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
-    using G = TileGeo<WS>;
+    constexpr bool PLANAR = OCC > 2 && WS <= 32;
+    using G = TileGeo<WS, PLANAR>;
     static_assert(WS == 8 || WS == 16 || WS == 32 || WS == 64, "tile sizes of this kernel");
     static_assert(64 * (WS + 1) <= G::LDS_FLOATS, "slow-path row buffer must fit the tile LDS");
     __shared__ float tile[G::LDS_FLOATS];
@@ -612,7 +641,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         // ---- forward 2-D transform of a + i*b: rows in registers, transpose, columns in registers
         fft_inreg<WS, 1>(x);                              // over x; bin kx at x[FFT_POS<kx>]
         TPIV_STAMP(3);      // forward row FFT
-        transpose_tile<WS, true>(x, tile, lane);          // lane = kx, x[y] natural
+        transpose_tile<WS, true, PLANAR>(x, tile, lane);          // lane = kx, x[y] natural
         TPIV_STAMP(4);      // transposition 1
         fft_inreg<WS, 1>(x);                              // over y; Z(ky, kx = lane) at x[FFT_POS<ky>]
         TPIV_STAMP(5);      // forward column FFT
@@ -661,7 +690,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         });
         fft_inreg<WS, -1>(t);                             // over ky; row y at t[FFT_POS<y>]
         TPIV_STAMP(7);      // inverse column FFT
-        transpose_tile<WS, true>(t, tile, lane);          // lane = y, t[kx] natural
+        transpose_tile<WS, true, PLANAR>(t, tile, lane);          // lane = y, t[kx] natural
         TPIV_STAMP(8);      // transposition 2
         fft_inreg<WS, -1>(t);                             // over kx; corr(y = lane, x) at t[FFT_POS<x>].x
         wave_sync();                                  // tile reads done: it becomes the map
@@ -818,7 +847,15 @@ static hipError_t launch_tile(const PassParams& p, int n_cu, hipStream_t stream)
     const long long groups = (N + G::WPW - 1) / G::WPW;
     const long long items = (long long)p.batch * groups;
     long long blocks = items;
-    const long long cap = (long long)n_cu * 64;     // a few waves of workgroups per CU, grid-stride above
+    // 64 single-wavefront workgroups per CU, grid-stride above that.  Measured (2048^2, 2-pass CWS):
+    // 8/CU (exactly the resident set, best L2 locality) 104.5 us/pair, 16/CU 102.6, 64/CU 98.2 --
+    // the dispatcher's dynamic balancing is worth more than keeping an XCD on adjacent windows
+    // (HBM traffic is ~6 % of peak either way).  TPIV_WG_PER_CU overrides for experiments.
+    static const int wg_per_cu = [] {
+        const char* e = getenv("TPIV_WG_PER_CU");
+        return e ? atoi(e) : 0;
+    }();
+    const long long cap = (long long)n_cu * (wg_per_cu > 0 ? wg_per_cu : 64);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;                  // the XCD remap needs a multiple of 8
     // experiment switch: TPIV_OCC selects the register budget (wavefronts per SIMD) of the
