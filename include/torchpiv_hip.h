@@ -143,6 +143,13 @@ int tpiv_debug_pass(int mode, const uint8_t* a_dev, const uint8_t* b_dev, int ba
                     double* u_dev, double* v_dev, uint8_t* invalid_dev,
                     float* win_dev, float* corr_dev, void* stream);
 
+/* Runs the plan's own (banded) predictor of pass `pass` (1 <= pass < n_pass) on caller-supplied
+ * coarse fields, exactly as tpiv_plan_run does between passes; same outputs as tpiv_predict.
+ * Lets the tests compare the banded operator with the dense one. */
+int tpiv_plan_debug_predict(tpiv_plan* plan, int pass, int batch,
+                            const double* u_c_dev, const double* v_c_dev, const uint8_t* invalid_c_dev,
+                            double* u0_dev, double* v0_dev, double* u2_dev, double* v2_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

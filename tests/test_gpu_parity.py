@@ -248,6 +248,35 @@ def test_single_iteration_vs_oracle(eng, mode):
     check_fields(gu[0], gv[0], ginv[0], ru, rv, rval, f"{mode} combined")
 
 
+@pytest.mark.parametrize("H,W,ws,n_pass,mode", [(256, 320, 64, 2, "CWS"), (264, 200, 32, 3, "DWS"),
+                                                  (2048, 2048, 64, 2, "CWS"), (4096, 4096, 32, 3, "CWS"),
+                                                  (2000, 3000, 64, 3, "DWS")])
+def test_banded_predictor_equals_dense(eng, H, W, ws, n_pass, mode):
+    """The plan's 65-tap banded spline predictor against the dense operator (itself checked against
+    SciPy/FITPACK on the CPU): the truncated tail is below float64 rounding."""
+    plan = eng.Plan(H, W, ws, ws // 2, n_pass=n_pass, mode=mode, max_batch=2)
+    g = torch.Generator(device="cpu").manual_seed(H + ws)
+    for p in range(1, n_pass):
+        wc, oc, nrc, ncc = plan.geometry[p - 1]
+        wf, of, nrf, ncf = plan.geometry[p]
+        u = (torch.randn(2, nrc, ncc, generator=g, dtype=torch.float64) * 5).cuda()
+        v = (torch.randn(2, nrc, ncc, generator=g, dtype=torch.float64) * 5).cuda()
+        inv = (torch.rand(2, nrc, ncc, generator=g) < 0.05).to(torch.uint8).cuda()
+        xc, yc = eng.coordinates_1d(H, W, wc, oc)
+        xf, yf = eng.coordinates_1d(H, W, wf, of)
+        Ay, Ax = dev(eng.spline_matrix(yc, yf)), dev(eng.spline_matrix(xc, xf))
+        dense = eng.predict(mode, Ay, Ax, u, v, inv)
+        banded = plan.debug_predict(p, u, v, inv)
+        for d, b_, name in zip(dense, banded, ("u0", "v0", "u2", "v2")):
+            # rint() in DWS may flip for a value within rounding of k + 0.5: compare where it did not
+            diff = (d - b_).abs()
+            if mode == "DWS" and name in ("u2", "v2"):
+                assert (diff > 1e-9).float().mean() < 1e-5
+            else:
+                assert diff.max().item() < 1e-12, (p, name, diff.max().item())
+    plan.close()
+
+
 def test_errors(eng):
     a = torch.zeros(64, 64, dtype=torch.uint8).cuda()
     with pytest.raises(ValueError):

@@ -32,5 +32,12 @@ ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters)]
 t = sorted(ts)[len(ts) // 2]
 print(f"size {H} ws {a.ws} passes {a.passes} {a.mode} batch {a.batch}: {t:.3f} ms/batch, "
       f"{t / a.batch * 1000:.1f} us/pair, {a.batch / t * 1000:.1f} pairs/s  (all: {[round(x, 2) for x in ts]})")
+plan.set_timing(True)
+for i in range(3):
+    plan.run(A, B, out=out)
+torch.cuda.synchronize()
+tm, n = plan.get_timing()
+print("per-kernel ms per batch:", {k: round(v, 3) for k, v in tm.items()}, " us/pair:",
+      {k: round(v / a.batch * 1000, 1) for k, v in tm.items()})
 u, v, inv = out
 print("invalid frac", inv.float().mean().item(), "u mean", u.mean().item(), "v mean", v.mean().item())

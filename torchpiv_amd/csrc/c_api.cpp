@@ -192,7 +192,11 @@ struct tpiv_plan {
     // device workspace
     std::vector<double*> u, v;           // per pass (all but the last): [max_batch, N_p]
     std::vector<uint8_t*> val;
-    std::vector<double*> Ay, Ax;         // per pass p >= 1: operators from pass p-1 to p
+    std::vector<double*> Ay, Ax;         // per pass p >= 1: dense operators from pass p-1 to p (debug)
+    // banded form used by tpiv_plan_run (piv_kernels.h: BandedPredictParams)
+    std::vector<double*> Wy, AxT;
+    std::vector<int*> k0y, startx;
+    std::vector<int> ku, bwx;
     double *u0 = nullptr, *v0 = nullptr, *u2 = nullptr, *v2 = nullptr, *T = nullptr;
     std::vector<void*> allocs;
     // optional per-kernel timing: events[run][2*slot + {0,1}]
@@ -227,6 +231,101 @@ struct tpiv_plan {
         return TPIV_OK;
     }
 };
+
+namespace {
+
+// band of one operator row: PRED_BW taps around the largest entry (clipped to the matrix); returns
+// the largest magnitude left outside so that the caller can verify the truncation is harmless
+constexpr int PRED_BW = 65;
+
+int band_start(const double* row, int nc, int bw) {
+    int c = 0;
+    double best = -1.0;
+    for (int j = 0; j < nc; ++j)
+        if (std::fabs(row[j]) > best) {
+            best = std::fabs(row[j]);
+            c = j;
+        }
+    int st = c - bw / 2;
+    if (st < 0) st = 0;
+    if (st + bw > nc) st = nc - bw;
+    return st;
+}
+
+template <typename T>
+int upload(tpiv_plan* pl, T** dst, const std::vector<T>& src) {
+    int rc = pl->alloc(dst, src.size());
+    if (rc) return rc;
+    hipError_t e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy(banded operator)");
+    return TPIV_OK;
+}
+
+int build_banded(tpiv_plan* pl, int p, int nrc, int ncc, int nrf, int ncf, const std::vector<double>& ay,
+                 const std::vector<double>& ax) {
+    // ---- column operator: per fine column a band, stored transposed [bw][ncf]
+    const int bwx = ncc < PRED_BW ? ncc : PRED_BW;
+    std::vector<int> sx(ncf);
+    std::vector<double> axT((size_t)bwx * ncf);
+    double leak = 0.0;
+    for (int f = 0; f < ncf; ++f) {
+        const double* row = &ax[(size_t)f * ncc];
+        int st = band_start(row, ncc, bwx);
+        if (f > 0 && st < sx[f - 1]) st = sx[f - 1];           // keep the starts monotone
+        sx[f] = st;
+        for (int j = 0; j < ncc; ++j) {
+            if (j >= st && j < st + bwx) axT[(size_t)(j - st) * ncf + f] = row[j];
+            else if (std::fabs(row[j]) > leak) leak = std::fabs(row[j]);
+        }
+    }
+    // the kernel stages startx[last] + bw - startx[first] values of a T1 row per 256 fine columns
+    for (int f0 = 0; f0 < ncf; f0 += 256) {
+        const int f1 = f0 + 255 < ncf ? f0 + 255 : ncf - 1;
+        if (sx[f1] + bwx - sx[f0] > 512) return fail(TPIV_EUNSUPPORTED, "predictor band stretch exceeds the LDS stage");
+    }
+    // ---- row operator: blocks of PRED_RB fine rows over the union of their bands
+    const int RB = tpiv::PRED_RB;
+    const int bwy = nrc < PRED_BW ? nrc : PRED_BW;
+    const int nblk = (nrf + RB - 1) / RB;
+    std::vector<int> sy(nrf);
+    for (int f = 0; f < nrf; ++f) {
+        int st = band_start(&ay[(size_t)f * nrc], nrc, bwy);
+        if (f > 0 && st < sy[f - 1]) st = sy[f - 1];
+        sy[f] = st;
+    }
+    int ku = 0;
+    std::vector<int> k0(nblk);
+    for (int b = 0; b < nblk; ++b) {
+        const int f0 = b * RB, f1 = (f0 + RB - 1 < nrf) ? f0 + RB - 1 : nrf - 1;
+        k0[b] = sy[f0];
+        const int len = sy[f1] + bwy - sy[f0];
+        if (len > ku) ku = len;
+    }
+    if (ku > nrc) ku = nrc;
+    std::vector<double> wy((size_t)nblk * ku * RB, 0.0);
+    for (int b = 0; b < nblk; ++b) {
+        if (k0[b] + ku > nrc) k0[b] = nrc - ku;                 // keep the tile inside the matrix
+        for (int i = 0; i < RB; ++i) {
+            const int f = b * RB + i;
+            if (f >= nrf) break;
+            const double* row = &ay[(size_t)f * nrc];
+            for (int j = 0; j < nrc; ++j) {
+                if (j >= k0[b] && j < k0[b] + ku) wy[((size_t)b * ku + (j - k0[b])) * RB + i] = row[j];
+                else if (std::fabs(row[j]) > leak) leak = std::fabs(row[j]);
+            }
+        }
+    }
+    if (leak > 1e-17) return fail(TPIV_EUNSUPPORTED, "spline operator does not fit the 65-tap band");
+    pl->ku[p] = ku;
+    pl->bwx[p] = bwx;
+    int rc = upload(pl, &pl->Wy[p], wy);
+    if (!rc) rc = upload(pl, &pl->AxT[p], axT);
+    if (!rc) rc = upload(pl, &pl->k0y[p], k0);
+    if (!rc) rc = upload(pl, &pl->startx[p], sx);
+    return rc;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -442,6 +541,12 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
     size_t max_fine = 0, max_T = 0;
     pl->Ay.assign(n_pass, nullptr);
     pl->Ax.assign(n_pass, nullptr);
+    pl->Wy.assign(n_pass, nullptr);
+    pl->AxT.assign(n_pass, nullptr);
+    pl->k0y.assign(n_pass, nullptr);
+    pl->startx.assign(n_pass, nullptr);
+    pl->ku.assign(n_pass, 0);
+    pl->bwx.assign(n_pass, 0);
     pl->u.assign(n_pass, nullptr);
     pl->v.assign(n_pass, nullptr);
     pl->val.assign(n_pass, nullptr);
@@ -466,9 +571,12 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
                     he = hipMemcpy(pl->Ax[p], ax.data(), ax.size() * sizeof(double), hipMemcpyHostToDevice);
                 if (he != hipSuccess) rc = hip_fail(he, "hipMemcpy(spline operators)");
             }
+            if (!rc) rc = build_banded(pl, p, c.n_rows, c.n_cols, g.n_rows, g.n_cols, ay, ax);
             if (N > max_fine) max_fine = N;
-            const size_t t = (size_t)3 * c.n_rows * g.n_cols;
+            const size_t t = (size_t)3 * g.n_rows * c.n_cols;     // T1 of the banded path
+            const size_t t_dense = (size_t)3 * c.n_rows * g.n_cols;
             if (t > max_T) max_T = t;
+            if (t_dense > max_T) max_T = t_dense;
         }
     }
     if (rc == TPIV_OK && n_pass > 1) {
@@ -511,6 +619,44 @@ int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u, double** 
     return TPIV_OK;
 }
 
+static int run_banded_predict(tpiv_plan* plan, int p, int batch, const double* u_c, const double* v_c,
+                              const uint8_t* val_c, double* u0, double* v0, double* u2, double* v2,
+                              hipStream_t st) {
+    const PassGeo& g = plan->geo[p];
+    const PassGeo& c = plan->geo[p - 1];
+    tpiv::BandedPredictParams q{};
+    q.batch = batch;
+    q.mode = plan->mode;
+    q.nrc = c.n_rows;
+    q.ncc = c.n_cols;
+    q.nrf = g.n_rows;
+    q.ncf = g.n_cols;
+    q.ku = plan->ku[p];
+    q.Wy = plan->Wy[p];
+    q.k0y = plan->k0y[p];
+    q.bwx = plan->bwx[p];
+    q.AxT = plan->AxT[p];
+    q.startx = plan->startx[p];
+    q.u_c = u_c;
+    q.v_c = v_c;
+    q.val_c = val_c;
+    q.T1 = plan->T;
+    q.u0 = u0;
+    q.v0 = v0;
+    q.u2 = u2;
+    q.v2 = v2;
+    hipError_t he = tpiv::launch_predict_banded(q, st);
+    return he == hipSuccess ? TPIV_OK : hip_fail(he, "launch_predict_banded");
+}
+
+int tpiv_plan_debug_predict(tpiv_plan* plan, int pass, int batch, const double* u_c, const double* v_c,
+                            const uint8_t* invalid_c, double* u0, double* v0, double* u2, double* v2,
+                            void* stream) {
+    if (!plan || pass < 1 || pass >= plan->n_pass) return fail(TPIV_EINVAL, "bad plan / pass index");
+    if (batch < 1 || batch > plan->max_batch) return fail(TPIV_EINVAL, "batch exceeds the plan's max_batch");
+    return run_banded_predict(plan, pass, batch, u_c, v_c, invalid_c, u0, v0, u2, v2, (hipStream_t)stream);
+}
+
 int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch, double* u, double* v,
                   uint8_t* invalid, void* stream) {
     if (!plan) return fail(TPIV_EINVAL, "null plan");
@@ -539,9 +685,8 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
         } else {
             const PassGeo& c = plan->geo[p - 1];
             mark(2 * p - 1, 0);
-            rc = tpiv_predict(plan->mode, batch, c.n_rows, c.n_cols, g.n_rows, g.n_cols, plan->Ay[p],
-                              plan->Ax[p], plan->u[p - 1], plan->v[p - 1], plan->val[p - 1], plan->T,
-                              plan->u0, plan->v0, plan->u2, plan->v2, stream);
+            rc = run_banded_predict(plan, p, batch, plan->u[p - 1], plan->v[p - 1], plan->val[p - 1], plan->u0,
+                                    plan->v0, plan->u2, plan->v2, st);
             mark(2 * p - 1, 1);
             mark(2 * p, 0);
             if (!rc)

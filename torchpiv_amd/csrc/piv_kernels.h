@@ -47,7 +47,32 @@ struct PredictParams {
     double* v2;
 };
 
+// Banded form of the predictor (plan path).  The rows of the spline operator decay like
+// 0.268^|j - j0|, so everything outside a 65-tap band is below float64 rounding of the sum.
+constexpr int PRED_RB = 8;        // fine rows per register block of the row operator
+struct BandedPredictParams {
+    int batch, mode;
+    int nrc, ncc, nrf, ncf;
+    // row operator Ay: per block of PRED_RB fine rows a zero-padded weight tile over the union band
+    int ku;                       // union band length (same for all blocks)
+    const double* Wy;             // [n_blk_y][ku][PRED_RB]
+    const int* k0y;               // [n_blk_y] first coarse row of the block's union band
+    // column operator Ax: per fine column a band of bwx taps starting at startx[cf]
+    int bwx;
+    const double* AxT;            // [bwx][ncf]
+    const int* startx;            // [ncf], non-decreasing
+    const double* u_c;            // [batch, nrc, ncc]
+    const double* v_c;
+    const uint8_t* val_c;
+    double* T1;                   // workspace [batch, 3, nrf, ncc]
+    double* u0;                   // [batch, nrf, ncf]
+    double* v0;
+    double* u2;
+    double* v2;
+};
+
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t stream);
 hipError_t launch_predict(const PredictParams& q, hipStream_t stream);
 
 }  // namespace tpiv

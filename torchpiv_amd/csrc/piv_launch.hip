@@ -90,6 +90,104 @@ __global__ void predict_rows_kernel(PredictParams q) {
     }
 }
 
+// ---- banded predictor (plan path) ------------------------------------------------------------
+// step A: T1[b, f, rf, cc] = sum_k Ay[rf, k] * Z_f[b, k, cc]; thread = coarse column (coalesced along
+// cc), PRED_RB fine rows per thread in registers, the block's weights are wave-uniform (scalar loads).
+__global__ __launch_bounds__(256) void predict_band_rows_kernel(BandedPredictParams q) {
+    const int cc = blockIdx.x * blockDim.x + threadIdx.x;
+    const int blk = blockIdx.y;
+    const int f = blockIdx.z % 3, b = blockIdx.z / 3;
+    if (cc >= q.ncc) return;
+    const int k0 = q.k0y[blk];
+    const double* __restrict__ w = q.Wy + (size_t)blk * q.ku * PRED_RB;
+    double acc[PRED_RB];
+#pragma unroll
+    for (int i = 0; i < PRED_RB; ++i) acc[i] = 0.0;
+    const size_t zoff = (size_t)b * q.nrc * q.ncc + cc;
+    const int kn = (k0 + q.ku <= q.nrc) ? q.ku : q.nrc - k0;
+    if (f == 2) {
+        const uint8_t* __restrict__ z = q.val_c + zoff;
+        for (int kk = 0; kk < kn; ++kk) {
+            const double zv = (double)z[(size_t)(k0 + kk) * q.ncc];
+#pragma unroll
+            for (int i = 0; i < PRED_RB; ++i) acc[i] += w[kk * PRED_RB + i] * zv;
+        }
+    } else {
+        const double* __restrict__ z = (f == 0 ? q.u_c : q.v_c) + zoff;
+        for (int kk = 0; kk < kn; ++kk) {
+            const double zv = z[(size_t)(k0 + kk) * q.ncc];
+#pragma unroll
+            for (int i = 0; i < PRED_RB; ++i) acc[i] += w[kk * PRED_RB + i] * zv;
+        }
+    }
+    double* __restrict__ t = q.T1 + (((size_t)b * 3 + f) * q.nrf) * q.ncc + cc;
+#pragma unroll
+    for (int i = 0; i < PRED_RB; ++i) {
+        const int rf = blk * PRED_RB + i;
+        if (rf < q.nrf) t[(size_t)rf * q.ncc] = acc[i];
+    }
+}
+
+// step B: out[b, rf, cf] = sum_k T1[b, f, rf, k] * Ax[cf, k] for the three fields, then the per-mode
+// predictor post-processing.  One block = one fine row x 256 fine columns; the needed stretch of the
+// T1 row is staged in LDS once, the weights are read coalesced from the transposed band table.
+__global__ __launch_bounds__(256) void predict_band_cols_kernel(BandedPredictParams q) {
+    __shared__ double seg[3][512];
+    const int cf0 = blockIdx.x * blockDim.x;
+    const int cf = cf0 + threadIdx.x;
+    const int rf = blockIdx.y, b = blockIdx.z;
+    const int cf_last = (cf0 + (int)blockDim.x - 1 < q.ncf) ? cf0 + (int)blockDim.x - 1 : q.ncf - 1;
+    const int kmin = q.startx[cf0];
+    const int len = q.startx[cf_last] + q.bwx - kmin;          // <= 512 (checked on the host)
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+            seg[f][i] = q.T1[(((size_t)b * 3 + f) * q.nrf + rf) * q.ncc + kmin + i];
+    }
+    __syncthreads();
+    if (cf >= q.ncf) return;
+    const int s0 = q.startx[cf] - kmin;
+    double u0 = 0.0, v0 = 0.0, vm = 0.0;
+    for (int kk = 0; kk < q.bwx; ++kk) {
+        const double a = q.AxT[(size_t)kk * q.ncf + cf];
+        u0 += a * seg[0][s0 + kk];
+        v0 += a * seg[1][s0 + kk];
+        vm += a * seg[2][s0 + kk];
+    }
+    const bool val = vm >= 0.5;                 // B:711 / B:778
+    double u2, v2;
+    if (q.mode == MODE_CWS) {                   // B:705-706: halves taken BEFORE the zeroing
+        u2 = u0 / 2;
+        v2 = v0 / 2;
+    }
+    if (val) {
+        u0 = 0.0;
+        v0 = 0.0;
+    }
+    if (q.mode == MODE_DWS) {                   // B:782-785: AFTER the zeroing, half-even
+        u2 = rint(u0 / 2);
+        v2 = rint(v0 / 2);
+    }
+    const size_t o = ((size_t)b * q.nrf + rf) * q.ncf + cf;
+    q.u0[o] = u0;
+    q.v0[o] = v0;
+    q.u2[o] = u2;
+    q.v2[o] = v2;
+}
+
+hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t stream) {
+    const int nblk = (q.nrf + PRED_RB - 1) / PRED_RB;
+    const int tx = q.ncc >= 256 ? 256 : (q.ncc >= 128 ? 128 : 64);
+    hipLaunchKernelGGL(predict_band_rows_kernel, dim3((q.ncc + tx - 1) / tx, nblk, q.batch * 3), dim3(tx), 0,
+                       stream, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int tc = q.ncf >= 256 ? 256 : (q.ncf >= 128 ? 128 : 64);
+    hipLaunchKernelGGL(predict_band_cols_kernel, dim3((q.ncf + tc - 1) / tc, q.nrf, q.batch), dim3(tc), 0,
+                       stream, q);
+    return hipGetLastError();
+}
+
 hipError_t launch_predict(const PredictParams& q, hipStream_t stream) {
     {
         const long long total = (long long)q.batch * 3 * q.nrc * q.ncf;

@@ -201,6 +201,17 @@ class Plan:
                                     v.data_ptr(), inv.data_ptr(), _stream()))
         return u, v, inv
 
+    def debug_predict(self, p, u_c, v_c, inv_c):
+        """Test hook: the plan's banded predictor of pass p on given coarse fields."""
+        B = u_c.shape[0]
+        _, _, nr, nc = self.geometry[p]
+        outs = [torch.empty(B, nr, nc, dtype=torch.float64, device=self.device) for _ in range(4)]
+        with torch.cuda.device(self.device):
+            check(lib.tpiv_plan_debug_predict(self._h, p, B, u_c.contiguous().data_ptr(),
+                                              v_c.contiguous().data_ptr(), inv_c.contiguous().data_ptr(),
+                                              *[o.data_ptr() for o in outs], _stream()))
+        return outs
+
     def set_timing(self, enable: bool):
         """Bracket every kernel of run() with hipEvents on the launch stream (bench.py)."""
         check(lib.tpiv_plan_set_timing(self._h, 1 if enable else 0))
