@@ -96,6 +96,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device: the hot path has no CPU fallback")
+    local = local % torch.cuda.device_count()       # rehearsal on fewer GPUs than ranks (gloo only)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     H = W = args.size
@@ -135,7 +136,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     timing, n_runs = plan.get_timing()

@@ -466,19 +466,30 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         const CwsRow c = cws_row(g.y0 + r, vy);
         const float gx0f = (float)g.x0;
         if (raw.reg) {
-            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-                constexpr int k = decltype(kc)::value;
-                const float gxf = gx0f + (float)k;                   // exact: small integers
+            // The x-direction weights depend on the column only (same for every row of the
+            // window): lane r evaluates them for column r exactly as B:164-171 does and parks
+            // them in LDS; every lane then reads the WS columns back (broadcast reads).
+            // In the fast path frac(vx) is away from 0/1, so ceil = floor + 1 and the column is
+            // never "integral" (only the row can be, ydeg_*).
+            float4* wbuf = reinterpret_cast<float4*>(lds) + (lane / WS) * WS;
+            {
+                const float gxf = gx0f + (float)r;               // exact: small integers
                 const float nxa = gxf - vx, nxb = gxf + vx;
                 const float uxa_f = ceilf(nxa), dxa_f = floorf(nxa);
                 const float uxb_f = ceilf(nxb), dxb_f = floorf(nxb);
+                wave_sync();
+                wbuf[r] = make_float4(uxa_f - nxa, nxa - dxa_f, uxb_f - nxb, nxb - dxb_f);
+                wave_sync();
+            }
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                const float4 wx = wbuf[k];
                 x[k].x = bilerp_ref(byte_f<k, NB>(raw.a0), byte_f<k + 1, NB>(raw.a0), byte_f<k, NB>(raw.a1),
-                                    byte_f<k + 1, NB>(raw.a1), uxa_f - nxa, nxa - dxa_f, c.wya_up, c.wya_dn,
-                                    c.ydeg_a || (uxa_f == dxa_f));
+                                    byte_f<k + 1, NB>(raw.a1), wx.x, wx.y, c.wya_up, c.wya_dn, c.ydeg_a != 0);
                 x[k].y = bilerp_ref(byte_f<k, NB>(raw.b0), byte_f<k + 1, NB>(raw.b0), byte_f<k, NB>(raw.b1),
-                                    byte_f<k + 1, NB>(raw.b1), uxb_f - nxb, nxb - dxb_f, c.wyb_up, c.wyb_dn,
-                                    c.ydeg_b || (uxb_f == dxb_f));
+                                    byte_f<k + 1, NB>(raw.b1), wx.z, wx.w, c.wyb_up, c.wyb_dn, c.ydeg_b != 0);
             });
+            wave_sync();
         } else {          // generic per-pixel gather with the flat-index clamp (rare: rolled loops
                           // that park the row in LDS)
             wave_sync();
@@ -631,10 +642,11 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             ka = dead ? 0.f : 1.0f / ma;
             kb = dead ? 0.f : 1.0f / mb;
         }
+        const float oa = -ma * ka, ob = -mb * kb;
 #pragma unroll
         for (int k = 0; k < WS; ++k) {
-            x[k].x = (x[k].x - ma) * ka;
-            x[k].y = (x[k].y - mb) * kb;
+            x[k].x = fmaf(x[k].x, ka, oa);          // (x - mean) * k
+            x[k].y = fmaf(x[k].y, kb, ob);
         }
 
         TPIV_STAMP(2);      // mean reduction + normalisation
@@ -651,10 +663,12 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         {
             const int partner = grp0 + ((WS - r) % WS);
             constexpr float scale = 0.25f / (float)(WS * WS);
+            // with zk = a + ib, zm = Z(-k) = c + id:  4 P = conj(2A) * (2B)
+            //   re = (a+c)(b+d) + (b-d)(c-a) = 2 (a d + b c),   im = (c^2 - a^2) + (d^2 - b^2)
             auto cross = [&](cf zk, cf zm) TPIV_LAMBDA_INLINE {
                 const float a_ = zk.x, b_ = zk.y, c_ = zm.x, d_ = zm.y;
                 cf pr;
-                pr.x = ((a_ + c_) * (b_ + d_) + (b_ - d_) * (c_ - a_)) * scale;
+                pr.x = (a_ * d_ + b_ * c_) * (2.0f * scale);
                 pr.y = ((c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_)) * scale;
                 return pr;
             };

@@ -22,7 +22,9 @@ def init_from_env(backend: str | None = None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # TPIV_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than
+            # ranks (RCCL refuses two ranks on one device); payloads are then staged through the host
+            backend = os.environ.get("TPIV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -57,6 +59,10 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
         return ids[order], fields[order]
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    out_dev = fields.device
+    if dist.get_backend(group) == "gloo" and fields.is_cuda:      # gloo moves host memory only
+        fields = fields.cpu()
+        ids = ids.cpu()
     dev = fields.device
     n_local = torch.tensor([ids.numel()], dtype=torch.int64, device=dev)
     counts = torch.zeros(world, dtype=torch.int64, device=dev)
@@ -76,7 +82,7 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
     keep = all_i >= 0
     all_i, all_f = all_i[keep], all_f[keep]
     order = torch.argsort(all_i)
-    return all_i[order], all_f[order]
+    return all_i[order].to(out_dev), all_f[order].to(out_dev)
 
 
 def run_sharded(piv, batch_size: int = 32, policy: str = "block", group=None):
