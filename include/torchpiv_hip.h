@@ -9,9 +9,12 @@
  *
  * Conventions
  *   - every pointer named *_dev is device memory on the CURRENT HIP device, owned by
- *     the caller (PyTorch-ROCm tensors: tensor.data_ptr()); nothing is allocated or
- *     freed by the run functions, which only enqueue work on `stream`
- *     (a hipStream_t passed as void*; NULL = the null stream) and return at once;
+ *     the caller (PyTorch-ROCm tensors: tensor.data_ptr()); the run functions only enqueue
+ *     work on `stream` (a hipStream_t passed as void*; NULL = the null stream) and return at
+ *     once.  tpiv_plan_run allocates nothing; the function-level entry points (tpiv_pass1 /
+ *     tpiv_iter) keep one grow-only scratch buffer per device inside the library (32 bytes per
+ *     window; re-allocated, with a device synchronise, only when a call needs more than any
+ *     earlier one);
  *   - fields are row-major [batch, n_rows, n_cols]; frames are uint8 [batch, H, W];
  *   - return value: TPIV_OK or an error code; tpiv_last_error() gives the message
  *     of the calling thread's last failure.  Nothing is thrown across the ABI.

@@ -33,6 +33,41 @@ int hip_fail(hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail(e_, #expr); \
     } while (0)
 
+// Workspace of the function-level seam (tpiv_pass1 / tpiv_iter / tpiv_debug_pass): the raw peak
+// records between the tile kernel and the finalize kernel.  One grow-only buffer per device, kept
+// by the library (a plan owns its own and never touches this one).
+struct Scratch {
+    int device = -1;
+    float* ptr = nullptr;
+    size_t bytes = 0;
+};
+Scratch g_scratch[16];
+
+int scratch_for(size_t bytes, float** out) {
+    *out = nullptr;
+    if (bytes == 0) return TPIV_OK;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return fail(TPIV_EUNSUPPORTED, "device index above 15");
+    Scratch& s = g_scratch[dev];
+    if (s.bytes < bytes) {
+        if (s.ptr) {
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(s.ptr);
+            s.ptr = nullptr;
+            s.bytes = 0;
+        }
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) return fail(TPIV_ENOMEM, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
+        s.ptr = static_cast<float*>(q);
+        s.bytes = bytes;
+        s.device = dev;
+    }
+    *out = s.ptr;
+    return TPIV_OK;
+}
+
 bool supported_ws(int ws) { return ws == 8 || ws == 16 || ws == 32 || ws == 64 || ws == 128; }
 
 // B:503-507 argument checks, then what the kernels cover
@@ -198,6 +233,7 @@ struct tpiv_plan {
     std::vector<int*> k0y, startx;
     std::vector<int> ku, bwx;
     double *u0 = nullptr, *v0 = nullptr, *u2 = nullptr, *v2 = nullptr, *T = nullptr;
+    float* peak_raw = nullptr;           // [max_batch, max N_p, 8] hand-off tile kernel -> finalize
     std::vector<void*> allocs;
     // optional per-kernel timing: events[run][2*slot + {0,1}]
     bool timing = false;
@@ -353,12 +389,15 @@ int tpiv_spline_matrix(int nc, const double* xc, int nf, const double* xf, doubl
     return spline_matrix(nc, xc, nf, xf, A);
 }
 
-int tpiv_pass1(const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws, int ov,
-               double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, void* stream) {
+static int pass1_impl(const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws, int ov,
+                      double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, float* peak_raw,
+                      float* dbg_win, float* dbg_corr, void* stream) {
     int rc = check_window(H, W, ws, ov, val_win);
     if (rc) return rc;
     if (batch <= 0) return TPIV_OK;
     tpiv::PassParams p{};
+    p.dbg_win = dbg_win;
+    p.dbg_corr = dbg_corr;
     p.A = a;
     p.B = b;
     p.batch = batch;
@@ -373,11 +412,22 @@ int tpiv_pass1(const uint8_t* a, const uint8_t* b, int batch, int H, int W, int 
     p.val_ratio = val_ratio;
     p.val_win = val_win;
     p.stamps = g_stamps;
+    p.peak_raw = peak_raw;
+    if (!peak_raw) {       // function-level call: library-owned scratch
+        rc = scratch_for(tpiv::peak_raw_bytes(ws, batch, p.n_rows * p.n_cols), &p.peak_raw);
+        if (rc) return rc;
+    }
     int n_cu;
     rc = n_cu_of_current_device(&n_cu);
     if (rc) return rc;
     HIP_TRY(tpiv::launch_xcorr(p, tpiv::MODE_PASS1, n_cu, (hipStream_t)stream));
     return TPIV_OK;
+}
+
+int tpiv_pass1(const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws, int ov,
+               double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, void* stream) {
+    return pass1_impl(a, b, batch, H, W, ws, ov, val_ratio, val_win, u, v, invalid, nullptr, nullptr, nullptr,
+                      stream);
 }
 
 int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf, const double* Ay,
@@ -409,7 +459,7 @@ int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf, const 
 static int run_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
                     int ov, const double* u0, const double* v0, const double* u2, const double* v2,
                     double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, double* du,
-                    double* dv, float* dbg_win, float* dbg_corr, void* stream) {
+                    double* dv, float* dbg_win, float* dbg_corr, float* peak_raw, void* stream) {
     if (mode != TPIV_MODE_DWS && mode != TPIV_MODE_CWS) return fail(TPIV_EKEY, "unknown multipass mode");
     int rc = check_window(H, W, ws, ov, val_win);
     if (rc) return rc;
@@ -437,6 +487,11 @@ static int run_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int
     p.dbg_win = dbg_win;
     p.dbg_corr = dbg_corr;
     p.stamps = g_stamps;
+    p.peak_raw = peak_raw;
+    if (!peak_raw) {
+        rc = scratch_for(tpiv::peak_raw_bytes(ws, batch, p.n_rows * p.n_cols), &p.peak_raw);
+        if (rc) return rc;
+    }
     int n_cu;
     rc = n_cu_of_current_device(&n_cu);
     if (rc) return rc;
@@ -449,37 +504,14 @@ int tpiv_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, in
               double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, double* du,
               double* dv, void* stream) {
     return run_iter(mode, a, b, batch, H, W, ws, ov, u0, v0, u2, v2, val_ratio, val_win, u, v, invalid,
-                    du, dv, nullptr, nullptr, stream);
+                    du, dv, nullptr, nullptr, nullptr, stream);
 }
 
 int tpiv_debug_pass(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
                     int ov, const double* u2, const double* v2, double* u, double* v,
                     uint8_t* invalid, float* win, float* corr, void* stream) {
-    if (mode == 0) {
-        int rc = check_window(H, W, ws, ov, 3);
-        if (rc) return rc;
-        tpiv::PassParams p{};
-        p.A = a;
-        p.B = b;
-        p.batch = batch;
-        p.H = H;
-        p.W = W;
-        p.ws = ws;
-        p.ov = ov;
-        field_shape(H, W, ws, ov, &p.n_rows, &p.n_cols);
-        p.u = u;
-        p.v = v;
-        p.val = invalid;
-        p.val_ratio = 1.2;
-        p.val_win = 3;
-        p.dbg_win = win;
-        p.dbg_corr = corr;
-        int n_cu;
-        rc = n_cu_of_current_device(&n_cu);
-        if (rc) return rc;
-        HIP_TRY(tpiv::launch_xcorr(p, tpiv::MODE_PASS1, n_cu, (hipStream_t)stream));
-        return TPIV_OK;
-    }
+    if (mode == 0)
+        return pass1_impl(a, b, batch, H, W, ws, ov, 1.2, 3, u, v, invalid, nullptr, win, corr, stream);
     int nr, nc;
     int rc = tpiv_field_shape(H, W, ws, ov, &nr, &nc);
     if (rc) return rc;
@@ -489,7 +521,7 @@ int tpiv_debug_pass(int mode, const uint8_t* a, const uint8_t* b, int batch, int
     hipError_t e = hipMemsetAsync(zero, 0, n * sizeof(double), (hipStream_t)stream);
     if (e == hipSuccess) {
         rc = run_iter(mode, a, b, batch, H, W, ws, ov, zero, zero, u2, v2, 1.2, 3, u, v, invalid, nullptr,
-                      nullptr, win, corr, stream);
+                      nullptr, win, corr, nullptr, stream);
         e = hipStreamSynchronize((hipStream_t)stream);
     }
     (void)hipFree(zero);
@@ -578,6 +610,14 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
             if (t > max_T) max_T = t;
             if (t_dense > max_T) max_T = t_dense;
         }
+    }
+    if (rc == TPIV_OK) {
+        size_t raw = 0;
+        for (const PassGeo& g : pl->geo) {
+            const size_t b = tpiv::peak_raw_bytes(g.ws, max_batch, g.n_rows * g.n_cols);
+            if (b > raw) raw = b;
+        }
+        if (raw) rc = pl->alloc(&pl->peak_raw, raw / sizeof(float));
     }
     if (rc == TPIV_OK && n_pass > 1) {
         rc = pl->alloc(&pl->u0, max_fine * max_batch);
@@ -679,8 +719,8 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
         int rc;
         if (p == 0) {
             mark(0, 0);
-            rc = tpiv_pass1(a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->val_ratio, plan->val_win, pu,
-                            pv, pval, stream);
+            rc = pass1_impl(a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->val_ratio, plan->val_win, pu, pv,
+                            pval, plan->peak_raw, nullptr, nullptr, stream);
             mark(0, 1);
         } else {
             const PassGeo& c = plan->geo[p - 1];
@@ -690,9 +730,9 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
             mark(2 * p - 1, 1);
             mark(2 * p, 0);
             if (!rc)
-                rc = tpiv_iter(plan->mode, a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->u0, plan->v0,
-                               plan->u2, plan->v2, plan->val_ratio, plan->val_win, pu, pv, pval, nullptr,
-                               nullptr, stream);
+                rc = run_iter(plan->mode, a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->u0, plan->v0,
+                              plan->u2, plan->v2, plan->val_ratio, plan->val_win, pu, pv, pval, nullptr,
+                              nullptr, nullptr, nullptr, plan->peak_raw, stream);
             mark(2 * p, 1);
         }
         if (rc) return rc;

@@ -30,6 +30,9 @@ struct PassParams {
     float* dbg_win;        // [batch, N, 2, ws, ws] staged windows (after the shift)
     float* dbg_corr;       // [batch, N, ws, ws] corr - min + eps, fftshift layout
     unsigned long long* stamps;   // diagnostic build (-DTPIV_STAMPS) only: per-phase cycle sums
+    // workspace [batch, N, 8] float32 between the tile kernel and finalize_kernel (WS <= 64):
+    // {c[m], c[left], c[right], c[top], c[bot], c[m2], bits(m), bits(dead)} per window
+    float* peak_raw;
 };
 
 struct PredictParams {
@@ -72,6 +75,8 @@ struct BandedPredictParams {
 };
 
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+// bytes of PassParams::peak_raw a pass needs (0 for the 128x128 kernel, which fuses its epilogue)
+size_t peak_raw_bytes(int ws, int batch, int n_windows);
 hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t stream);
 hipError_t launch_predict(const PredictParams& q, hipStream_t stream);
 

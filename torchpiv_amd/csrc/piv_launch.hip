@@ -12,15 +12,84 @@ hipError_t launch_xcorr_ws32(const PassParams& p, int mode, int n_cu, hipStream_
 hipError_t launch_xcorr_ws64(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws128(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 
+// ---- finalize: sub-pixel fit, validation and multipass combine, one thread per window -----------
+// PIVbackend.py:385-422 (correlation_to_displacement) and B:728-738 / B:800-810 (combine).  Input:
+// PassParams::peak_raw written by the tile kernel.
+__device__ __forceinline__ double nan_to_num_f(double x) {      // torch.nan_to_num_ defaults, B:418-419
+    if (x != x) return 0.0;
+    if (x > 1.7976931348623157e308) return 1.7976931348623157e308;
+    if (x < -1.7976931348623157e308) return -1.7976931348623157e308;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void finalize_kernel(PassParams p, int mode) {
+    const size_t total = (size_t)p.batch * p.n_rows * p.n_cols;
+    const int ws = p.ws;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float4* __restrict__ rw = reinterpret_cast<const float4*>(p.peak_raw + i * 8);
+        const float4 r0 = rw[0], r1 = rw[1];
+        const double cm = (double)r0.x, cl = (double)r0.y, cr = (double)r0.z, ct = (double)r0.w;
+        const double cb = (double)r1.x, c2 = (double)r1.y;
+        const int m = __float_as_int(r1.z);
+        const bool dead = __float_as_int(r1.w) != 0;
+        const double lm = log(cm), ll = log(cl), lr = log(cr), lt = log(ct), lb = log(cb);
+        const double nom1 = lr - ll;                           // B:399-402
+        const double den1 = 2 * (ll + lr) - 4 * lm;
+        const double nom2 = lb - lt;
+        const double den2 = 2 * (lb + lt) - 4 * lm;
+        double du = (double)(m % ws) + nom1 / den1 - (double)(ws / 2);
+        double dv = (double)(m / ws) + nom2 / den2 - (double)(ws / 2);
+        du = nan_to_num_f(du);
+        dv = nan_to_num_f(dv);
+        bool invalid = (cm / c2) < p.val_ratio;                // B:411
+        if (mode == MODE_PASS1) {
+            if (dead) {              // zero-mean window: all-NaN map in the reference -> u = v = 0, "valid"
+                du = 0.0;
+                dv = 0.0;
+                invalid = false;
+            }
+            p.u[i] = du;
+            p.v[i] = dv;
+            p.val[i] = invalid ? 1 : 0;
+        } else {                     // multipass combine (B:728-738 / B:800-810)
+            const double u0 = p.u0[i], v0 = p.v0[i], u2 = p.u2[i], v2 = p.v2[i];
+            double u = 2 * u2 + du;
+            double v = 2 * v2 + dv;
+            const bool mask_u = ((du > u0) && (rint(u0) > 0)) || invalid;
+            const bool mask_v = ((dv > v0) && (rint(v0) > 0)) || invalid;
+            if (mask_u) u = u0;
+            if (mask_v) v = v0;
+            p.u[i] = u;
+            p.v[i] = v;
+            p.val[i] = invalid ? 1 : 0;
+            if (p.du != nullptr) {
+                p.du[i] = du;
+                p.dv[i] = dv;
+            }
+        }
+    }
+}
+
+size_t peak_raw_bytes(int ws, int batch, int n_windows) {
+    return ws <= 64 ? (size_t)batch * n_windows * 8 * sizeof(float) : 0;
+}
+
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream) {
+    hipError_t e;
     switch (p.ws) {
-        case 8: return launch_xcorr_ws8(p, mode, n_cu, stream);
-        case 16: return launch_xcorr_ws16(p, mode, n_cu, stream);
-        case 32: return launch_xcorr_ws32(p, mode, n_cu, stream);
-        case 64: return launch_xcorr_ws64(p, mode, n_cu, stream);
-        case 128: return launch_xcorr_ws128(p, mode, n_cu, stream);
+        case 8: e = launch_xcorr_ws8(p, mode, n_cu, stream); break;
+        case 16: e = launch_xcorr_ws16(p, mode, n_cu, stream); break;
+        case 32: e = launch_xcorr_ws32(p, mode, n_cu, stream); break;
+        case 64: e = launch_xcorr_ws64(p, mode, n_cu, stream); break;
+        case 128: return launch_xcorr_ws128(p, mode, n_cu, stream);      // fused epilogue
         default: return hipErrorInvalidValue;
     }
+    if (e != hipSuccess) return e;
+    const size_t total = (size_t)p.batch * p.n_rows * p.n_cols;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > (size_t)n_cu * 32) blocks = (size_t)n_cu * 32;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, mode);
+    return hipGetLastError();
 }
 
 // ----------------------------------------------------------------------------

@@ -583,11 +583,16 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
 
     long long item = lo + slot;
     if (item >= hi) return;
+    auto next_of = [&](long long it) TPIV_LAMBDA_INLINE { return it + per_xcd < hi ? it + per_xcd : it; };
+    // software pipeline: rows of item i+1 in flight during item i, shifts fetched two items ahead
     ItemGeom gcur = geom_of(item);
     float vx, vy;
     shift_of(gcur, vx, vy);
     RawRows<WS, MODE> raw;
     issue_rows<WS, MODE>(p, gcur, r, vx, vy, raw);
+    ItemGeom gnext = geom_of(next_of(item));
+    float nvx, nvy;
+    shift_of(gnext, nvx, nvy);
 
     TPIV_STAMP_DECL
     TPIV_STAMP_START;
@@ -598,28 +603,19 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         const ItemGeom g = gcur;
         const bool active = g.active != 0;
         const size_t fidx = g.fidx;
-        // shifts of the NEXT item: fetched now, needed when its row loads are issued further down
-        // (the last iteration simply re-loads its own item: no branch around the prefetch)
-        const long long nitem = item + per_xcd < hi ? item + per_xcd : item;
-        const ItemGeom gnext = geom_of(nitem);
-        float nvx, nvy;
-        shift_of(gnext, nvx, nvy);
-
-        // predictor values of the combine step: loaded here, ahead of the row prefetch in the
-        // memory queue (vmcnt retires in order, so a later load would also wait for the prefetch)
-        double cu0 = 0.0, cv0 = 0.0, cu2 = 0.0, cv2 = 0.0;
-        if constexpr (MODE != MODE_PASS1) {
-            cu0 = p.u0[fidx];
-            cv0 = p.v0[fidx];
-            cu2 = p.u2[fidx];
-            cv2 = p.v2[fidx];
-        }
+        // (the last iterations simply re-load their own item: no branch around the prefetch)
+        const ItemGeom gnn = geom_of(next_of(next_of(item)));
+        float nnvx, nnvy;
+        shift_of(gnn, nnvx, nnvy);
 
         cf x[WS];
         float sa, sb;                      // window sums (for the mean)
         TPIV_STAMP(0);      // loop head: geometry, next shifts, combine loads
         convert_rows<WS, MODE>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile);
         TPIV_STAMP(1);      // wait for the rows + conversion / bilinear sampling
+        // small tiles: the row registers are free again, so the next item's loads go out now and
+        // have the whole iteration to land (64x64 is register-bound: it waits until the peak search)
+        if constexpr (WS <= 32) issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
 
         if (p.dbg_win != nullptr && active) {     // test hook: the staged (shifted) windows
             float* d = p.dbg_win + fidx * 2 * WS * WS;
@@ -711,10 +707,13 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         TPIV_STAMP(9);      // inverse row FFT
 
         // ---- prefetch: the next item's row loads fly while this item's peak search runs
-        issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
+        if constexpr (WS > 32) issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
         gcur = gnext;
         vx = nvx;
         vy = nvy;
+        gnext = gnn;
+        nvx = nnvx;
+        nvy = nnvy;
 
         TPIV_STAMP(10);     // issue of the next item's row loads
         // ---- correlation map in fftshift coordinates: y' = (r + WS/2) % WS, x' = (x + WS/2) % WS
@@ -788,9 +787,11 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         second = grp_argmax<WS>(second);
 
         TPIV_STAMP(12);     // second peak
-        // ---- sub-pixel fit (B:385-407): lanes 0..5 of the window take one logarithm each
+        // ---- hand-off to finalize_kernel (piv_launch.hip): the float64 logarithms, divisions and the
+        //      multipass combine of B:385-422 / B:728-738 need ONE lane per window, so they run in a
+        //      separate thread-per-window kernel; lanes 0..7 of the window store the raw peak data.
         {
-            int left = m + 1, right = m - 1, top = m + WS, bot = m - WS;
+            int left = m + 1, right = m - 1, top = m + WS, bot = m - WS;     // B:385-392 (flat index)
             if (left >= KD - 1) left = m;
             if (right <= 0) right = m;
             if (top >= KD - 1) top = m;
@@ -801,52 +802,10 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             q = (r == 3) ? top : q;
             q = (r == 4) ? bot : q;
             q = (r == 5) ? (second.idx < KD ? second.idx : m) : q;
-            const double val = (double)my_map[(q / WS) * G::MAP_PITCH + (q % WS)];
-            const double lg = log(val);
-            const double lm = __shfl(lg, grp0 + 0, 64);
-            const double ll = __shfl(lg, grp0 + 1, 64);
-            const double lr = __shfl(lg, grp0 + 2, 64);
-            const double lt = __shfl(lg, grp0 + 3, 64);
-            const double lb = __shfl(lg, grp0 + 4, 64);
-            const double cm = __shfl(val, grp0 + 0, 64);
-            const double c2 = __shfl(val, grp0 + 5, 64);
-            if (r == 0 && active) {
-                const double nom1 = lr - ll;
-                const double den1 = 2 * (ll + lr) - 4 * lm;
-                const double nom2 = lb - lt;
-                const double den2 = 2 * (lb + lt) - 4 * lm;
-                double du = (double)mx_ + nom1 / den1 - (double)(WS / 2);
-                double dv = (double)my_ + nom2 / den2 - (double)(WS / 2);
-                du = nan_to_num_t(du);
-                dv = nan_to_num_t(dv);
-                bool invalid = (cm / c2) < p.val_ratio;                  // B:411
-                if constexpr (MODE == MODE_PASS1) {
-                    if (dead) {             // all-NaN map in the reference: u = v = 0, "valid"
-                        du = 0.0;
-                        dv = 0.0;
-                        invalid = false;
-                    }
-                    p.u[fidx] = du;
-                    p.v[fidx] = dv;
-                    p.val[fidx] = invalid ? 1 : 0;
-                } else {
-                    // multipass combine (B:728-738 / B:800-810)
-                    const double u0 = cu0, v0 = cv0, u2 = cu2, v2 = cv2;
-                    double u = 2 * u2 + du;
-                    double v = 2 * v2 + dv;
-                    const bool mask_u = ((du > u0) && (rint(u0) > 0)) || invalid;
-                    const bool mask_v = ((dv > v0) && (rint(v0) > 0)) || invalid;
-                    if (mask_u) u = u0;
-                    if (mask_v) v = v0;
-                    p.u[fidx] = u;
-                    p.v[fidx] = v;
-                    p.val[fidx] = invalid ? 1 : 0;
-                    if (p.du != nullptr) {
-                        p.du[fidx] = du;
-                        p.dv[fidx] = dv;
-                    }
-                }
-            }
+            float outv = my_map[(q / WS) * G::MAP_PITCH + (q % WS)];
+            outv = (r == 6) ? __int_as_float(m) : outv;
+            outv = (r == 7) ? __int_as_float(dead ? 1 : 0) : outv;
+            if (r < 8 && active) p.peak_raw[fidx * 8 + r] = outv;
         }
         wave_sync();
         TPIV_STAMP(13);     // sub-pixel fit, combine, stores
