@@ -283,9 +283,68 @@ def g6_kats():
     save("g6_kats", **out)
 
 
+# ------------------------------------------------- G7 generic (non power-of-two) sizes
+G7_P1 = [
+    # name, H, W, ws, ov, kind, noise, special, index
+    ("ws48", 160, 208, 48, 12, "wavy", 2.0, False, 30),
+    ("ws24", 96, 136, 24, 8, "uniform", 1.0, False, 31),
+    ("ws100", 256, 320, 100, 50, "vortex", 2.0, True, 32),
+    ("ws256", 512, 640, 256, 128, "shear", 1.0, False, 33),
+    ("ws6", 40, 52, 6, 2, "zero", 3.0, False, 34),
+    ("ws33", 120, 150, 33, 11, "wavy", 2.0, False, 35),
+]
+G7_MP = [
+    # name, H, W, ws, ov, passes, scale, kind, noise, special, index: 64/32 -> 42/21 -> 28/14
+    ("s15x3", 320, 384, 64, 32, 3, 1.5, "wavy", 2.0, False, 36),
+    ("s13x2", 256, 288, 48, 24, 2, 1.3, "vortex", 3.0, True, 37),
+]
+
+
+def g7_generic():
+    out = {}
+    names = []
+    for (name, H, W, ws, ov, kind, noise, special, index) in G7_P1:
+        a, b = make_frames(H, W, kind, noise, special, index)
+        u, v, x, y, mask = ref.extended_search_area_piv(a, b, window_size=ws, overlap=ov, validate=True)
+        names.append(name)
+        out[name + "_a"], out[name + "_b"] = a.numpy(), b.numpy()
+        out[name + "_cfg"] = np.array([ws, ov])
+        out[name + "_u"], out[name + "_v"], out[name + "_mask"] = u, v, mask
+        print(f"  generic pass1 {name}: grid {u.shape}, invalid {int(mask.sum())}")
+    out["p1_names"] = np.array(names)
+    names = []
+    for (name, H, W, ws, ov, n_pass, scale, kind, noise, special, index) in G7_MP:
+        a, b = make_frames(H, W, kind, noise, special, index)
+        names.append(name)
+        out[name + "_a"], out[name + "_b"] = a.numpy(), b.numpy()
+        out[name + "_cfg"] = np.array([ws, ov, n_pass])
+        out[name + "_scale"] = np.array([scale])
+        for mode in ("DWS", "CWS"):
+            u, v, x, y, val = ref.extended_search_area_piv(a, b, window_size=ws, overlap=ov, validate=True)
+            out[f"{name}_{mode}_p0_u"], out[f"{name}_{mode}_p0_v"], out[f"{name}_{mode}_p0_val"] = u, v, val
+            w, o = ws, ov
+            geo = [[w, o]]
+            for p in range(1, n_pass):
+                w, o = int(w // scale), int(o // scale)
+                geo.append([w, o])
+                it = ref.IterModMap.functions[mode](a.shape, w, o, torch.device("cpu"))
+                u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
+                out[f"{name}_{mode}_p{p}_u"], out[f"{name}_{mode}_p{p}_v"] = u.copy(), v.copy()
+                out[f"{name}_{mode}_p{p}_val"] = val.copy()
+                print(f"\n  generic {name} {mode} pass {p}: ws {w}/{o} grid {u.shape} invalid {int(val.sum())}")
+            out[name + "_geo"] = np.array(geo)
+    out["mp_names"] = np.array(names)
+    save("g7_generic", **out)
+
+
 if __name__ == "__main__":
+    import sys as _sys
+    if len(_sys.argv) > 1 and _sys.argv[1] == "g7":
+        g7_generic()
+        raise SystemExit(0)
     g1_geometry()
     g3_pass1()
     g4_multipass()
     g5_generator()
     g6_kats()
+    g7_generic()

@@ -277,6 +277,69 @@ def test_banded_predictor_equals_dense(eng, H, W, ws, n_pass, mode):
     plan.close()
 
 
+def test_generic_sizes_pass1(eng, golden):
+    """Window sizes outside 8/16/32/64/128 run the generic-size kernel (plain DFT)."""
+    g = golden("g7_generic")
+    for name in g["p1_names"]:
+        ws, ov = (int(t) for t in g[name + "_cfg"])
+        a, b = g[name + "_a"], g[name + "_b"]
+        if ws % 2:           # odd sizes: the reference's ws x (ws-1) irfft2 quirk is not reproduced
+            with pytest.raises(NotImplementedError):
+                eng.pass1(dev(a), dev(b), ws, ov)
+            continue
+        u, v, inv = eng.pass1(dev(a), dev(b), ws, ov)
+        tie = near_tie_windows(a, b, ws, ov)
+        e, f = check_fields(u[0], v[0], inv[0], g[name + "_u"], g[name + "_v"], g[name + "_mask"], name,
+                            excused=tie)
+        print(f"generic pass1 {name} (ws {ws}): max err {e:.2e} px, mask flips {f}")
+
+
+@pytest.mark.parametrize("mode", ["DWS", "CWS"])
+def test_generic_sizes_multipass(eng, golden, mode):
+    """Refinement scales other than 2 (64 -> 42 -> 28; 48 -> 36): per pass from the reference's fields,
+    and the whole plan."""
+    g = golden("g7_generic")
+    for name in g["mp_names"]:
+        a, b = g[name + "_a"], g[name + "_b"]
+        H, W = a.shape
+        geo = g[name + "_geo"]
+        scale = float(g[name + "_scale"][0])
+        da, db = dev(a), dev(b)
+        for p in range(1, len(geo)):
+            wc, oc = (int(t) for t in geo[p - 1])
+            w, o = (int(t) for t in geo[p])
+            xc, yc = eng.coordinates_1d(H, W, wc, oc)
+            xf, yf = eng.coordinates_1d(H, W, w, o)
+            Ay, Ax = dev(eng.spline_matrix(yc, yf)), dev(eng.spline_matrix(xc, xf))
+            u0, v0, u2, v2 = eng.predict(mode, Ay, Ax, dev(g[f"{name}_{mode}_p{p-1}_u"])[None],
+                                         dev(g[f"{name}_{mode}_p{p-1}_v"])[None],
+                                         dev(g[f"{name}_{mode}_p{p-1}_val"].astype(np.uint8))[None])
+            u, v, inv = eng.iterate(mode, da, db, w, o, u0, v0, u2, v2)
+            idx = O.window_index((H, W), w, o)
+            sh = (lambda t: t[0].cpu().numpy().reshape(-1)[:, None, None])
+            if mode == "CWS":
+                aa = O.shift_cws(a, idx, -sh(u2).astype(np.float32), -sh(v2).astype(np.float32))
+                bb = O.shift_cws(b, idx, sh(u2).astype(np.float32), sh(v2).astype(np.float32))
+            else:
+                aa = O.shift_dws(a, idx, -sh(u2).astype(np.int64), -sh(v2).astype(np.int64))
+                bb = O.shift_dws(b, idx, sh(u2).astype(np.int64), sh(v2).astype(np.int64))
+            nr, nc = O.field_shape((H, W), w, o)
+            e, f = check_fields(u[0], v[0], inv[0], g[f"{name}_{mode}_p{p}_u"], g[f"{name}_{mode}_p{p}_v"],
+                                g[f"{name}_{mode}_p{p}_val"], f"{name} {mode} pass {p}",
+                                max_flip_frac=0.0, max_bad_frac=0.0, excused=fp32_noise_excuse(aa, bb, nr, nc))
+            print(f"generic {name} {mode} pass {p} (ws {w}/{o}): max err {e:.2e} px, mask flips {f}")
+        plan = eng.Plan(H, W, int(geo[0][0]), int(geo[0][1]), n_pass=len(geo), mode=mode, pass_scale=scale,
+                        max_batch=1)
+        assert [list(t[:2]) for t in plan.geometry] == geo.tolist()
+        u, v, inv = plan.run(da, db)
+        last = len(geo) - 1
+        err = np.maximum(np.abs(u[0].cpu().numpy() - g[f"{name}_{mode}_p{last}_u"]),
+                         np.abs(v[0].cpu().numpy() - g[f"{name}_{mode}_p{last}_v"]))
+        same = inv[0].cpu().numpy().astype(bool) == g[f"{name}_{mode}_p{last}_val"]
+        assert ((err <= TOL_PX) & same).mean() >= 0.93
+        plan.close()
+
+
 def test_errors(eng):
     a = torch.zeros(64, 64, dtype=torch.uint8).cuda()
     with pytest.raises(ValueError):
@@ -284,7 +347,8 @@ def test_errors(eng):
     with pytest.raises(ValueError):
         eng.pass1(a, a, 128, 64)
     with pytest.raises(NotImplementedError):
-        eng.pass1(a, a, 24, 12)
+        eng.pass1(torch.zeros(600, 600, dtype=torch.uint8).cuda(), torch.zeros(600, 600, dtype=torch.uint8).cuda(),
+                  300, 100)
     with pytest.raises(KeyError):
         eng.Plan(64, 64, 32, 16, n_pass=2, mode="XYZ")
     with pytest.raises(RuntimeError):

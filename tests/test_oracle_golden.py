@@ -108,3 +108,23 @@ def test_kats_post_validation(golden):
     assert np.allclose(filled, g["pv_filled"], rtol=0, atol=TOL, equal_nan=True)
     # quirk: a field with no invalid vector is dropped (returns None), B:303-304
     assert O.fill_missing(np.ones((5, 5))) is None
+
+
+def test_generic_sizes(golden):
+    """Non power-of-two windows and a 1.5 refinement scale (64 -> 42 -> 28), as the reference allows."""
+    g = golden("g7_generic")
+    for name in g["p1_names"]:
+        ws, ov = (int(t) for t in g[name + "_cfg"])
+        u, v, x, y, mask = O.pass1(g[name + "_a"], g[name + "_b"], ws, ov, validate=True)
+        assert np.abs(u - g[name + "_u"]).max() <= TOL and np.abs(v - g[name + "_v"]).max() <= TOL, name
+        assert np.array_equal(mask, g[name + "_mask"]), name
+    for name in g["mp_names"]:
+        a, b = g[name + "_a"], g[name + "_b"]
+        geo = g[name + "_geo"]
+        for mode in ("DWS", "CWS"):
+            u, v, x, y, val = O.pass1(a, b, int(geo[0][0]), int(geo[0][1]), validate=True)
+            for p in range(1, len(geo)):
+                it = O.ITER[mode](a.shape, int(geo[p][0]), int(geo[p][1]))
+                u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
+                assert np.abs(u - g[f"{name}_{mode}_p{p}_u"]).max() <= 1e-9, (name, mode, p)
+                assert np.array_equal(val, g[f"{name}_{mode}_p{p}_val"]), (name, mode, p)

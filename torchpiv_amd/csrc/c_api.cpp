@@ -68,7 +68,9 @@ int scratch_for(size_t bytes, float** out) {
     return TPIV_OK;
 }
 
-bool supported_ws(int ws) { return ws == 8 || ws == 16 || ws == 32 || ws == 64 || ws == 128; }
+// 8/16/32/64: second-generation tile kernel; 128: first-generation; anything else in 2..256:
+// generic-size DFT kernel (xcorr_generic.hip)
+bool supported_ws(int ws) { return ws >= 2 && ws <= 256; }
 
 // B:503-507 argument checks, then what the kernels cover
 int check_window(int H, int W, int ws, int ov, int val_win) {
@@ -76,9 +78,13 @@ int check_window(int H, int W, int ws, int ov, int val_win) {
     if (ws > H || ws > W) return fail(TPIV_EINVAL, "window size cannot be larger than the image");
     if (ws <= 0 || ov < 0 || H <= 0 || W <= 0) return fail(TPIV_EINVAL, "non-positive size");
     if (!supported_ws(ws))
-        return fail(TPIV_EUNSUPPORTED, "window size must be one of 8, 16, 32, 64, 128 (got " +
-                                           std::to_string(ws) + ")");
-    if (val_win < 0 || 2 * val_win >= ws)
+        return fail(TPIV_EUNSUPPORTED, "window size must be in 2..256 (got " + std::to_string(ws) + ")");
+    if (ws % 2 != 0)
+        return fail(TPIV_EUNSUPPORTED,
+                    "odd window sizes are not supported: the reference's irfft2 (no `s`) returns a "
+                    "ws x (ws-1) correlation map for them and its peak formulas mix the two extents");
+    const bool pow2 = ws == 8 || ws == 16 || ws == 32 || ws == 64 || ws == 128;
+    if (val_win < 0 || (pow2 && 2 * val_win >= ws))
         return fail(TPIV_EUNSUPPORTED, "validation half-window must satisfy 2*val_win < window size");
     if ((long long)H * W >= (1LL << 31)) return fail(TPIV_EUNSUPPORTED, "frame too large");
     return TPIV_OK;
@@ -617,7 +623,7 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
             const size_t b = tpiv::peak_raw_bytes(g.ws, max_batch, g.n_rows * g.n_cols);
             if (b > raw) raw = b;
         }
-        if (raw) rc = pl->alloc(&pl->peak_raw, raw / sizeof(float));
+        if (raw) rc = pl->alloc(&pl->peak_raw, raw / sizeof(float) + 64);
     }
     if (rc == TPIV_OK && n_pass > 1) {
         rc = pl->alloc(&pl->u0, max_fine * max_batch);

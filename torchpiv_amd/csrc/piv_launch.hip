@@ -11,6 +11,9 @@ hipError_t launch_xcorr_ws16(const PassParams& p, int mode, int n_cu, hipStream_
 hipError_t launch_xcorr_ws32(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws64(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws128(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+struct cf;
+hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, cf* scratch, hipStream_t stream);
+int generic_blocks(int ws, long long items, int n_cu);
 
 // ---- finalize: sub-pixel fit, validation and multipass combine, one thread per window -----------
 // PIVbackend.py:385-422 (correlation_to_displacement) and B:728-738 / B:800-810 (combine).  Input:
@@ -70,8 +73,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(PassParams p, int mode) {
     }
 }
 
+static bool tile_size(int ws) { return ws == 8 || ws == 16 || ws == 32 || ws == 64; }
+static size_t peak_bytes(int batch, int n_windows) {
+    return (((size_t)batch * n_windows * 8 * sizeof(float)) + 255) / 256 * 256;
+}
+
+// peak records, followed (generic sizes only) by the DFT scratch tiles of the resident workgroups
 size_t peak_raw_bytes(int ws, int batch, int n_windows) {
-    return ws <= 64 ? (size_t)batch * n_windows * 8 * sizeof(float) : 0;
+    if (ws == 128) return 0;                          // first-generation kernel: fused epilogue
+    size_t b = peak_bytes(batch, n_windows);
+    if (!tile_size(ws))
+        b += (size_t)generic_blocks(ws, (long long)batch * n_windows, 256) * 2 * ws * ws * 8;
+    return b;
 }
 
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream) {
@@ -82,7 +95,12 @@ hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t str
         case 32: e = launch_xcorr_ws32(p, mode, n_cu, stream); break;
         case 64: e = launch_xcorr_ws64(p, mode, n_cu, stream); break;
         case 128: return launch_xcorr_ws128(p, mode, n_cu, stream);      // fused epilogue
-        default: return hipErrorInvalidValue;
+        default: {
+            if (p.ws < 2 || p.ws > 256) return hipErrorInvalidValue;
+            cf* scratch = reinterpret_cast<cf*>(reinterpret_cast<char*>(p.peak_raw) +
+                                                peak_bytes(p.batch, p.n_rows * p.n_cols));
+            e = launch_xcorr_generic(p, mode, 256, scratch, stream);
+        }
     }
     if (e != hipSuccess) return e;
     const size_t total = (size_t)p.batch * p.n_rows * p.n_cols;
