@@ -340,28 +340,72 @@ class OfflinePIV:
 
     # ---- extension: batched processing (same results, many pairs per launch) ------------
     def batched(self, batch_size: int = 32, indices=None) -> Generator:
-        """Like __call__, but uploads and processes `batch_size` pairs per launch.  Yields
-        (pair_index, x, y, u, v); dropped pairs yield nothing."""
+        """Like __call__, but decodes, uploads and processes `batch_size` pairs per launch: a loader
+        thread decodes the next batch straight into pinned staging memory while the GPU works on the
+        current one (double buffered).  Yields (pair_index, x, y, u, v); dropped pairs yield nothing."""
+        import queue
+        import threading
+        from .io import decode_into
         idx = list(range(len(self._dataset))) if indices is None else list(indices)
-        for s in range(0, len(idx), batch_size):
-            chunk, A, B = [], [], []
-            for i in idx[s:s + batch_size]:
-                a, b = self._dataset[i]
-                if a is None or b is None:
-                    continue
-                chunk.append(i)
-                A.append(a)
-                B.append(b)
+        if not idx:
+            return
+        first = None
+        for i in idx:                       # frame shape from the first decodable pair
+            a0, _ = self._dataset[i]
+            if a0 is not None:
+                first = tuple(a0.shape)
+                break
+        if first is None:
+            return
+        H, W = first
+        plan = self._get_plan(H, W, max_batch=batch_size)
+        stage = [(torch.empty(batch_size, H, W, dtype=torch.uint8).pin_memory(),
+                  torch.empty(batch_size, H, W, dtype=torch.uint8).pin_memory()) for _ in range(2)]
+        free = [threading.Event(), threading.Event()]
+        for e in free:
+            e.set()
+        q = queue.Queue(maxsize=2)
+
+        def loader():
+            try:
+                for n, s in enumerate(range(0, len(idx), batch_size)):
+                    buf = n % 2
+                    free[buf].wait()
+                    free[buf].clear()
+                    sa, sb = stage[buf][0].numpy(), stage[buf][1].numpy()
+                    chunk = []
+                    for i in idx[s:s + batch_size]:
+                        pa, pb = self._dataset.img_pairs[i]
+                        k = len(chunk)
+                        if decode_into(pb, sb[k]) and decode_into(pa, sa[k]):
+                            chunk.append(i)
+                    q.put((buf, chunk))
+            finally:
+                q.put(None)
+
+        th = threading.Thread(target=loader, daemon=True)
+        th.start()
+        w, o, _, _ = plan.geometry[-1]
+        x, y = get_coordinates((H, W), w, o)
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            buf, chunk = item
             if not chunk:
+                free[buf].set()
                 continue
-            A = torch.stack(A).pin_memory().to(self._device, non_blocking=True)
-            B = torch.stack(B).pin_memory().to(self._device, non_blocking=True)
-            plan = self._get_plan(A.shape[-2], A.shape[-1], max_batch=batch_size)
+            n = len(chunk)
+            A = stage[buf][0][:n].to(self._device, non_blocking=True)
+            B = stage[buf][1][:n].to(self._device, non_blocking=True)
+            up = torch.cuda.Event()
+            up.record()
             u, v, inv = plan.run(A, B)
-            w, o, _, _ = plan.geometry[-1]
-            x, y = get_coordinates(A.shape[-2:], w, o)
+            up.synchronize()                  # staging buffer may be refilled now
+            free[buf].set()
             u, v, inv = u.cpu().numpy(), v.cpu().numpy(), inv.cpu().numpy().astype(bool)
             for k, i in enumerate(chunk):
                 out = self._finish(u[k], v[k], inv[k], x, y)
                 if out is not None:
                     yield (i,) + out
+        th.join()

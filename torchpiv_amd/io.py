@@ -55,7 +55,10 @@ def decode_bmp_gray(buf: bytes):
         pal = np.frombuffer(buf, dtype=np.uint8, count=n * 4, offset=14 + hdr).reshape(n, 4)
         lut = np.zeros(256, dtype=np.uint8)
         lut[:n] = _bgr_to_gray(pal[:, 0], pal[:, 1], pal[:, 2])
-        img = lut[raw[:, :w]]
+        if n == 256 and np.array_equal(lut, np.arange(256, dtype=np.uint8)):
+            img = raw[:, :w]            # grey ramp palette (what cameras write): the index IS the value
+        else:
+            img = lut[raw[:, :w]]
     else:
         px = raw[:, : w * (bpp // 8)].reshape(h, w, bpp // 8)
         img = _bgr_to_gray(px[..., 0], px[..., 1], px[..., 2])
@@ -85,6 +88,16 @@ def imdecode_gray(path: str):
         return None
 
 
+def decode_into(path: str, out: np.ndarray) -> bool:
+    """Decode `path` straight into a preallocated uint8 [H, W] buffer (e.g. a view of pinned
+    staging memory).  False if the file cannot be decoded or has another shape."""
+    img = imdecode_gray(path)
+    if img is None or img.shape != out.shape:
+        return False
+    np.copyto(out, img)
+    return True
+
+
 class ToTensor:
     """numpy array -> torch.Tensor of a fixed dtype (PIVbackend.py:103-112)."""
 
@@ -94,7 +107,10 @@ class ToTensor:
     def __call__(self, data):
         if data is None:
             return None
-        return torch.tensor(data, dtype=self.dtype)
+        # (the reference calls torch.tensor(data, dtype=...), a 19 ms element-wise copy for a 4 MP
+        #  frame; from_numpy shares the decoded buffer instead)
+        t = torch.from_numpy(np.ascontiguousarray(data))
+        return t if t.dtype == self.dtype else t.to(self.dtype)
 
 
 class PIVDataset(torch.utils.data.Dataset):
