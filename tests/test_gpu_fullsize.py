@@ -1,0 +1,78 @@
+"""BASELINE.json sizes on the GPU: direct comparison with the oracle on one 2048x2048 pair
+(2-pass CWS and DWS, wind 64 / overlap 32) and size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import piv_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from torchpiv_amd import synth
+    a, b = synth.make_pair(2048, 2048, 321, kind="wavy", noise=3.0, device="cuda")
+    return a, b
+
+
+@pytest.mark.parametrize("mode", ["CWS", "DWS"])
+def test_cfg2_against_oracle(pair, mode):
+    """configs[1]/[2] geometry (2048^2, 64/32 -> 32/16): >= 99.5 % of the 16 129 vectors within
+    1e-3 px of the oracle with the same validity (the rest: cascaded threshold decisions)."""
+    from torchpiv_amd import engine
+    a, b = pair
+    plan = engine.Plan(2048, 2048, 64, 32, n_pass=2, mode=mode, max_batch=1)
+    u, v, inv = plan.run(a, b)
+    an, bn = a.cpu().numpy(), b.cpu().numpy()
+    ou, ov, x, y, oval = O.pass1(an, bn, 64, 32, validate=True)
+    p1u, p1v, p1i = plan.pass_fields(0, 1)
+    assert np.abs(p1u[0].cpu().numpy() - ou).max() < 1e-3 and np.array_equal(p1i[0].cpu().numpy().astype(bool), oval)
+    ou, ov, x, y, oval = O.ITER[mode]((2048, 2048), 32, 16)(an, bn, x, y, ou, ov, oval)
+    err = np.maximum(np.abs(u[0].cpu().numpy() - ou), np.abs(v[0].cpu().numpy() - ov))
+    same = inv[0].cpu().numpy().astype(bool) == oval
+    frac = float(((err < 1e-3) & same).mean())
+    print(f"cfg2 {mode}: {frac:.5f} within 1e-3 px, median err {np.median(err):.2e}, invalid {int(oval.sum())}")
+    assert u.shape[1:] == (127, 127) and frac >= 0.995
+    plan.close()
+
+
+def test_batch_position_invariance(pair):
+    """A pair gives bit-identical fields wherever it sits in a batch (windows are independent)."""
+    from torchpiv_amd import engine, synth
+    a, b = pair
+    a2, b2 = synth.make_pair(2048, 2048, 322, kind="vortex", noise=2.0, device="cuda")
+    plan = engine.Plan(2048, 2048, 64, 32, n_pass=2, mode="CWS", max_batch=5)
+    A = torch.stack([a, a2, a2, a, a2])
+    B = torch.stack([b, b2, b2, b, b2])
+    u, v, inv = plan.run(A, B)
+    assert torch.equal(u[0], u[3]) and torch.equal(v[0], v[3]) and torch.equal(inv[0], inv[3])
+    assert torch.equal(u[1], u[2]) and torch.equal(u[1], u[4])
+    u1, v1, inv1 = engine.Plan(2048, 2048, 64, 32, n_pass=2, mode="CWS", max_batch=1).run(a, b)
+    assert torch.equal(u1[0], u[0]) and torch.equal(inv1[0], inv[0])
+    plan.close()
+
+
+def test_translation_covariance():
+    """Pass 1 depends on window content only: cropping both frames by one grid step (32 px) moves
+    the field by exactly one cell."""
+    from torchpiv_amd import engine, synth
+    a, b = synth.make_pair(1024 + 32, 1024 + 32, 77, kind="shear", noise=2.0, device="cuda")
+    u0, v0, i0 = engine.pass1(a[:1024, :1024].contiguous(), b[:1024, :1024].contiguous(), 64, 32)
+    u1, v1, i1 = engine.pass1(a[32:, 32:].contiguous(), b[32:, 32:].contiguous(), 64, 32)
+    assert torch.equal(u0[0, 1:, 1:], u1[0, :-1, :-1]) and torch.equal(v0[0, 1:, 1:], v1[0, :-1, :-1])
+    assert torch.equal(i0[0, 1:, 1:], i1[0, :-1, :-1])
+
+
+def test_known_displacement_recovered():
+    """Synthetic uniform flow (2.3, -1.6) px: the measured field recovers it (sign convention:
+    +u = frame b shifted towards +x, +v towards +y) on 4096^2 with three passes down to 8x8 tiles."""
+    from torchpiv_amd import engine, synth
+    a, b = synth.make_pair(4096, 4096, 9, kind="uniform", noise=1.0, device="cuda")
+    plan = engine.Plan(4096, 4096, 32, 16, n_pass=3, mode="CWS", max_batch=1)
+    u, v, inv = plan.run(a, b)
+    assert u.shape[1:] == (1023, 1023)
+    ok = inv[0] == 0
+    assert ok.float().mean() > 0.7
+    assert abs(u[0][ok].median().item() - 2.3) < 0.05 and abs(v[0][ok].median().item() + 1.6) < 0.05
+    plan.close()
