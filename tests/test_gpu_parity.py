@@ -130,6 +130,37 @@ def test_shift_kats_bit_exact(eng, golden):
     assert np.array_equal(win[0, :, 0].cpu().numpy(), g["shift_dws"].astype(np.float32))
 
 
+@pytest.mark.parametrize("ws", [16, 32, 64])
+def test_border_rows_bit_exact(eng, ws):
+    """Large shifts push whole window rows out of the frame (flat-index clamp: such a row reads the
+    first / last pixel everywhere, partially-outside rows wrap into the neighbouring image row):
+    the staged windows must stay bit-identical to the oracle for every border configuration."""
+    rng = np.random.default_rng(ws)
+    H, W, ov = 3 * ws + 8, 4 * ws + 4, ws // 2
+    frame_a = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
+    frame_b = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
+    idx = O.window_index((H, W), ws, ov)
+    nr, nc = O.field_shape((H, W), ws, ov)
+    n = nr * nc
+    for trial in range(3):
+        amp = (0.6 * ws, 2.5 * ws, 4.0)[trial]
+        vx = rng.uniform(-amp, amp, n).astype(np.float32)
+        vy = rng.uniform(-amp, amp, n).astype(np.float32)
+        vxd = torch.from_numpy(vx.astype(np.float64)).cuda().view(1, nr, nc)
+        vyd = torch.from_numpy(vy.astype(np.float64)).cuda().view(1, nr, nc)
+        _, _, _, win, _ = eng.debug_pass("CWS", dev(frame_a), dev(frame_b), ws, ov, vxd, vyd)
+        ra = O.shift_cws(frame_a, idx, -vx[:, None, None], -vy[:, None, None])
+        rb = O.shift_cws(frame_b, idx, vx[:, None, None], vy[:, None, None])
+        assert np.array_equal(win[0, :, 0].cpu().numpy(), ra) and np.array_equal(win[0, :, 1].cpu().numpy(), rb)
+        ix, iy = np.rint(vx).astype(np.int64), np.rint(vy).astype(np.int64)
+        ixd = torch.from_numpy(ix.astype(np.float64)).cuda().view(1, nr, nc)
+        iyd = torch.from_numpy(iy.astype(np.float64)).cuda().view(1, nr, nc)
+        _, _, _, win, _ = eng.debug_pass("DWS", dev(frame_a), dev(frame_b), ws, ov, ixd, iyd)
+        ra = O.shift_dws(frame_a, idx, -ix[:, None, None], -iy[:, None, None]).astype(np.float32)
+        rb = O.shift_dws(frame_b, idx, ix[:, None, None], iy[:, None, None]).astype(np.float32)
+        assert np.array_equal(win[0, :, 0].cpu().numpy(), ra) and np.array_equal(win[0, :, 1].cpu().numpy(), rb)
+
+
 @pytest.mark.parametrize("ws,ov,H,W", [(8, 4, 64, 96), (16, 8, 96, 128), (32, 16, 128, 192),
                                        (64, 32, 192, 256), (128, 64, 256, 384), (32, 0, 96, 160)])
 def test_corr_map_vs_oracle(eng, ws, ov, H, W):

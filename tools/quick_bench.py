@@ -12,9 +12,10 @@ ap.add_argument("--mode", default="CWS")
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--distinct", type=int, default=2)
 ap.add_argument("--iters", type=int, default=5)
+ap.add_argument("--kind", default="wavy")
 a = ap.parse_args()
 H = W = a.size
-A0, B0 = synth.make_batch(a.distinct, H, W, device="cuda")
+A0, B0 = synth.make_batch(a.distinct, H, W, device="cuda", kind=a.kind)
 A = A0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
 B = B0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
 plan = engine.Plan(H, W, a.ws, a.ws // 2, n_pass=a.passes, mode=a.mode, max_batch=a.batch)

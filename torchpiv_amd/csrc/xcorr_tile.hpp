@@ -327,12 +327,16 @@ template <int WS>
 struct RawRows<WS, MODE_DWS> {
     uint32_t a[WS / 4], b[WS / 4];
     long long qa, qb;
-    int reg;             // wave-uniform: every lane's row is a plain in-frame byte run
+    int reg;             // wave-uniform: every lane's rows can take the wide-load path
+    int cls;             // per lane, 2 bits per row: 0 in frame, 1 entirely before it, 2 entirely behind it
+    int fix;             // wave-uniform: some lane has a row of class 1 or 2
 };
 template <int WS>
 struct RawRows<WS, MODE_CWS> {
     uint32_t a0[WS / 4 + 1], a1[WS / 4 + 1], b0[WS / 4 + 1], b1[WS / 4 + 1];    // WS+1 bytes per row
     int reg;
+    int cls;             // see above (rows a0, a1, b0, b1 in bits 0-1, 2-3, 4-5, 6-7)
+    int fix;
 };
 
 // per-lane row geometry of the bilinear (CWS) shift, exactly as PIVbackend.py:162-172 computes it
@@ -360,6 +364,36 @@ __device__ __forceinline__ CwsRow cws_row(int gy, float vy) {
     return c;
 }
 
+// Row classes under the flat-index clamp (B:177-180, B:214): a run of `used` pixels starting at
+// flat index q that lies entirely before pixel 0 reads f[0] everywhere, entirely behind the last
+// pixel reads f[HW-1] everywhere; such rows (top / bottom border windows) stay on the wide-load
+// path: they load a safe address and the loaded dwords are overwritten with the broadcast pixel.
+// Class 3 (the run straddles either end of the frame) needs the per-pixel path.
+__device__ __forceinline__ int classify_row(long long q, int used, int loaded, int HW, long long& qload) {
+    const long long lim = (long long)HW - loaded;
+    if (q >= 0 && q <= lim) {
+        qload = q;
+        return 0;
+    }
+    if (q + used - 1 <= 0) {
+        qload = 0;
+        return 1;
+    }
+    if (q >= (long long)HW - 1) {
+        qload = lim;
+        return 2;
+    }
+    qload = 0;
+    return 3;
+}
+
+template <int N>
+__device__ __forceinline__ void fix_row(uint32_t (&d)[N], int cls) {
+    const uint32_t px = (cls == 1 ? (d[0] & 0xffu) : (d[N - 1] >> 24)) * 0x01010101u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = cls != 0 ? px : d[i];
+}
+
 // The loads are issued UNCONDITIONALLY: a load under `if` makes the loaded registers the target of
 // a PHI copy, and the compiler then waits for the data right behind the load -- which would
 // cancel the prefetch.  Rows that need the slow path (frame border / rounding corner cases) load
@@ -379,10 +413,13 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         const long long sh = (long long)vy * p.W + (long long)vx;
         raw.qa = base - sh;
         raw.qb = base + sh;
-        const bool reg = raw.qa >= 0 && raw.qa + WS <= HW && raw.qb >= 0 && raw.qb + WS <= HW;
-        raw.reg = __all(reg) ? 1 : 0;
-        load_dwords<WS / 4>(fa + (raw.reg ? raw.qa : base), raw.a);
-        load_dwords<WS / 4>(fb + (raw.reg ? raw.qb : base), raw.b);
+        long long la, lb;
+        const int ca = classify_row(raw.qa, WS, WS, HW, la), cb = classify_row(raw.qb, WS, WS, HW, lb);
+        raw.reg = __all(ca != 3 && cb != 3) ? 1 : 0;
+        raw.cls = ca | (cb << 2);
+        raw.fix = (raw.reg && __any(raw.cls != 0)) ? 1 : 0;
+        load_dwords<WS / 4>(fa + (raw.reg ? la : base), raw.a);
+        load_dwords<WS / 4>(fb + (raw.reg ? lb : base), raw.b);
     } else {
         constexpr int NB = WS / 4 + 1;
         const CwsRow c = cws_row(g.y0 + r, vy);
@@ -399,22 +436,26 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         const long long qb0 = (long long)c.dyb * p.W + (g.x0 + ivx);
         const long long qb1 = (long long)c.uyb * p.W + (g.x0 + ivx);
         const long long lim = (long long)HW - 4 * NB;
-        const bool inb = qa0 >= 0 && qa0 <= lim && qa1 >= 0 && qa1 <= lim && qb0 >= 0 && qb0 <= lim &&
-                         qb1 >= 0 && qb1 <= lim;
-        const bool reg = inb && frac > thr && frac < 1.0f - thr && fabsf(vx) < (float)p.W;
+        long long la0, la1, lb0, lb1;
+        const int c0 = classify_row(qa0, WS + 1, 4 * NB, HW, la0), c1 = classify_row(qa1, WS + 1, 4 * NB, HW, la1);
+        const int c2 = classify_row(qb0, WS + 1, 4 * NB, HW, lb0), c3 = classify_row(qb1, WS + 1, 4 * NB, HW, lb1);
+        const bool reg = c0 != 3 && c1 != 3 && c2 != 3 && c3 != 3 && frac > thr && frac < 1.0f - thr &&
+                         fabsf(vx) < (float)p.W;
         raw.reg = __all(reg) ? 1 : 0;
+        raw.cls = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
+        raw.fix = (raw.reg && __any(raw.cls != 0)) ? 1 : 0;
         const long long safe = base < lim ? base : lim;
-        load_dwords<NB>(fa + (raw.reg ? qa0 : safe), raw.a0);
-        load_dwords<NB>(fa + (raw.reg ? qa1 : safe), raw.a1);
-        load_dwords<NB>(fb + (raw.reg ? qb0 : safe), raw.b0);
-        load_dwords<NB>(fb + (raw.reg ? qb1 : safe), raw.b1);
+        load_dwords<NB>(fa + (raw.reg ? la0 : safe), raw.a0);
+        load_dwords<NB>(fa + (raw.reg ? la1 : safe), raw.a1);
+        load_dwords<NB>(fb + (raw.reg ? lb0 : safe), raw.b0);
+        load_dwords<NB>(fb + (raw.reg ? lb1 : safe), raw.b1);
     }
 }
 
 // raw rows -> float samples x[k] = (a, b) and the lane's partial sums
 template <int WS, int MODE>
 __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom& g, int r, int lane, float vx,
-                                             float vy, const RawRows<WS, MODE>& raw, cf (&x)[WS], float& sa,
+                                             float vy, RawRows<WS, MODE>& raw, cf (&x)[WS], float& sa,
                                              float& sb, float* lds) {
     const int HW = p.H * p.W;
     const uint8_t* __restrict__ fa = p.A + (size_t)g.pair * HW;
@@ -436,6 +477,10 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         });
     } else if constexpr (MODE == MODE_DWS) {
         if (raw.reg) {
+            if (raw.fix) {            // border windows: rows entirely outside the frame
+                fix_row(raw.a, raw.cls & 3);
+                fix_row(raw.b, (raw.cls >> 2) & 3);
+            }
             static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int k = decltype(kc)::value;
                 x[k].x = byte_f<k, WS / 4>(raw.a);
@@ -466,6 +511,12 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         const CwsRow c = cws_row(g.y0 + r, vy);
         const float gx0f = (float)g.x0;
         if (raw.reg) {
+            if (raw.fix) {            // border windows: rows entirely outside the frame
+                fix_row(raw.a0, raw.cls & 3);
+                fix_row(raw.a1, (raw.cls >> 2) & 3);
+                fix_row(raw.b0, (raw.cls >> 4) & 3);
+                fix_row(raw.b1, (raw.cls >> 6) & 3);
+            }
             // The x-direction weights depend on the column only (same for every row of the
             // window): lane r evaluates them for column r exactly as B:164-171 does and parks
             // them in LDS; every lane then reads the WS columns back (broadcast reads).
