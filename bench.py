@@ -157,7 +157,9 @@ def main():
         achieved = b_launch / t_dom / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        # the PMC passes were taken on the default workload only
+        default_cfg = (args.batch, args.size, args.ws, args.passes, args.mode) == (256, 2048, 64, 2, "CWS")
+        if default_cfg and os.path.exists(tpath):
             try:
                 with open(tpath) as f:
                     traffic = json.load(f).get(dom)
