@@ -146,6 +146,13 @@ int tpiv_debug_pass(int mode, const uint8_t* a_dev, const uint8_t* b_dev, int ba
                     double* u_dev, double* v_dev, uint8_t* invalid_dev,
                     float* win_dev, float* corr_dev, void* stream);
 
+/* Peak analysis alone -- correlation_to_displacement (B:360-422) + peak2peak_secondpeak
+ * (B:346-358) -- on caller-supplied correlation maps [n_maps, ws, ws] float32 in fftshift layout
+ * (ws = 8 or 16): runs the tile kernel's peak stage and finalize on them.  The kernel subtracts the
+ * map minimum first (B:518), so feed maps whose minimum is 0 to compare with the reference function. */
+int tpiv_debug_peaks(const float* maps_dev, int n_maps, int ws, double val_ratio, int val_win,
+                     double* u_dev, double* v_dev, uint8_t* invalid_dev, void* stream);
+
 /* Runs the plan's own (banded) predictor of pass `pass` (1 <= pass < n_pass) on caller-supplied
  * coarse fields, exactly as tpiv_plan_run does between passes; same outputs as tpiv_predict.
  * Lets the tests compare the banded operator with the dense one. */

@@ -371,6 +371,41 @@ def test_generic_sizes_multipass(eng, golden, mode):
         plan.close()
 
 
+@pytest.mark.parametrize("ws", [8, 16])
+def test_peak_logic_on_handmade_maps(eng, golden, ws):
+    """correlation_to_displacement + peak2peak_secondpeak on crafted maps: every one-sided fix-up
+    (m = 0, 1, k, k*d-2, k*(d-1)-1, last column -> first pixel of the next row), the wrap and the clamps
+    of the second-peak exclusion zone, ties, constant maps -- compared with the oracle, which the CPU
+    suite pins to the reference on the same tables (tests/golden/g6_kats.npz)."""
+    g = golden("g6_kats")
+    rng = np.random.default_rng(100 + ws)
+    maps = []
+    if ws == 16:
+        maps += [m for m in g["c2d16_maps"] if np.isfinite(m).all()]
+    else:
+        maps += list(g["c2d8_maps"])
+    n = ws * ws
+    specials = [0, 1, ws - 1, ws, ws + 1, n - ws - 1, n - ws, n - 2, n - 1, n // 2 + ws // 2, 5 * ws - 1, 6 * ws]
+    for m in specials:                      # a peak at every special flat index, rivals near the wraps
+        for rival in (None, (m + 4) % n, (m - 4) % n, (m + 3 * ws + 3) % n, (m + 4 * ws) % n, 0, n - 1):
+            a = rng.random((ws, ws)) * 5 + 1
+            a.flat[m] = 100.0
+            if m + 1 < n:
+                a.flat[m + 1] = 60.0
+            if m - 1 >= 0:
+                a.flat[m - 1] = 40.0
+            if rival is not None and rival != m:
+                a.flat[rival] = max(a.flat[rival], 90.0 if (rival + m) % 2 else 80.0)
+            maps.append(a)
+    maps += [rng.random((ws, ws)) * 10 for _ in range(64)]
+    maps = np.stack(maps).astype(np.float32)
+    maps = maps - maps.min(axis=(-2, -1), keepdims=True)          # the kernel applies B:518 itself
+    u, v, inv = eng.debug_peaks(torch.from_numpy(maps).cuda())
+    ou, ov, om = O.corr_to_disp(maps.copy(), maps.shape[0], 1, validate=True)
+    assert np.array_equal(inv.cpu().numpy().astype(bool), om[:, 0])
+    assert np.abs(u.cpu().numpy() - ou[:, 0]).max() < 1e-9 and np.abs(v.cpu().numpy() - ov[:, 0]).max() < 1e-9
+
+
 def test_errors(eng):
     a = torch.zeros(64, 64, dtype=torch.uint8).cuda()
     with pytest.raises(ValueError):

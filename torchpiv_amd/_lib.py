@@ -64,6 +64,7 @@ SIGNATURES = {
     "tpiv_plan_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), _int, C.POINTER(C.c_int)]),
     "tpiv_plan_debug_predict": (C.c_int, [C.c_void_p, _int, _int, _f64p, _f64p, _u8p, _f64p, _f64p, _f64p,
                                           _f64p, _vp]),
+    "tpiv_debug_peaks": (C.c_int, [_f32p, _int, _int, _dbl, _int, _f64p, _f64p, _u8p, _vp]),
     "tpiv_debug_pass": (C.c_int, [_int, _u8p, _u8p, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p,
                                   _f64p, _u8p, _f32p, _f32p, _vp]),
 }

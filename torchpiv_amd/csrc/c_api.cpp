@@ -535,6 +535,26 @@ int tpiv_debug_pass(int mode, const uint8_t* a, const uint8_t* b, int batch, int
     return rc;
 }
 
+int tpiv_debug_peaks(const float* maps, int n_maps, int ws, double val_ratio, int val_win, double* u,
+                     double* v, uint8_t* invalid, void* stream) {
+    if (ws != 8 && ws != 16) return fail(TPIV_EUNSUPPORTED, "tpiv_debug_peaks handles 8x8 and 16x16 maps");
+    if (n_maps <= 0) return TPIV_OK;
+    tpiv::PassParams p{};
+    p.batch = 1;
+    p.ws = ws;
+    p.n_rows = n_maps;
+    p.n_cols = 1;
+    p.u = u;
+    p.v = v;
+    p.val = invalid;
+    p.val_ratio = val_ratio;
+    p.val_win = val_win;
+    int rc = scratch_for((size_t)n_maps * 8 * sizeof(float), &p.peak_raw);
+    if (rc) return rc;
+    HIP_TRY(tpiv::launch_peaks_from_maps(p, maps, n_maps, (hipStream_t)stream));
+    return TPIV_OK;
+}
+
 int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, int mode,
                      double pass_scale, double val_ratio, int val_win, int max_batch) {
     if (!out) return fail(TPIV_EINVAL, "null plan pointer");

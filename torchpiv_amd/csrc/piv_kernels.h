@@ -77,6 +77,7 @@ struct BandedPredictParams {
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 // bytes of PassParams::peak_raw a pass needs (0 for the 128x128 kernel, which fuses its epilogue)
 size_t peak_raw_bytes(int ws, int batch, int n_windows);
+hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_maps, hipStream_t stream);
 hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t stream);
 hipError_t launch_predict(const PredictParams& q, hipStream_t stream);
 

@@ -11,6 +11,8 @@ hipError_t launch_xcorr_ws16(const PassParams& p, int mode, int n_cu, hipStream_
 hipError_t launch_xcorr_ws32(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws64(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws128(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+hipError_t launch_peak_debug_ws8(const PassParams& p, const float* maps, int n_maps, hipStream_t stream);
+hipError_t launch_peak_debug_ws16(const PassParams& p, const float* maps, int n_maps, hipStream_t stream);
 struct cf;
 hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, cf* scratch, hipStream_t stream);
 int generic_blocks(int ws, long long items, int n_cu);
@@ -79,6 +81,17 @@ static size_t peak_bytes(int batch, int n_windows) {
 }
 
 // peak records, followed (generic sizes only) by the DFT scratch tiles of the resident workgroups
+// test hook: peak analysis + finalize (pass-1 semantics) on caller-supplied correlation maps
+hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_maps, hipStream_t stream) {
+    hipError_t e;
+    if (p.ws == 8) e = launch_peak_debug_ws8(p, maps, n_maps, stream);
+    else if (p.ws == 16) e = launch_peak_debug_ws16(p, maps, n_maps, stream);
+    else return hipErrorInvalidValue;
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(finalize_kernel, dim3((n_maps + 255) / 256), dim3(256), 0, stream, p, (int)MODE_PASS1);
+    return hipGetLastError();
+}
+
 size_t peak_raw_bytes(int ws, int batch, int n_windows) {
     if (ws == 128) return 0;                          // first-generation kernel: fused epilogue
     size_t b = peak_bytes(batch, n_windows);

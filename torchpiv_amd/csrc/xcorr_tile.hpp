@@ -582,6 +582,104 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
     }
 }
 
+// ---- peak analysis of one correlation row per lane (B:346-358, B:381-392, B:518) -----------------
+// in: lane (w, r) holds row y = r of its window's circular correlation, value at column x in
+// t[FFT_POS<x>].x (un-shifted coordinates).  Writes the window's 8-float record for finalize_kernel.
+template <int WS, bool PLANAR>
+__device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], float* tile, int w, int r,
+                                              bool active, bool dead, size_t fidx) {
+    using G = TileGeo<WS, PLANAR>;
+    // ---- correlation map in fftshift coordinates: y' = (r + WS/2) % WS, x' = (x + WS/2) % WS
+    float* my_map = tile + w * (WS * G::MAP_PITCH);
+    static_assert(G::WPW * WS * G::MAP_PITCH <= G::LDS_FLOATS, "map must fit the tile LDS");
+    const int ys = (r + WS / 2) % WS;
+    float cmin = 3.4e38f;
+    static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+        constexpr int k = decltype(kc)::value;
+        cmin = fminf(cmin, t[FFT_POS<k, WS>].x);
+    });
+    cmin = grp_min<WS>(cmin);
+    ArgMaxT best{-1.f, 0};
+    float c[WS];                                      // shifted row: c[x'] = corr - min + eps
+    static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+        constexpr int xsft = decltype(kc)::value;     // ascending shifted column
+        constexpr int xo = (xsft + WS / 2) % WS;
+        // B:518 corr - min; B:381 corr += eps (float32 arithmetic in passes >= 2)
+        const float v = __fadd_rn(__fsub_rn(t[FFT_POS<xo, WS>].x, cmin), 1e-7f);
+        c[xsft] = v;
+        my_map[ys * G::MAP_PITCH + xsft] = v;
+        if (v > best.v) {
+            best.v = v;
+            best.idx = ys * WS + xsft;
+        }
+    });
+    best = grp_argmax<WS>(best);
+    wave_sync();                                  // map complete
+
+    if (p.dbg_corr != nullptr && active) {
+        float* d = p.dbg_corr + fidx * WS * WS;
+#pragma unroll
+        for (int k = 0; k < WS; ++k) d[ys * WS + k] = c[k];
+    }
+
+    // ---- second peak: arg-max outside the (2*wv+1)^2 FLAT-index neighbourhood (B:346-358):
+    //      excluded q = clamp(m + i + WS*j), |i|,|j| <= wv, i.e. in row y' the columns
+    //      mx+i (j = y'-my), mx+i+WS (j = y'-my+1) and mx+i-WS (j = y'-my-1), plus the clamps.
+    const int m = best.idx;
+    const int KD = WS * WS;
+    const int wv = p.val_win;
+    const int my_ = m / WS, mx_ = m % WS;
+    ArgMaxT second{-1.f, KD};
+    {
+        const int dj = ys - my_;
+        unsigned long long ex = 0ull;                 // bit x' set = excluded in this lane's row
+        auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {     // bits lo_..hi_ clipped to the row
+            lo_ = lo_ < 0 ? 0 : lo_;
+            hi_ = hi_ > WS - 1 ? WS - 1 : hi_;
+            if (lo_ > hi_) return 0ull;
+            const unsigned long long ones = (hi_ - lo_ + 1) >= 64 ? ~0ull : ((1ull << (hi_ - lo_ + 1)) - 1ull);
+            return ones << lo_;
+        };
+        if (dj >= -wv && dj <= wv) ex |= span(mx_ - wv, mx_ + wv);
+        if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(mx_ - wv + WS, mx_ + wv + WS);
+        if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx_ - wv - WS, mx_ + wv - WS);
+        if (ys == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;                       // clamp to 0
+        if (ys == WS - 1 && (m + wv + wv * WS) >= KD - 1) ex |= 1ull << (WS - 1);  // clamp to KD-1
+        const unsigned exl = (unsigned)ex, exh = (unsigned)(ex >> 32);
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int xsft = decltype(kc)::value;
+            const bool excl = ((xsft < 32 ? exl : exh) >> (xsft & 31)) & 1u;
+            const float v = c[xsft];
+            if (!excl && v > second.v) {
+                second.v = v;
+                second.idx = ys * WS + xsft;
+            }
+        });
+    }
+    second = grp_argmax<WS>(second);
+
+    // ---- hand-off to finalize_kernel (piv_launch.hip): the float64 logarithms, divisions and the
+    //      multipass combine of B:385-422 / B:728-738 need ONE lane per window, so they run in a
+    //      separate thread-per-window kernel; lanes 0..7 of the window store the raw peak data.
+    {
+        int left = m + 1, right = m - 1, top = m + WS, bot = m - WS;     // B:385-392 (flat index)
+        if (left >= KD - 1) left = m;
+        if (right <= 0) right = m;
+        if (top >= KD - 1) top = m;
+        if (bot <= 0) bot = m;
+        int q = m;
+        q = (r == 1) ? left : q;
+        q = (r == 2) ? right : q;
+        q = (r == 3) ? top : q;
+        q = (r == 4) ? bot : q;
+        q = (r == 5) ? (second.idx < KD ? second.idx : m) : q;
+        float outv = my_map[(q / WS) * G::MAP_PITCH + (q % WS)];
+        outv = (r == 6) ? __int_as_float(m) : outv;
+        outv = (r == 7) ? __int_as_float(dead ? 1 : 0) : outv;
+        if (r < 8 && active) p.peak_raw[fidx * 8 + r] = outv;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int WS, int MODE, int OCC>
 __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
@@ -767,101 +865,42 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         nvy = nnvy;
 
         TPIV_STAMP(10);     // issue of the next item's row loads
-        // ---- correlation map in fftshift coordinates: y' = (r + WS/2) % WS, x' = (x + WS/2) % WS
-        float* my_map = tile + w * (WS * G::MAP_PITCH);
-        static_assert(G::WPW * WS * G::MAP_PITCH <= G::LDS_FLOATS, "map must fit the tile LDS");
-        const int ys = (r + WS / 2) % WS;
-        float cmin = 3.4e38f;
-        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-            constexpr int k = decltype(kc)::value;
-            cmin = fminf(cmin, t[FFT_POS<k, WS>].x);
-        });
-        cmin = grp_min<WS>(cmin);
-        ArgMaxT best{-1.f, 0};
-        float c[WS];                                      // shifted row: c[x'] = corr - min + eps
-        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-            constexpr int xsft = decltype(kc)::value;     // ascending shifted column
-            constexpr int xo = (xsft + WS / 2) % WS;
-            // B:518 corr - min; B:381 corr += eps (float32 arithmetic in passes >= 2)
-            const float v = __fadd_rn(__fsub_rn(t[FFT_POS<xo, WS>].x, cmin), 1e-7f);
-            c[xsft] = v;
-            my_map[ys * G::MAP_PITCH + xsft] = v;
-            if (v > best.v) {
-                best.v = v;
-                best.idx = ys * WS + xsft;
-            }
-        });
-        best = grp_argmax<WS>(best);
-        wave_sync();                                  // map complete
-
-        if (p.dbg_corr != nullptr && active) {
-            float* d = p.dbg_corr + fidx * WS * WS;
-#pragma unroll
-            for (int k = 0; k < WS; ++k) d[ys * WS + k] = c[k];
-        }
-
-        TPIV_STAMP(11);     // min, map, first peak
-        // ---- second peak: arg-max outside the (2*wv+1)^2 FLAT-index neighbourhood (B:346-358):
-        //      excluded q = clamp(m + i + WS*j), |i|,|j| <= wv, i.e. in row y' the columns
-        //      mx+i (j = y'-my), mx+i+WS (j = y'-my+1) and mx+i-WS (j = y'-my-1), plus the clamps.
-        const int m = best.idx;
-        const int KD = WS * WS;
-        const int wv = p.val_win;
-        const int my_ = m / WS, mx_ = m % WS;
-        ArgMaxT second{-1.f, KD};
-        {
-            const int dj = ys - my_;
-            unsigned long long ex = 0ull;                 // bit x' set = excluded in this lane's row
-            auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {     // bits lo_..hi_ clipped to the row
-                lo_ = lo_ < 0 ? 0 : lo_;
-                hi_ = hi_ > WS - 1 ? WS - 1 : hi_;
-                if (lo_ > hi_) return 0ull;
-                const unsigned long long ones = (hi_ - lo_ + 1) >= 64 ? ~0ull : ((1ull << (hi_ - lo_ + 1)) - 1ull);
-                return ones << lo_;
-            };
-            if (dj >= -wv && dj <= wv) ex |= span(mx_ - wv, mx_ + wv);
-            if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(mx_ - wv + WS, mx_ + wv + WS);
-            if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx_ - wv - WS, mx_ + wv - WS);
-            if (ys == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;                       // clamp to 0
-            if (ys == WS - 1 && (m + wv + wv * WS) >= KD - 1) ex |= 1ull << (WS - 1);  // clamp to KD-1
-            const unsigned exl = (unsigned)ex, exh = (unsigned)(ex >> 32);
-            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-                constexpr int xsft = decltype(kc)::value;
-                const bool excl = ((xsft < 32 ? exl : exh) >> (xsft & 31)) & 1u;
-                const float v = c[xsft];
-                if (!excl && v > second.v) {
-                    second.v = v;
-                    second.idx = ys * WS + xsft;
-                }
-            });
-        }
-        second = grp_argmax<WS>(second);
-
-        TPIV_STAMP(12);     // second peak
-        // ---- hand-off to finalize_kernel (piv_launch.hip): the float64 logarithms, divisions and the
-        //      multipass combine of B:385-422 / B:728-738 need ONE lane per window, so they run in a
-        //      separate thread-per-window kernel; lanes 0..7 of the window store the raw peak data.
-        {
-            int left = m + 1, right = m - 1, top = m + WS, bot = m - WS;     // B:385-392 (flat index)
-            if (left >= KD - 1) left = m;
-            if (right <= 0) right = m;
-            if (top >= KD - 1) top = m;
-            if (bot <= 0) bot = m;
-            int q = m;
-            q = (r == 1) ? left : q;
-            q = (r == 2) ? right : q;
-            q = (r == 3) ? top : q;
-            q = (r == 4) ? bot : q;
-            q = (r == 5) ? (second.idx < KD ? second.idx : m) : q;
-            float outv = my_map[(q / WS) * G::MAP_PITCH + (q % WS)];
-            outv = (r == 6) ? __int_as_float(m) : outv;
-            outv = (r == 7) ? __int_as_float(dead ? 1 : 0) : outv;
-            if (r < 8 && active) p.peak_raw[fidx * 8 + r] = outv;
-        }
+        peak_analysis<WS, PLANAR>(p, t, tile, w, r, active, dead, fidx);
         wave_sync();
         TPIV_STAMP(13);     // sub-pixel fit, combine, stores
     }
     TPIV_STAMP_FLUSH(p);
+}
+
+// ---- test hook: feed hand-made correlation maps straight into peak_analysis ------------------------
+// maps: [n_windows, WS, WS] float32 in fftshift layout (what correlation_to_displacement receives,
+// before its `+= eps`); one wavefront handles 64/WS maps.  Output: peak_raw records.
+template <int WS>
+__global__ __launch_bounds__(64, 2) void peak_debug_kernel(PassParams p, const float* maps, int n_maps) {
+    using G = TileGeo<WS, false>;
+    __shared__ float tile[G::LDS_FLOATS];
+    const int lane = threadIdx.x;
+    const int w = lane / WS, r = lane % WS;
+    const int win_raw = blockIdx.x * G::WPW + w;
+    const bool active = win_raw < n_maps;
+    const int win = active ? win_raw : n_maps - 1;
+    cf t[WS];
+    const int ys = (r + WS / 2) % WS;
+    static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+        constexpr int xo = decltype(kc)::value;
+        constexpr int xs = (xo + WS / 2) % WS;
+        t[FFT_POS<xo, WS>].x = maps[((size_t)win * WS + ys) * WS + xs];
+        t[FFT_POS<xo, WS>].y = 0.f;
+    });
+    peak_analysis<WS, false>(p, t, tile, w, r, active, false, (size_t)win);
+}
+
+template <int WS>
+hipError_t launch_peak_debug(const PassParams& p, const float* maps, int n_maps, hipStream_t stream) {
+    using G = TileGeo<WS, false>;
+    const int blocks = (n_maps + G::WPW - 1) / G::WPW;
+    hipLaunchKernelGGL((peak_debug_kernel<WS>), dim3(blocks), dim3(64), 0, stream, p, maps, n_maps);
+    return hipGetLastError();
 }
 
 template <int WS, int MODE>

@@ -144,6 +144,20 @@ def debug_pass(mode, a, b, ws, ov, u2=None, v2=None):
     return u, v, inv, win, corr
 
 
+def debug_peaks(maps: torch.Tensor, val_ratio=1.2, val_win=3):
+    """Test hook: the kernels' peak analysis on hand-made correlation maps [n, ws, ws] (ws 8 or 16)."""
+    _need_cuda(maps)
+    maps = maps.contiguous().float()
+    n, ws = maps.shape[0], maps.shape[-1]
+    u = torch.empty(n, dtype=torch.float64, device=maps.device)
+    v = torch.empty_like(u)
+    inv = torch.empty(n, dtype=torch.uint8, device=maps.device)
+    with torch.cuda.device(maps.device):
+        check(lib.tpiv_debug_peaks(maps.data_ptr(), n, ws, float(val_ratio), int(val_win), u.data_ptr(),
+                                   v.data_ptr(), inv.data_ptr(), _stream()))
+    return u, v, inv
+
+
 class Plan:
     """The multipass pipeline of OfflinePIV.__call__ (PIVbackend.py:873-882) for batches of
     pairs resident on one GPU.  Owns the device workspace; `run` only enqueues kernels."""
