@@ -14,7 +14,8 @@
  *     once.  tpiv_plan_run allocates nothing; the function-level entry points (tpiv_pass1 /
  *     tpiv_iter) keep one grow-only scratch buffer per device inside the library (32 bytes per
  *     window; re-allocated, with a device synchronise, only when a call needs more than any
- *     earlier one);
+ *     earlier one).  That buffer is shared by all function-level calls on a device: do not
+ *     overlap them on different streams (plans own their workspace and may run concurrently);
  *   - fields are row-major [batch, n_rows, n_cols]; frames are uint8 [batch, H, W];
  *   - return value: TPIV_OK or an error code; tpiv_last_error() gives the message
  *     of the calling thread's last failure.  Nothing is thrown across the ABI.
