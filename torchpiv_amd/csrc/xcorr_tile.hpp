@@ -921,12 +921,14 @@ static hipError_t launch_tile(const PassParams& p, int n_cu, hipStream_t stream)
     const long long cap = (long long)n_cu * (wg_per_cu > 0 ? wg_per_cu : 64);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;                  // the XCD remap needs a multiple of 8
-    // experiment switch: TPIV_OCC selects the register budget (wavefronts per SIMD) of the
-    // WS <= 32 kernels: 2 (256 VGPRs), 3 (168) or 4 (128)
-    static const int occ = [] {
+    // Register budget (wavefronts per SIMD).  32x32 pass-1 / DWS kernels are spill-free at 168 VGPRs:
+    // with planar LDS tiles (8.4 KB per wavefront) three wavefronts fit per SIMD (+4.5 % measured).
+    // The CWS variant needs 215 VGPRs and stays at two.  TPIV_OCC=2|3|4 overrides for experiments.
+    static const int occ_env = [] {
         const char* e = getenv("TPIV_OCC");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 0;
     }();
+    const int occ = occ_env ? occ_env : ((WS == 32 && MODE != MODE_CWS) ? 3 : 2);
     if (WS <= 32 && occ == 3)
         hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, (WS <= 32 ? 3 : 2)>), dim3((unsigned)blocks), dim3(64), 0,
                            stream, p);
