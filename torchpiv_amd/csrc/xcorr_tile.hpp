@@ -534,6 +534,8 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
             }
             static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int k = decltype(kc)::value;
+                // keep the scheduler from hoisting all WS weight reads (4 VGPRs each) to the top
+                if constexpr (k % 8 == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
                 const float4 wx = wbuf[k];
                 x[k].x = bilerp_ref(byte_f<k, NB>(raw.a0), byte_f<k + 1, NB>(raw.a0), byte_f<k, NB>(raw.a1),
                                     byte_f<k + 1, NB>(raw.a1), wx.x, wx.y, c.wya_up, c.wya_dn, c.ydeg_a != 0);
@@ -921,14 +923,16 @@ static hipError_t launch_tile(const PassParams& p, int n_cu, hipStream_t stream)
     const long long cap = (long long)n_cu * (wg_per_cu > 0 ? wg_per_cu : 64);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;                  // the XCD remap needs a multiple of 8
-    // Register budget (wavefronts per SIMD).  32x32 pass-1 / DWS kernels are spill-free at 168 VGPRs:
-    // with planar LDS tiles (8.4 KB per wavefront) three wavefronts fit per SIMD (+4.5 % measured).
-    // The CWS variant needs 215 VGPRs and stays at two.  TPIV_OCC=2|3|4 overrides for experiments.
+    // Register budget (wavefronts per SIMD).  The 32x32 and 16x16 kernels run three wavefronts per
+    // SIMD: 168 VGPRs (pass 1 / DWS spill-free, 32x32 CWS with ~20 cold spills of loop-carried
+    // scalars) and planar LDS tiles (8.4 KB per wavefront at 32x32).  Measured vs two wavefronts:
+    // 32x32 DWS pass 33.6 -> 27.4 us/pair, 32x32 CWS pass 48.0 -> 43.9, 16x16 CWS pass (4096^2)
+    // 213.9 -> 189.6; 8x8 is unchanged and stays at two.  TPIV_OCC=2|3|4 overrides for experiments.
     static const int occ_env = [] {
         const char* e = getenv("TPIV_OCC");
         return e ? atoi(e) : 0;
     }();
-    const int occ = occ_env ? occ_env : ((WS == 32 && MODE != MODE_CWS) ? 3 : 2);
+    const int occ = occ_env ? occ_env : ((WS == 32 || WS == 16) ? 3 : 2);
     if (WS <= 32 && occ == 3)
         hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, (WS <= 32 ? 3 : 2)>), dim3((unsigned)blocks), dim3(64), 0,
                            stream, p);
