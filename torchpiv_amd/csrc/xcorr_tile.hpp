@@ -619,9 +619,11 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
     wave_sync();                                  // map complete
 
     if (p.dbg_corr != nullptr && active) {
-        float* d = p.dbg_corr + fidx * WS * WS;
+        int yy = ys;                 // opaque: keeps the WS store addresses out of the item loop's registers
+        asm volatile("" : "+v"(yy));
+        float* d = p.dbg_corr + fidx * WS * WS + yy * WS;
 #pragma unroll
-        for (int k = 0; k < WS; ++k) d[ys * WS + k] = c[k];
+        for (int k = 0; k < WS; ++k) d[k] = c[k];
     }
 
     // ---- second peak: arg-max outside the (2*wv+1)^2 FLAT-index neighbourhood (B:346-358):
@@ -735,15 +737,13 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
     long long item = lo + slot;
     if (item >= hi) return;
     auto next_of = [&](long long it) TPIV_LAMBDA_INLINE { return it + per_xcd < hi ? it + per_xcd : it; };
-    // software pipeline: rows of item i+1 in flight during item i, shifts fetched two items ahead
+    // software pipeline: rows of item i+1 in flight during item i (its shifts are fetched at the loop
+    // head and have the conversion of item i to land)
     ItemGeom gcur = geom_of(item);
     float vx, vy;
     shift_of(gcur, vx, vy);
     RawRows<WS, MODE> raw;
     issue_rows<WS, MODE>(p, gcur, r, vx, vy, raw);
-    ItemGeom gnext = geom_of(next_of(item));
-    float nvx, nvy;
-    shift_of(gnext, nvx, nvy);
 
     TPIV_STAMP_DECL
     TPIV_STAMP_START;
@@ -754,10 +754,10 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         const ItemGeom g = gcur;
         const bool active = g.active != 0;
         const size_t fidx = g.fidx;
-        // (the last iterations simply re-load their own item: no branch around the prefetch)
-        const ItemGeom gnn = geom_of(next_of(next_of(item)));
-        float nnvx, nnvy;
-        shift_of(gnn, nnvx, nnvy);
+        // (the last iteration simply re-loads its own item: no branch around the prefetch)
+        const ItemGeom gnext = geom_of(next_of(item));
+        float nvx, nvy;
+        shift_of(gnext, nvx, nvy);
 
         cf x[WS];
         float sa, sb;                      // window sums (for the mean)
@@ -769,11 +769,15 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         if constexpr (WS <= 32) issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
 
         if (p.dbg_win != nullptr && active) {     // test hook: the staged (shifted) windows
-            float* d = p.dbg_win + fidx * 2 * WS * WS;
+            // (the row index is made opaque here: otherwise the WS loop-invariant store addresses get
+            //  hoisted out of the item loop and occupy WS VGPRs for the whole kernel)
+            int rr = r;
+            asm volatile("" : "+v"(rr));
+            float* d = p.dbg_win + fidx * 2 * WS * WS + rr * WS;
 #pragma unroll
             for (int k = 0; k < WS; ++k) {
-                d[r * WS + k] = x[k].x;
-                d[WS * WS + r * WS + k] = x[k].y;
+                d[k] = x[k].x;
+                d[WS * WS + k] = x[k].y;
             }
         }
 
@@ -862,12 +866,22 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         gcur = gnext;
         vx = nvx;
         vy = nvy;
-        gnext = gnn;
-        nvx = nnvx;
-        nvy = nnvy;
 
         TPIV_STAMP(10);     // issue of the next item's row loads
-        peak_analysis<WS, PLANAR>(p, t, tile, w, r, active, dead, fidx);
+        {
+            // Re-derive the window index from the (wave-uniform) item position instead of keeping
+            // the per-lane geometry alive through the transforms: those cold values were what the
+            // register allocator spilled (13 dwords per lane per iteration = 3x the algorithmic bytes
+            // of scratch traffic).  The asm makes the value opaque so that it is really recomputed.
+            int pair_e = __builtin_amdgcn_readfirstlane(g.pair);
+            int gi_e = __builtin_amdgcn_readfirstlane((int)(item % groups));
+            asm volatile("" : "+s"(pair_e), "+s"(gi_e));
+            const int win_raw_e = gi_e * G::WPW + w;
+            const bool active_e = win_raw_e < N;
+            const int win_e = active_e ? win_raw_e : N - 1;
+            const size_t fidx_e = (size_t)pair_e * N + win_e;
+            peak_analysis<WS, PLANAR>(p, t, tile, w, r, active_e, dead, fidx_e);
+        }
         wave_sync();
         TPIV_STAMP(13);     // sub-pixel fit, combine, stores
     }
