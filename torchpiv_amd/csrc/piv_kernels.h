@@ -33,6 +33,7 @@ struct PassParams {
     // workspace [batch, N, 8] float32 between the tile kernel and finalize_kernel (WS <= 64):
     // {c[m], c[left], c[right], c[top], c[bot], c[m2], bits(m), bits(dead)} per window
     float* peak_raw;
+    unsigned* work_ctr;      // 8 x 16 dwords: per-XCD item counters of the tile kernel (set by launch_xcorr)
 };
 
 struct PredictParams {

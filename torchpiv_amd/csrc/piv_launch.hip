@@ -92,16 +92,27 @@ hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_
     return hipGetLastError();
 }
 
+static constexpr size_t WORK_CTR_BYTES = 8 * 16 * sizeof(unsigned);
+static size_t work_ctr_offset(int batch, int n_windows) { return (peak_bytes(batch, n_windows) + 127) / 128 * 128; }
+
 size_t peak_raw_bytes(int ws, int batch, int n_windows) {
     if (ws == 128) return 0;                          // first-generation kernel: fused epilogue
+    if (tile_size(ws)) return work_ctr_offset(batch, n_windows) + WORK_CTR_BYTES;   // records + item counters
     size_t b = peak_bytes(batch, n_windows);
     if (!tile_size(ws))
         b += (size_t)generic_blocks(ws, (long long)batch * n_windows, 256) * 2 * ws * ws * 8;
     return b;
 }
 
-hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream) {
+hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t stream) {
     hipError_t e;
+    PassParams p = p_in;
+    if (tile_size(p.ws)) {       // per-XCD work queue of the tile kernel: counters behind the peak records
+        p.work_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.peak_raw) +
+                                                 work_ctr_offset(p.batch, p.n_rows * p.n_cols));
+        e = hipMemsetAsync(p.work_ctr, 0, WORK_CTR_BYTES, stream);
+        if (e != hipSuccess) return e;
+    }
     switch (p.ws) {
         case 8: e = launch_xcorr_ws8(p, mode, n_cu, stream); break;
         case 16: e = launch_xcorr_ws16(p, mode, n_cu, stream); break;

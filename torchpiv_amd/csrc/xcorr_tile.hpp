@@ -703,14 +703,37 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
     const long long items = (long long)p.batch * groups;
     const int st = p.ws - p.ov;
 
-    // XCD-aware item order: workgroups b, b+8, ... share an XCD (and its L2); give every XCD one
-    // contiguous run of windows so that overlapping windows re-read the frame from the same L2.
+    // XCD-aware item order: workgroups b, b+8, ... share an XCD (and its L2); every XCD owns one
+    // contiguous run of windows and its wavefronts pull the next item(s) from a per-XCD counter
+    // (PassParams::work_ctr, zeroed by the host before the launch).  The wavefronts resident on an XCD
+    // therefore always work on ADJACENT windows -- the overlapping halves and the rows shared with
+    // the window row below come out of that XCD's L2 instead of HBM -- and the tail balances itself.
+    // Small tiles take QCH items per atomic to keep the counter below its ~88 dequeues/us limit.
+    constexpr int QCH = WS <= 16 ? 4 : 1;
     const int xcd = blockIdx.x & 7;
-    const int slot = blockIdx.x >> 3;
-    const int per_xcd = gridDim.x >> 3;                   // the host launches a multiple of 8
     const long long chunk = (items + 7) / 8;
     const long long lo = (long long)xcd * chunk;
     const long long hi = (lo + chunk < items) ? lo + chunk : items;
+    unsigned* const ctr = p.work_ctr + xcd * 16;          // one 64-byte line per counter
+    // The dequeue is split into issue (atomic goes out at the loop head) and take (its result is read
+    // at the loop end), so that its ~2 us round trip hides behind a whole item.
+    long long q_base = 0;
+    int q_left = 0;
+    unsigned q_raw = 0;
+    auto q_issue = [&]() TPIV_LAMBDA_INLINE {
+        if (QCH == 1 || q_left == 0) {
+            if (lane == 0) q_raw = atomicAdd(ctr, (unsigned)QCH);
+        }
+    };
+    auto q_take = [&]() TPIV_LAMBDA_INLINE -> long long {
+        if (QCH == 1 || q_left == 0) {
+            q_base = lo + (long long)__builtin_amdgcn_readfirstlane((int)q_raw);
+            q_left = QCH;
+        }
+        const long long it = q_base + (QCH - q_left);
+        --q_left;
+        return it;
+    };
 
     auto geom_of = [&](long long item) TPIV_LAMBDA_INLINE {
         ItemGeom g;
@@ -734,9 +757,11 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         }
     };
 
-    long long item = lo + slot;
+    q_issue();
+    long long item = q_take();
     if (item >= hi) return;
-    auto next_of = [&](long long it) TPIV_LAMBDA_INLINE { return it + per_xcd < hi ? it + per_xcd : it; };
+    q_issue();
+    long long nitem = q_take();                          // the queue runs two items ahead of the FFTs
     // software pipeline: rows of item i+1 in flight during item i (its shifts are fetched at the loop
     // head and have the conversion of item i to land)
     ItemGeom gcur = geom_of(item);
@@ -747,7 +772,8 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
 
     TPIV_STAMP_DECL
     TPIV_STAMP_START;
-    for (; item < hi; item += per_xcd) {
+    for (; item < hi; item = nitem, nitem = q_take()) {
+        q_issue();
 #ifdef TPIV_STAMPS
         ++st_iter;
 #endif
@@ -755,7 +781,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         const bool active = g.active != 0;
         const size_t fidx = g.fidx;
         // (the last iteration simply re-loads its own item: no branch around the prefetch)
-        const ItemGeom gnext = geom_of(next_of(item));
+        const ItemGeom gnext = geom_of(nitem < hi ? nitem : item);
         float nvx, nvy;
         shift_of(gnext, nvx, nvy);
 
@@ -926,10 +952,12 @@ static hipError_t launch_tile(const PassParams& p, int n_cu, hipStream_t stream)
     const long long groups = (N + G::WPW - 1) / G::WPW;
     const long long items = (long long)p.batch * groups;
     long long blocks = items;
-    // 64 single-wavefront workgroups per CU, grid-stride above that.  Measured (2048^2, 2-pass CWS):
-    // 8/CU (exactly the resident set, best L2 locality) 104.5 us/pair, 16/CU 102.6, 64/CU 98.2 --
-    // the dispatcher's dynamic balancing is worth more than keeping an XCD on adjacent windows
-    // (HBM traffic is ~6 % of peak either way).  TPIV_WG_PER_CU overrides for experiments.
+    // Up to 64 single-wavefront workgroups per CU; each pulls items from its XCD's counter until the
+    // run is empty, so surplus workgroups exit at once and the grid size only has to cover the
+    // resident set.  (History: with a static grid-stride order 64/CU beat the exact resident set,
+    // 98.2 vs 104.5 us/pair, because of dynamic balancing, but spread every XCD over its whole run:
+    // FETCH_SIZE was 1.5x (pass 1) to 3x (pass 2) the algorithmic bytes.  The queue keeps both.)
+    // TPIV_WG_PER_CU overrides for experiments.
     static const int wg_per_cu = [] {
         const char* e = getenv("TPIV_WG_PER_CU");
         return e ? atoi(e) : 0;
