@@ -601,8 +601,12 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
         cmin = fminf(cmin, t[FFT_POS<k, WS>].x);
     });
     cmin = grp_min<WS>(cmin);
-    ArgMaxT best{-1.f, 0};
+    // Instruction-cost note (tools/micro/gen_issue_rate.py, MI355X): fp32 add/mul/max issue in ~2.1
+    // cycles per wavefront, but every compare (SGPR result) and every select (SGPR mask) costs ~4.3.
+    // The scans below therefore avoid per-element compare/select: the arg-max is a plain max per
+    // row, and its position is found afterwards with one row of the LDS map spread over the lanes.
     float c[WS];                                      // shifted row: c[x'] = corr - min + eps
+    float rmax = 0.f;                                 // every c is >= 1e-7 > 0
     static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
         constexpr int xsft = decltype(kc)::value;     // ascending shifted column
         constexpr int xo = (xsft + WS / 2) % WS;
@@ -610,12 +614,13 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
         const float v = __fadd_rn(__fsub_rn(t[FFT_POS<xo, WS>].x, cmin), 1e-7f);
         c[xsft] = v;
         my_map[ys * G::MAP_PITCH + xsft] = v;
-        if (v > best.v) {
-            best.v = v;
-            best.idx = ys * WS + xsft;
-        }
+        rmax = fmaxf(rmax, v);
     });
-    best = grp_argmax<WS>(best);
+    const float gmax = grp_reduce<WS>(rmax, [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); });
+    auto imin = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
+    // arg-max = FIRST flat index holding the maximum (torch.argmax, B:383): the smallest row y' whose
+    // maximum equals it, then the smallest column of that row
+    const int ywin = grp_reduce<WS>(rmax == gmax ? ys : WS - 1, imin);      // (WS - 1: NaN maps stay in range)
     wave_sync();                                  // map complete
 
     if (p.dbg_corr != nullptr && active) {
@@ -625,15 +630,17 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
 #pragma unroll
         for (int k = 0; k < WS; ++k) d[k] = c[k];
     }
+    const int xwin = grp_reduce<WS>(my_map[ywin * G::MAP_PITCH + r] == gmax ? r : WS - 1, imin);   // lane r = column r
 
-    // ---- second peak: arg-max outside the (2*wv+1)^2 FLAT-index neighbourhood (B:346-358):
+    // ---- second peak: maximum outside the (2*wv+1)^2 FLAT-index neighbourhood (B:346-358):
     //      excluded q = clamp(m + i + WS*j), |i|,|j| <= wv, i.e. in row y' the columns
     //      mx+i (j = y'-my), mx+i+WS (j = y'-my+1) and mx+i-WS (j = y'-my-1), plus the clamps.
-    const int m = best.idx;
+    //      Only its VALUE is needed (the validity ratio); "none left" falls back to the first peak.
+    const int m = ywin * WS + xwin;
     const int KD = WS * WS;
     const int wv = p.val_win;
-    const int my_ = m / WS, mx_ = m % WS;
-    ArgMaxT second{-1.f, KD};
+    const int my_ = ywin, mx_ = xwin;
+    int smax = 0;                                     // float bits; positive floats order like ints
     {
         const int dj = ys - my_;
         unsigned long long ex = 0ull;                 // bit x' set = excluded in this lane's row
@@ -649,18 +656,17 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
         if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx_ - wv - WS, mx_ + wv - WS);
         if (ys == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;                       // clamp to 0
         if (ys == WS - 1 && (m + wv + wv * WS) >= KD - 1) ex |= 1ull << (WS - 1);  // clamp to KD-1
-        const unsigned exl = (unsigned)ex, exh = (unsigned)(ex >> 32);
+        const int exl = (int)(unsigned)ex, exh = (int)(unsigned)(ex >> 32);
         static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
             constexpr int xsft = decltype(kc)::value;
-            const bool excl = ((xsft < 32 ? exl : exh) >> (xsft & 31)) & 1u;
-            const float v = c[xsft];
-            if (!excl && v > second.v) {
-                second.v = v;
-                second.idx = ys * WS + xsft;
-            }
+            // sign-extended exclusion bit: 0 keeps the value, -1 turns it into a negative integer
+            const int kill = __builtin_amdgcn_sbfe(xsft < 32 ? exl : exh, xsft & 31, 1);
+            const int cand = __float_as_int(c[xsft]) | kill;
+            smax = cand > smax ? cand : smax;
         });
     }
-    second = grp_argmax<WS>(second);
+    smax = grp_reduce<WS>(smax, [](int a, int b) TPIV_LAMBDA_INLINE { return a > b ? a : b; });
+    const float second_v = smax > 0 ? __int_as_float(smax) : gmax;
 
     // ---- hand-off to finalize_kernel (piv_launch.hip): the float64 logarithms, divisions and the
     //      multipass combine of B:385-422 / B:728-738 need ONE lane per window, so they run in a
@@ -676,8 +682,8 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
         q = (r == 2) ? right : q;
         q = (r == 3) ? top : q;
         q = (r == 4) ? bot : q;
-        q = (r == 5) ? (second.idx < KD ? second.idx : m) : q;
         float outv = my_map[(q / WS) * G::MAP_PITCH + (q % WS)];
+        outv = (r == 5) ? second_v : outv;
         outv = (r == 6) ? __int_as_float(m) : outv;
         outv = (r == 7) ? __int_as_float(dead ? 1 : 0) : outv;
         if (r < 8 && active) p.peak_raw[fidx * 8 + r] = outv;
