@@ -146,6 +146,9 @@ def test_border_rows_bit_exact(eng, ws):
         amp = (0.6 * ws, 2.5 * ws, 4.0)[trial]
         vx = rng.uniform(-amp, amp, n).astype(np.float32)
         vy = rng.uniform(-amp, amp, n).astype(np.float32)
+        vy[::5] = np.rint(vy[::5])          # integral row shift: the "nearest sample" quirk (B:170, B:193)
+        vx[::7] = np.rint(vx[::7])          # integral column shift (per-pixel path)
+        vy[3] = vx[3] = 0.0
         vxd = torch.from_numpy(vx.astype(np.float64)).cuda().view(1, nr, nc)
         vyd = torch.from_numpy(vy.astype(np.float64)).cuda().view(1, nr, nc)
         _, _, _, win, _ = eng.debug_pass("CWS", dev(frame_a), dev(frame_b), ws, ov, vxd, vyd)

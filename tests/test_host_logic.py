@@ -170,3 +170,34 @@ int main(){ run<8,1>(); run<16,1>(); run<32,1>(); run<64,1>(); run<128,1>();
         x = ((i * 37 + 11) % 101 - 50.0) + 1j * ((i * 53 + 7) % 89 - 44.0)
         ref = np.fft.fft(x) if D > 0 else np.fft.ifft(x) * N
         assert np.abs(z - ref).max() / np.abs(ref).max() < 3e-7, (N, D)
+
+
+def test_c2r_codelet_on_host(tmp_path):
+    """c2r_inreg (real inverse through a half-size complex transform) against numpy.fft.irfft."""
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include "fft_inreg.hpp"
+#include <cstdio>
+using namespace tpiv;
+template<int N> void run() {
+  cf Y[N / 2 + 1], h[N / 2];
+  for (int i = 0; i <= N / 2; ++i) { Y[i].x = (float)((i*37+11)%101) - 50.f; Y[i].y = (float)((i*53+7)%89) - 44.f; }
+  c2r_inreg<N>(Y, h);
+  printf("%d", N);
+  for (int n = 0; n < N; ++n) printf(" %.9g", (n & 1) ? h[fft_pos(n / 2, N / 2)].y : h[fft_pos(n / 2, N / 2)].x);
+  printf("\n");
+}
+int main(){ run<8>(); run<16>(); run<32>(); run<64>(); }
+''')
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "torchpiv_amd", "csrc"), str(src),
+                    "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    for line in out.strip().splitlines():
+        t = line.split()
+        N = int(t[0])
+        got = np.array(t[1:], dtype=float)
+        i = np.arange(N // 2 + 1)
+        Y = ((i * 37 + 11) % 101 - 50.0) + 1j * ((i * 53 + 7) % 89 - 44.0)
+        ref = np.fft.irfft(Y, n=N) * N
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 3e-7, N
