@@ -233,8 +233,58 @@ __device__ __forceinline__ void transpose_tile(cf (&a)[WS], float* lds, int lane
     using G = TileGeo<WS, PLANAR>;
     constexpr int P = G::PITCH;
     cf* tile = reinterpret_cast<cf*>(lds);
-    if constexpr (PLANAR) {
-        static_assert(WS <= 32, "planar tiles are for WS <= 32");
+    if constexpr (PLANAR && WS > 32) {
+        // 64x64, one float plane at a time through two 32x33 float tiles (8.4 KB per wavefront, which
+        // is what lets three wavefronts per SIMD fit in the LDS): swap the off-diagonal blocks
+        // between the lane halves, then transpose the four blocks of each plane, two at a time.
+        static_for<0, 32>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            constexpr int lo = DIGITREV ? FFT_POS<k, WS> : k;
+            constexpr int hi = DIGITREV ? FFT_POS<k + 32, WS> : k + 32;
+            auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[lo].x), __float_as_uint(a[hi].x),
+                                                       false, false);
+            auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[lo].y), __float_as_uint(a[hi].y),
+                                                       false, false);
+            a[lo].x = __uint_as_float(rx[0]);
+            a[hi].x = __uint_as_float(rx[1]);
+            a[lo].y = __uint_as_float(ry[0]);
+            a[hi].y = __uint_as_float(ry[1]);
+        });
+        float* t = lds + (lane >> 5) * G::TILE;
+        const int i = lane & 31;
+        auto plane = [&](auto comp) TPIV_LAMBDA_INLINE {
+            constexpr bool Y = decltype(comp)::value;
+            float lowhalf[32];
+            wave_sync();
+            static_for<0, 32>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                constexpr int src = DIGITREV ? FFT_POS<k, WS> : k;
+                t[i * P + k] = Y ? a[src].y : a[src].x;
+            });
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 32; ++r) lowhalf[r] = t[r * P + i];
+            wave_sync();
+            static_for<0, 32>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                constexpr int src = DIGITREV ? FFT_POS<k + 32, WS> : k + 32;
+                t[i * P + k] = Y ? a[src].y : a[src].x;
+            });
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                if constexpr (Y) {
+                    a[32 + r].y = t[r * P + i];
+                    a[r].y = lowhalf[r];
+                } else {
+                    a[32 + r].x = t[r * P + i];
+                    a[r].x = lowhalf[r];
+                }
+            }
+        };
+        plane(std::false_type{});
+        plane(std::true_type{});
+    } else if constexpr (PLANAR) {
         float* t = lds + (lane / WS) * G::TILE;
         const int i = lane % WS;
         wave_sync();
@@ -592,8 +642,11 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
                                               bool active, bool dead, size_t fidx) {
     using G = TileGeo<WS, PLANAR>;
     // ---- correlation map in fftshift coordinates: y' = (r + WS/2) % WS, x' = (x + WS/2) % WS
-    float* my_map = tile + w * (WS * G::MAP_PITCH);
-    static_assert(G::WPW * WS * G::MAP_PITCH <= G::LDS_FLOATS, "map must fit the tile LDS");
+    // SMALLMAP (planar 64x64, 8.4 KB of LDS): only the rows ywin-1..ywin+1 around the peak are parked in
+    // LDS (everything the lookups below touch); otherwise the whole map is, written during the scan.
+    constexpr bool SMALLMAP = G::WPW * WS * G::MAP_PITCH > G::LDS_FLOATS;
+    static_assert(G::WPW * 3 * G::MAP_PITCH <= G::LDS_FLOATS, "map rows must fit the tile LDS");
+    float* my_map = tile + w * ((SMALLMAP ? 3 : WS) * G::MAP_PITCH);
     const int ys = (r + WS / 2) % WS;
     float cmin = 3.4e38f;
     static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
@@ -613,7 +666,7 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
         // B:518 corr - min; B:381 corr += eps (float32 arithmetic in passes >= 2)
         const float v = __fadd_rn(__fsub_rn(t[FFT_POS<xo, WS>].x, cmin), 1e-7f);
         c[xsft] = v;
-        my_map[ys * G::MAP_PITCH + xsft] = v;
+        if constexpr (!SMALLMAP) my_map[ys * G::MAP_PITCH + xsft] = v;
         rmax = fmaxf(rmax, v);
     });
     const float gmax = grp_reduce<WS>(rmax, [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); });
@@ -621,6 +674,15 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
     // arg-max = FIRST flat index holding the maximum (torch.argmax, B:383): the smallest row y' whose
     // maximum equals it, then the smallest column of that row
     const int ywin = grp_reduce<WS>(rmax == gmax ? ys : WS - 1, imin);      // (WS - 1: NaN maps stay in range)
+    const int row0 = SMALLMAP ? ywin - 1 : 0;     // map row held in LDS row 0
+    if constexpr (SMALLMAP) {
+        wave_sync();
+        const int slot = ys - row0;
+        if (slot >= 0 && slot <= 2) {
+#pragma unroll
+            for (int k = 0; k < WS; ++k) my_map[slot * G::MAP_PITCH + k] = c[k];
+        }
+    }
     wave_sync();                                  // map complete
 
     if (p.dbg_corr != nullptr && active) {
@@ -630,7 +692,7 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
 #pragma unroll
         for (int k = 0; k < WS; ++k) d[k] = c[k];
     }
-    const int xwin = grp_reduce<WS>(my_map[ywin * G::MAP_PITCH + r] == gmax ? r : WS - 1, imin);   // lane r = column r
+    const int xwin = grp_reduce<WS>(my_map[(ywin - row0) * G::MAP_PITCH + r] == gmax ? r : WS - 1, imin);   // lane r = column r
 
     // ---- second peak: maximum outside the (2*wv+1)^2 FLAT-index neighbourhood (B:346-358):
     //      excluded q = clamp(m + i + WS*j), |i|,|j| <= wv, i.e. in row y' the columns
@@ -682,7 +744,7 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
         q = (r == 2) ? right : q;
         q = (r == 3) ? top : q;
         q = (r == 4) ? bot : q;
-        float outv = my_map[(q / WS) * G::MAP_PITCH + (q % WS)];
+        float outv = my_map[(q / WS - row0) * G::MAP_PITCH + (q % WS)];     // rows ywin-1..ywin+1 only
         outv = (r == 5) ? second_v : outv;
         outv = (r == 6) ? __int_as_float(m) : outv;
         outv = (r == 7) ? __int_as_float(dead ? 1 : 0) : outv;
@@ -693,10 +755,11 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
 // ---------------------------------------------------------------------------------------------
 template <int WS, int MODE, int OCC>
 __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
-    constexpr bool PLANAR = OCC > 2 && WS <= 32;
+    constexpr bool PLANAR = OCC > 2;
     using G = TileGeo<WS, PLANAR>;
     static_assert(WS == 8 || WS == 16 || WS == 32 || WS == 64, "tile sizes of this kernel");
-    static_assert(64 * (WS + 1) <= G::LDS_FLOATS, "slow-path row buffer must fit the tile LDS");
+    static_assert(MODE == MODE_PASS1 || 64 * (WS + 1) <= G::LDS_FLOATS,
+                  "slow-path row buffer (shifted passes) must fit the tile LDS");
     __shared__ float tile[G::LDS_FLOATS];
 
     const int lane = threadIdx.x;
@@ -980,7 +1043,14 @@ static hipError_t launch_tile(const PassParams& p, int n_cu, hipStream_t stream)
         const char* e = getenv("TPIV_OCC");
         return e ? atoi(e) : 0;
     }();
-    const int occ = occ_env ? occ_env : ((WS == 32 || WS == 16) ? 3 : 2);
+    const int occ = occ_env ? occ_env : ((WS == 32 || WS == 16 || (WS == 64 && MODE == MODE_PASS1)) ? 3 : 2);
+    if constexpr (WS == 64 && MODE == MODE_PASS1) {
+        // 64x64 pass 1 (no shifted-window slow paths, so the small planar LDS layout is enough)
+        if (occ == 3) {
+            hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 3>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+            return hipGetLastError();
+        }
+    }
     if (WS <= 32 && occ == 3)
         hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, (WS <= 32 ? 3 : 2)>), dim3((unsigned)blocks), dim3(64), 0,
                            stream, p);
