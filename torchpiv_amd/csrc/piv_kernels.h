@@ -34,6 +34,10 @@ struct PassParams {
     // {c[m], c[left], c[right], c[top], c[bot], c[m2], bits(m), bits(dead)} per window
     float* peak_raw;
     unsigned* work_ctr;      // 8 x 16 dwords: per-XCD item counters of the tile kernel (set by launch_xcorr)
+    // n / d for n < 2^31 as (n * magic) >> shift (set by the tile launcher; keeps the per-item index
+    // arithmetic in the scalar unit instead of a hoisted float reciprocal that occupies a VGPR)
+    unsigned groups_magic, ncols_magic;
+    int groups_shift, ncols_shift;
 };
 
 struct PredictParams {

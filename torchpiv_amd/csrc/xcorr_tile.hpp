@@ -215,6 +215,26 @@ __device__ __forceinline__ float bilerp_ref(float f11, float f21, float f12, flo
 #define TPIV_STAMP_FLUSH(pp)
 #endif
 
+// n / d for 0 <= n < 2^31 with a host-made (magic, shift): exact (magic = ceil(2^shift / d),
+// shift = 31 + ceil(log2 d)); two scalar multiplies for wave-uniform n, v_mul_hi otherwise.
+__device__ __forceinline__ int fast_div(int n, unsigned magic, int shift) {
+    return (int)(((unsigned long long)(unsigned)n * magic) >> shift);
+}
+inline void fast_div_setup(unsigned d, unsigned& magic, int& shift) {
+    int s_ = 0;
+    while ((1ull << s_) < d) ++s_;
+    shift = 31 + s_;
+    magic = (unsigned)(((1ull << shift) + d - 1) / d);
+}
+
+// The lane id, recomputed (two VALU instructions) and opaque to CSE: values derived from it at the
+// point of use do not have to stay in registers (or get spilled) across the transforms.
+__device__ __forceinline__ int fresh_lane() {
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
+
 // A workgroup is ONE wavefront, and the LDS executes one wavefront's DS instructions in order,
 // so exchanging data between lanes through LDS needs no s_barrier and no s_waitcnt: only the
 // compiler must keep the program order of the LDS accesses.  (A real __syncthreads() would also
@@ -762,14 +782,9 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
                   "slow-path row buffer (shifted passes) must fit the tile LDS");
     __shared__ float tile[G::LDS_FLOATS];
 
-    const int lane = threadIdx.x;
-    const int w = lane / WS;          // window slot inside the wavefront
-    const int r = lane % WS;          // image row of the window held by this lane (then: column / line)
-    const int grp0 = lane - r;        // first lane of this window
-
     const int N = p.n_rows * p.n_cols;
     const int groups = (N + G::WPW - 1) / G::WPW;
-    const long long items = (long long)p.batch * groups;
+    const int items = p.batch * groups;               // < 2^31 (checked by the launcher)
     const int st = p.ws - p.ov;
 
     // XCD-aware item order: workgroups b, b+8, ... share an XCD (and its L2); every XCD owns one
@@ -780,39 +795,44 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
     // Small tiles take QCH items per atomic to keep the counter below its ~88 dequeues/us limit.
     constexpr int QCH = WS <= 16 ? 4 : 1;
     const int xcd = blockIdx.x & 7;
-    const long long chunk = (items + 7) / 8;
-    const long long lo = (long long)xcd * chunk;
-    const long long hi = (lo + chunk < items) ? lo + chunk : items;
+    const int chunk = (int)(((long long)items + 7) / 8);
+    const int lo = __builtin_amdgcn_readfirstlane(xcd * chunk < items ? xcd * chunk : items);
+    const int hi = __builtin_amdgcn_readfirstlane(items - lo > chunk ? lo + chunk : items);
     unsigned* const ctr = p.work_ctr + xcd * 16;          // one 64-byte line per counter
     // The dequeue is split into issue (atomic goes out at the loop head) and take (its result is read
-    // at the loop end), so that its ~2 us round trip hides behind a whole item.
-    long long q_base = 0;
+    // after the sample conversion), so that its round trip hides behind the conversion.
+    int q_base = 0;
     int q_left = 0;
-    unsigned q_raw = 0;
-    auto q_issue = [&]() TPIV_LAMBDA_INLINE {
+    auto q_issue = [&]() TPIV_LAMBDA_INLINE -> unsigned {      // returns lane 0's counter value (a VGPR)
+        unsigned v = 0;
         if (QCH == 1 || q_left == 0) {
-            if (lane == 0) q_raw = atomicAdd(ctr, (unsigned)QCH);
+            if (fresh_lane() == 0) v = atomicAdd(ctr, (unsigned)QCH);
         }
+        return v;
     };
-    auto q_take = [&]() TPIV_LAMBDA_INLINE -> long long {
+    auto q_take = [&](unsigned q_raw) TPIV_LAMBDA_INLINE -> int {
         if (QCH == 1 || q_left == 0) {
-            q_base = lo + (long long)__builtin_amdgcn_readfirstlane((int)q_raw);
+            // (a counter value past the end of the run can be anything below 2^31 + grid size: clamp)
+            const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)q_raw);
+            q_base = v < (unsigned)(hi - lo) ? lo + (int)v : hi;
             q_left = QCH;
         }
-        const long long it = q_base + (QCH - q_left);
+        const int it = q_base + (QCH - q_left);
         --q_left;
         return it;
     };
 
-    auto geom_of = [&](long long item) TPIV_LAMBDA_INLINE {
+    // per-lane geometry of an item; `w` = the lane's window slot (a fresh copy at every call site)
+    auto geom_of = [&](int item, int w) TPIV_LAMBDA_INLINE {
         ItemGeom g;
-        g.pair = (int)(item / groups);
-        const int gi = (int)(item % groups);
+        g.pair = fast_div(item, p.groups_magic, p.groups_shift);
+        const int gi = item - g.pair * groups;
         const int win_raw = gi * G::WPW + w;
         g.active = win_raw < N ? 1 : 0;
         g.win = g.active ? win_raw : N - 1;
-        g.y0 = (g.win / p.n_cols) * st;
-        g.x0 = (g.win % p.n_cols) * st;
+        const int wrow = fast_div(g.win, p.ncols_magic, p.ncols_shift);
+        g.y0 = wrow * st;
+        g.x0 = (g.win - wrow * p.n_cols) * st;
         g.fidx = (size_t)g.pair * N + g.win;
         return g;
     };
@@ -826,31 +846,41 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         }
     };
 
-    q_issue();
-    long long item = q_take();
+    int item = q_take(q_issue());
     if (item >= hi) return;
-    q_issue();
-    long long nitem = q_take();                          // the queue runs two items ahead of the FFTs
+    int nitem = q_take(q_issue());                       // the queue runs two items ahead of the FFTs
     // software pipeline: rows of item i+1 in flight during item i (its shifts are fetched at the loop
     // head and have the conversion of item i to land)
-    ItemGeom gcur = geom_of(item);
+    // Tiles of 32 and 64 are register-bound: they re-derive the per-lane geometry where it is needed
+    // (scalar magic division + a few VALU instructions).  Small tiles have registers to spare and
+    // short iterations, so they carry it instead (recomputing cost the 16x16 pass 5 %).
+    constexpr bool RECOMPUTE = WS >= 32;
     float vx, vy;
-    shift_of(gcur, vx, vy);
     RawRows<WS, MODE> raw;
-    issue_rows<WS, MODE>(p, gcur, r, vx, vy, raw);
+    ItemGeom gcur;
+    {
+        const int l0 = fresh_lane();
+        gcur = geom_of(item, l0 / WS);
+        shift_of(gcur, vx, vy);
+        issue_rows<WS, MODE>(p, gcur, l0 % WS, vx, vy, raw);
+    }
 
     TPIV_STAMP_DECL
     TPIV_STAMP_START;
-    for (; item < hi; item = nitem, nitem = q_take()) {
-        q_issue();
+    for (int nnitem; item < hi; item = nitem, nitem = nnitem) {
+        const unsigned q_raw = q_issue();
 #ifdef TPIV_STAMPS
         ++st_iter;
 #endif
-        const ItemGeom g = gcur;
+        const int lane = fresh_lane();
+        const int w = lane / WS;          // window slot inside the wavefront
+        const int r = lane % WS;          // image row of the window held by this lane
+        const ItemGeom g = RECOMPUTE ? geom_of(item, w) : gcur;
         const bool active = g.active != 0;
         const size_t fidx = g.fidx;
         // (the last iteration simply re-loads its own item: no branch around the prefetch)
-        const ItemGeom gnext = geom_of(nitem < hi ? nitem : item);
+        const int nit = nitem < hi ? nitem : item;
+        const ItemGeom gnext = geom_of(nit, w);
         float nvx, nvy;
         shift_of(gnext, nvx, nvy);
 
@@ -859,6 +889,11 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         TPIV_STAMP(0);      // loop head: geometry, next shifts, combine loads
         convert_rows<WS, MODE>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile);
         TPIV_STAMP(1);      // wait for the rows + conversion / bilinear sampling
+        // the dequeue issued at the loop head has landed by now: move it to a scalar register (kept in
+        // a VGPR to the loop end it would be spilled, and the reload would wait behind the prefetch)
+        // (small tiles: the conversion is too short to cover the round trip; there it is read at the
+        //  loop end, where the VGPR it waits in costs nothing)
+        if constexpr (WS >= 32) nnitem = q_take(q_raw);
         // small tiles: the row registers are free again, so the next item's loads go out now and
         // have the whole iteration to land (64x64 is register-bound: it waits until the peak search)
         if constexpr (WS <= 32) issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
@@ -899,7 +934,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         // ---- forward 2-D transform of a + i*b: rows in registers, transpose, columns in registers
         fft_inreg<WS, 1>(x);                              // over x; bin kx at x[FFT_POS<kx>]
         TPIV_STAMP(3);      // forward row FFT
-        transpose_tile<WS, true, PLANAR>(x, tile, lane);          // lane = kx, x[y] natural
+        transpose_tile<WS, true, PLANAR>(x, tile, fresh_lane());  // lane = kx, x[y] natural
         TPIV_STAMP(4);      // transposition 1
         fft_inreg<WS, 1>(x);                              // over y; Z(ky, kx = lane) at x[FFT_POS<ky>]
         TPIV_STAMP(5);      // forward column FFT
@@ -907,7 +942,9 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         // ---- cross-spectrum.  A = (Z(k) + conj Z(-k))/2, B = (Z(k) - conj Z(-k))/(2i),
         //      P = conj(A) * B / n^2.  Z(-ky, -kx) sits in lane (-kx mod WS), register (-ky mod WS).
         {
-            const int partner = grp0 + ((WS - r) % WS);
+            const int lane_c = fresh_lane();
+            const int r_c = lane_c % WS;
+            const int partner = (lane_c - r_c) + ((WS - r_c) % WS);
             constexpr float scale = 0.25f / (float)(WS * WS);
             // with zk = a + ib, zm = Z(-k) = c + id:  4 P = conj(2A) * (2B)
             //   re = (a+c)(b+d) + (b-d)(c-a) = 2 (a d + b c),   im = (c^2 - a^2) + (d^2 - b^2)
@@ -950,34 +987,37 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         });
         fft_inreg<WS, -1>(t);                             // over ky; row y at t[FFT_POS<y>]
         TPIV_STAMP(7);      // inverse column FFT
-        transpose_tile<WS, true, PLANAR>(t, tile, lane);          // lane = y, t[kx] natural
+        transpose_tile<WS, true, PLANAR>(t, tile, fresh_lane());  // lane = y, t[kx] natural
         TPIV_STAMP(8);      // transposition 2
         fft_inreg<WS, -1>(t);                             // over kx; corr(y = lane, x) at t[FFT_POS<x>].x
         wave_sync();                                  // tile reads done: it becomes the map
         TPIV_STAMP(9);      // inverse row FFT
 
         // ---- prefetch: the next item's row loads fly while this item's peak search runs
-        if constexpr (WS > 32) issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
-        gcur = gnext;
+        if constexpr (WS > 32) {
+            const int lane_p = fresh_lane();
+            issue_rows<WS, MODE>(p, geom_of(nit, lane_p / WS), lane_p % WS, nvx, nvy, raw);
+        }
         vx = nvx;
         vy = nvy;
+        if constexpr (!RECOMPUTE) gcur = gnext;
 
         TPIV_STAMP(10);     // issue of the next item's row loads
-        {
-            // Re-derive the window index from the (wave-uniform) item position instead of keeping
-            // the per-lane geometry alive through the transforms: those cold values were what the
-            // register allocator spilled (13 dwords per lane per iteration = 3x the algorithmic bytes
-            // of scratch traffic).  The asm makes the value opaque so that it is really recomputed.
-            int pair_e = __builtin_amdgcn_readfirstlane(g.pair);
-            int gi_e = __builtin_amdgcn_readfirstlane((int)(item % groups));
-            asm volatile("" : "+s"(pair_e), "+s"(gi_e));
-            const int win_raw_e = gi_e * G::WPW + w;
+        if constexpr (RECOMPUTE) {
+            // the window index is re-derived from the (wave-uniform) item position, see above
+            const int lane_e = fresh_lane();
+            const int w_e = lane_e / WS, r_e = lane_e % WS;
+            const int pair_e = fast_div(item, p.groups_magic, p.groups_shift);
+            const int win_raw_e = (item - pair_e * groups) * G::WPW + w_e;
             const bool active_e = win_raw_e < N;
             const int win_e = active_e ? win_raw_e : N - 1;
             const size_t fidx_e = (size_t)pair_e * N + win_e;
-            peak_analysis<WS, PLANAR>(p, t, tile, w, r, active_e, dead, fidx_e);
+            peak_analysis<WS, PLANAR>(p, t, tile, w_e, r_e, active_e, dead, fidx_e);
+        } else {
+            peak_analysis<WS, PLANAR>(p, t, tile, w, r, active, dead, fidx);
         }
         wave_sync();
+        if constexpr (WS < 32) nnitem = q_take(q_raw);
         TPIV_STAMP(13);     // sub-pixel fit, combine, stores
     }
     TPIV_STAMP_FLUSH(p);
@@ -1015,11 +1055,15 @@ hipError_t launch_peak_debug(const PassParams& p, const float* maps, int n_maps,
 }
 
 template <int WS, int MODE>
-static hipError_t launch_tile(const PassParams& p, int n_cu, hipStream_t stream) {
+static hipError_t launch_tile(const PassParams& p_in, int n_cu, hipStream_t stream) {
     using G = TileGeo<WS>;
+    PassParams p = p_in;
     const int N = p.n_rows * p.n_cols;
     const long long groups = (N + G::WPW - 1) / G::WPW;
     const long long items = (long long)p.batch * groups;
+    if (items <= 0 || items >= (1ll << 31) - 64) return hipErrorInvalidValue;     // 32-bit item arithmetic
+    fast_div_setup((unsigned)groups, p.groups_magic, p.groups_shift);
+    fast_div_setup((unsigned)p.n_cols, p.ncols_magic, p.ncols_shift);
     long long blocks = items;
     // Up to 64 single-wavefront workgroups per CU; each pulls items from its XCD's counter until the
     // run is empty, so surplus workgroups exit at once and the grid size only has to cover the
@@ -1034,11 +1078,12 @@ static hipError_t launch_tile(const PassParams& p, int n_cu, hipStream_t stream)
     const long long cap = (long long)n_cu * (wg_per_cu > 0 ? wg_per_cu : 64);
     if (blocks > cap) blocks = cap;
     blocks = (blocks + 7) / 8 * 8;                  // the XCD remap needs a multiple of 8
-    // Register budget (wavefronts per SIMD).  The 32x32 and 16x16 kernels run three wavefronts per
-    // SIMD: 168 VGPRs (pass 1 / DWS spill-free, 32x32 CWS with ~20 cold spills of loop-carried
-    // scalars) and planar LDS tiles (8.4 KB per wavefront at 32x32).  Measured vs two wavefronts:
+    // Register budget (wavefronts per SIMD).  32x32, 16x16 and 64x64 pass 1 run three wavefronts per
+    // SIMD (<= 168 VGPRs, planar LDS tiles of 8.4 KB per wavefront).  Measured vs two wavefronts:
     // 32x32 DWS pass 33.6 -> 27.4 us/pair, 32x32 CWS pass 48.0 -> 43.9, 16x16 CWS pass (4096^2)
-    // 213.9 -> 189.6; 8x8 is unchanged and stays at two.  TPIV_OCC=2|3|4 overrides for experiments.
+    // 213.9 -> 189.6, 64x64 pass 1 32.3 -> 29.1; four (possible for 32x32 pass 1 / DWS and 16x16 since
+    // the peak search stopped using compare/select chains) gains nothing more: the VALU is saturated.
+    // 8x8 stays at two.  TPIV_OCC=2|3|4 overrides for experiments.
     static const int occ_env = [] {
         const char* e = getenv("TPIV_OCC");
         return e ? atoi(e) : 0;
