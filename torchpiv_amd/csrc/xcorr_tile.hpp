@@ -923,11 +923,16 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             ka = dead ? 0.f : 1.0f / ma;
             kb = dead ? 0.f : 1.0f / mb;
         }
+        // The 1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra are applied
+        // HERE, as the power of two 0.5/WS on both inputs: exact (no rounding anywhere changes), and
+        // it saves the per-bin scaling multiplies of the cross-spectrum.
+        constexpr float PRE = 0.5f / (float)WS;
         const float oa = -ma * ka, ob = -mb * kb;
+        const float kas = ka * PRE, kbs = kb * PRE, oas = oa * PRE, obs = ob * PRE;
 #pragma unroll
         for (int k = 0; k < WS; ++k) {
-            x[k].x = fmaf(x[k].x, ka, oa);          // (x - mean) * k
-            x[k].y = fmaf(x[k].y, kb, ob);
+            x[k].x = fmaf(x[k].x, kas, oas);        // (x - mean) * k * 0.5/WS
+            x[k].y = fmaf(x[k].y, kbs, obs);
         }
 
         TPIV_STAMP(2);      // mean reduction + normalisation
@@ -945,14 +950,14 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             const int lane_c = fresh_lane();
             const int r_c = lane_c % WS;
             const int partner = (lane_c - r_c) + ((WS - r_c) % WS);
-            constexpr float scale = 0.25f / (float)(WS * WS);
             // with zk = a + ib, zm = Z(-k) = c + id:  4 P = conj(2A) * (2B)
             //   re = (a+c)(b+d) + (b-d)(c-a) = 2 (a d + b c),   im = (c^2 - a^2) + (d^2 - b^2)
+            // (the factor 0.25 / WS^2 is already in the inputs, see the normalisation above)
             auto cross = [&](cf zk, cf zm) TPIV_LAMBDA_INLINE {
                 const float a_ = zk.x, b_ = zk.y, c_ = zm.x, d_ = zm.y;
                 cf pr;
-                pr.x = (a_ * d_ + b_ * c_) * (2.0f * scale);
-                pr.y = ((c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_)) * scale;
+                pr.x = (a_ * d_ + b_ * c_) * 2.0f;
+                pr.y = (c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_);
                 return pr;
             };
             static_for<0, WS / 2 + 1>([&](auto kc) TPIV_LAMBDA_INLINE {
