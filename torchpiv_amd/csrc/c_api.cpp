@@ -86,7 +86,7 @@ int check_window(int H, int W, int ws, int ov, int val_win) {
     const bool pow2 = ws == 8 || ws == 16 || ws == 32 || ws == 64 || ws == 128;
     if (val_win < 0 || (pow2 && 2 * val_win >= ws))
         return fail(TPIV_EUNSUPPORTED, "validation half-window must satisfy 2*val_win < window size");
-    if ((long long)H * W >= (1LL << 31)) return fail(TPIV_EUNSUPPORTED, "frame too large");
+    if (((long long)H + 32) * W >= (1LL << 30)) return fail(TPIV_EUNSUPPORTED, "frame too large");   // 32-bit flat indices
     return TPIV_OK;
 }
 

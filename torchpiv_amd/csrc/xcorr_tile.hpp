@@ -457,6 +457,19 @@ __device__ __forceinline__ int classify_row(long long q, int used, int loaded, i
     return 3;
 }
 
+__device__ __forceinline__ int clamp_i(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// The same classification in 32-bit arithmetic (callers clamp the row index first, see issue_rows):
+// a 64-bit compare or select is two to four VALU instructions, and this runs four times per item.
+__device__ __forceinline__ int classify_row32(int q, int used, int loaded, int HW, int& qload) {
+    const int lim = HW - loaded;
+    const bool inside = (unsigned)q <= (unsigned)lim;          // 0 <= q <= lim
+    const bool before = q + used - 1 <= 0;
+    const bool behind = q >= HW - 1;
+    qload = inside ? q : (behind && !before ? lim : 0);
+    return inside ? 0 : (before ? 1 : (behind ? 2 : 3));
+}
+
 template <int N>
 __device__ __forceinline__ void fix_row(uint32_t (&d)[N], int cls) {
     const uint32_t px = (cls == 1 ? (d[0] & 0xffu) : (d[N - 1] >> 24)) * 0x01010101u;
@@ -499,26 +512,34 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         const float fvx = floorf(vx);
         const float frac = vx - fvx;
         const float thr = (float)(p.W + 64) * 4.76837158e-07f;       // (W + 64) * 2^-21
-        const int ivx = f2i_sat_t(fvx);
+        // 32-bit flat indices: |floor(vx)| <= W on the fast path, and a source row further than 8
+        // rows outside the frame classifies exactly like row -8 / H+7 (the whole run stays before
+        // pixel 0 / behind the last pixel), so the clamped values give the same class and address.
+        const int W_ = p.W;
+        const int ivx = clamp_i(f2i_sat_t(fvx), -W_, W_);
+        const int rlo = -8, rhi = p.H + 7;
+        const int dya = clamp_i(c.dya, rlo, rhi), uya = clamp_i(c.uya, rlo, rhi);
+        const int dyb = clamp_i(c.dyb, rlo, rhi), uyb = clamp_i(c.uyb, rlo, rhi);
         // frame a uses -vx: floor(-vx) = -floor(vx) - 1 when frac != 0
-        const long long qa0 = (long long)c.dya * p.W + (g.x0 - ivx - 1);
-        const long long qa1 = (long long)c.uya * p.W + (g.x0 - ivx - 1);
-        const long long qb0 = (long long)c.dyb * p.W + (g.x0 + ivx);
-        const long long qb1 = (long long)c.uyb * p.W + (g.x0 + ivx);
-        const long long lim = (long long)HW - 4 * NB;
-        long long la0, la1, lb0, lb1;
-        const int c0 = classify_row(qa0, WS + 1, 4 * NB, HW, la0), c1 = classify_row(qa1, WS + 1, 4 * NB, HW, la1);
-        const int c2 = classify_row(qb0, WS + 1, 4 * NB, HW, lb0), c3 = classify_row(qb1, WS + 1, 4 * NB, HW, lb1);
+        const int xa = g.x0 - ivx - 1, xb = g.x0 + ivx;
+        const int qa0 = dya * W_ + xa, qa1 = uya * W_ + xa;
+        const int qb0 = dyb * W_ + xb, qb1 = uyb * W_ + xb;
+        int la0, la1, lb0, lb1;
+        const int c0 = classify_row32(qa0, WS + 1, 4 * NB, HW, la0), c1 = classify_row32(qa1, WS + 1, 4 * NB, HW, la1);
+        const int c2 = classify_row32(qb0, WS + 1, 4 * NB, HW, lb0), c3 = classify_row32(qb1, WS + 1, 4 * NB, HW, lb1);
         const bool reg = c0 != 3 && c1 != 3 && c2 != 3 && c3 != 3 && frac > thr && frac < 1.0f - thr &&
                          fabsf(vx) < (float)p.W;
         raw.reg = __all(reg) ? 1 : 0;
         raw.cls = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
         raw.fix = (raw.reg && __any(raw.cls != 0)) ? 1 : 0;
-        const long long safe = base < lim ? base : lim;
-        load_dwords<NB>(fa + (raw.reg ? la0 : safe), raw.a0);
-        load_dwords<NB>(fa + (raw.reg ? la1 : safe), raw.a1);
-        load_dwords<NB>(fb + (raw.reg ? lb0 : safe), raw.b0);
-        load_dwords<NB>(fb + (raw.reg ? lb1 : safe), raw.b1);
+        const int lim = HW - 4 * NB;
+        const int base32 = (g.y0 + r) * W_ + g.x0;
+        const int safe = base32 < lim ? base32 : lim;
+        // (unsigned 32-bit offsets from the wave-uniform frame pointers: scalar base + VGPR offset loads)
+        load_dwords<NB>(fa + (unsigned)(raw.reg ? la0 : safe), raw.a0);
+        load_dwords<NB>(fa + (unsigned)(raw.reg ? la1 : safe), raw.a1);
+        load_dwords<NB>(fb + (unsigned)(raw.reg ? lb0 : safe), raw.b0);
+        load_dwords<NB>(fb + (unsigned)(raw.reg ? lb1 : safe), raw.b1);
     }
 }
 
