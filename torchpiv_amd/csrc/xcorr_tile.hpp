@@ -910,11 +910,11 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         TPIV_STAMP(0);      // loop head: geometry, next shifts, combine loads
         convert_rows<WS, MODE>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile);
         TPIV_STAMP(1);      // wait for the rows + conversion / bilinear sampling
-        // the dequeue issued at the loop head has landed by now: move it to a scalar register (kept in
-        // a VGPR to the loop end it would be spilled, and the reload would wait behind the prefetch)
-        // (small tiles: the conversion is too short to cover the round trip; there it is read at the
-        //  loop end, where the VGPR it waits in costs nothing)
-        if constexpr (WS >= 32) nnitem = q_take(q_raw);
+        // 64x64 (register-bound): the dequeue issued at the loop head has landed by now; move it to a
+        // scalar register (kept in a VGPR to the loop end it would be spilled, and the reload would
+        // wait behind the prefetch).  Smaller tiles: the conversion is too short to cover the atomic's
+        // round trip (the stamps showed the wait), and a VGPR to the loop end costs nothing there.
+        if constexpr (WS >= 64) nnitem = q_take(q_raw);
         // small tiles: the row registers are free again, so the next item's loads go out now and
         // have the whole iteration to land (64x64 is register-bound: it waits until the peak search)
         if constexpr (WS <= 32) issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             peak_analysis<WS, PLANAR>(p, t, tile, w, r, active, dead, fidx);
         }
         wave_sync();
-        if constexpr (WS < 32) nnitem = q_take(q_raw);
+        if constexpr (WS < 64) nnitem = q_take(q_raw);
         TPIV_STAMP(13);     // sub-pixel fit, combine, stores
     }
     TPIV_STAMP_FLUSH(p);
