@@ -11,6 +11,7 @@ hipError_t launch_xcorr_ws16(const PassParams& p, int mode, int n_cu, hipStream_
 hipError_t launch_xcorr_ws32(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws64(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws128(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+hipError_t launch_xcorr_big128_pass1(const PassParams& p, int n_cu, hipStream_t stream);
 hipError_t launch_peak_debug_ws8(const PassParams& p, const float* maps, int n_maps, hipStream_t stream);
 hipError_t launch_peak_debug_ws16(const PassParams& p, const float* maps, int n_maps, hipStream_t stream);
 struct cf;
@@ -96,7 +97,7 @@ static constexpr size_t WORK_CTR_BYTES = 8 * 16 * sizeof(unsigned);
 static size_t work_ctr_offset(int batch, int n_windows) { return (peak_bytes(batch, n_windows) + 127) / 128 * 128; }
 
 size_t peak_raw_bytes(int ws, int batch, int n_windows) {
-    if (ws == 128) return 0;                          // first-generation kernel: fused epilogue
+    if (ws == 128) return peak_bytes(batch, n_windows);      // pass 1 (xcorr_big.hpp); shifted passes fuse the epilogue
     if (tile_size(ws)) return work_ctr_offset(batch, n_windows) + WORK_CTR_BYTES;   // records + item counters
     size_t b = peak_bytes(batch, n_windows);
     if (!tile_size(ws))
@@ -118,7 +119,10 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
         case 16: e = launch_xcorr_ws16(p, mode, n_cu, stream); break;
         case 32: e = launch_xcorr_ws32(p, mode, n_cu, stream); break;
         case 64: e = launch_xcorr_ws64(p, mode, n_cu, stream); break;
-        case 128: return launch_xcorr_ws128(p, mode, n_cu, stream);      // fused epilogue
+        case 128:
+            if (mode != MODE_PASS1) return launch_xcorr_ws128(p, mode, n_cu, stream);      // fused epilogue
+            e = launch_xcorr_big128_pass1(p, n_cu, stream);
+            break;
         default: {
             if (p.ws < 2 || p.ws > 256) return hipErrorInvalidValue;
             cf* scratch = reinterpret_cast<cf*>(reinterpret_cast<char*>(p.peak_raw) +

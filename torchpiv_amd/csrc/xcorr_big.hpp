@@ -1,0 +1,374 @@
+// Second-generation kernel for 128x128 interrogation windows, first pass (no window shift).
+//
+// A 128-point line does not fit one lane (128 complex samples = 256 VGPRs), so a line is split over
+// TWO threads by sample parity and every 128-point transform becomes a 64-point in-register codelet
+// (fft_inreg.hpp) plus one radix-2 combine, and the combines are folded into the LDS transposes that
+// are needed anyway:
+//
+//   workgroup = 256 threads = one window;  thread t:  line = t & 127,  parity = t >> 7
+//   stage 0   rows:    thread (y, h) takes samples x = 2j + h of image row y (a in .x, b in .y),
+//                      window means by a block reduction, normalise (B:513-514)
+//   stage 1   rows:    64-point forward FFT              F_h[y][k1]
+//   stage 2   T1:      plane[y][64h + k1] <- F_h;   thread (k, g) reads rows y = 2i + g and forms
+//                      X[y][k] = F_0[y][k1] +- w^k1 F_1[y][k1]          (decimation in time, k1 = k mod 64)
+//   stage 3   columns: 64-point forward FFT over i       G_g[ky1]       (column k, row parity g)
+//   stage 4   spectrum: plane[ky1 + 64g][k] <- (g ? w^ky1 G_1 : G_0);  thread (k, a) forms
+//                      Z[ky1 + 64a][k] = G_0 +- w^ky1 G_1  and the mirrored bin Z[-ky][-k] from the
+//                      same plane, then the cross-spectrum P = conj(A) B of the packed transform
+//   stage 5   columns^-1: partner exchange through the plane (decimation in frequency):
+//                      u = P[ky1] + P[ky1+64]  (even rows, a = 0),  (P[ky1] - P[ky1+64]) w^-ky1  (odd rows)
+//                      and a 64-point inverse FFT  ->  Y[2i + a][k]
+//   stage 6   T2 + rows^-1: plane[2i + a][k] <- Y;  thread (y, h) reads its row, forms the DIF
+//                      split over k and runs the last 64-point inverse FFT -> corr[y][2j + h]
+//   stage 7   peak analysis of the 128x128 map in LDS (same record for finalize_kernel as the tile
+//                      kernel: B:346-358, B:381-392, B:518)
+//
+// The LDS plane holds ONE float component of the 128x128 tile (66 KB): two workgroups per CU, two
+// wavefronts per SIMD, 256 VGPRs per thread.  Real and imaginary planes pass one after the other.
+#pragma once
+#include "xcorr_tile.hpp"
+
+namespace tpiv {
+
+constexpr int BW = 128;               // window edge
+constexpr int BP = 129;               // plane pitch (floats): conflict-free rows and columns
+constexpr int BH = 64;                // codelet length
+
+struct BigShared {
+    float plane[BW * BP];
+    float redf[8];
+    int redi[8];
+};
+
+// reduction over the 256 threads of the workgroup; every thread gets the result
+template <typename T, typename OP>
+__device__ __forceinline__ T block_reduce(T v, OP op, T* red, int wave, int lane) {
+    v = grp_reduce<64>(v, op);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return op(op(red[0], red[1]), op(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
+    __shared__ BigShared sm;
+    float* const plane = sm.plane;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int line = t & 127;         // row y (stages 0-1, 6-7) or column k (stages 2-5)
+    const int par = t >> 7;           // sample / line parity handled by this thread (wave-uniform)
+    const float sgn = par ? -1.f : 1.f;
+
+    const int N = p.n_rows * p.n_cols;
+    const long long items = (long long)p.batch * N;
+    const int st = p.ws - p.ov;
+    const int HW = p.H * p.W;
+
+    // forward twiddle of the row combine (stage 2): w^k1 = exp(-2 pi i k1 / 128), sign of the half folded in
+    const int k1r = line & 63;
+    const float twr = (float)cospi((double)k1r / 64.0), twi = (float)(-sinpi((double)k1r / 64.0));
+    const float s2 = line < 64 ? 1.f : -1.f;
+    const float cwr = s2 * twr, cwi = s2 * twi;
+
+    // XCD-aware static order: workgroups b, b+8, ... share an XCD and walk one contiguous run of windows
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const long long chunk = (items + 7) / 8;
+    const long long lo = (long long)xcd * chunk;
+    const long long hi = lo + chunk < items ? lo + chunk : items;
+
+    for (long long item = lo + slot; item < hi; item += per_xcd) {
+        const int pair = (int)(item / N), win = (int)(item % N);
+        const int y0 = (win / p.n_cols) * st, x0 = (win % p.n_cols) * st;
+        const size_t fidx = (size_t)item;
+
+        // ---------------- stage 0: samples 2j + par of row `line`
+        cf x[BH];
+        float sa, sb;
+        {
+            const uint8_t* __restrict__ ra = p.A + (size_t)pair * HW + (size_t)(y0 + line) * p.W + x0;
+            const uint8_t* __restrict__ rb = p.B + (size_t)pair * HW + (size_t)(y0 + line) * p.W + x0;
+            uint32_t da[32], db[32];
+            load_dwords<32>(ra, da);
+            load_dwords<32>(rb, db);
+            const uint32_t mask = par ? 0xff00ff00u : 0x00ff00ffu;
+            const int sh = 8 * par;
+            unsigned ia = 0, ib = 0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                ia = __builtin_amdgcn_sad_u8(da[q] & mask, 0u, ia);
+                ib = __builtin_amdgcn_sad_u8(db[q] & mask, 0u, ib);
+                da[q] >>= sh;
+                db[q] >>= sh;
+            }
+            static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
+                constexpr int j = decltype(jc)::value;          // byte 2j (+par, shifted away) of the row
+                x[j].x = byte_f<2 * j, 32>(da);
+                x[j].y = byte_f<2 * j, 32>(db);
+            });
+            sa = (float)ia;
+            sb = (float)ib;
+        }
+        if (p.dbg_win != nullptr) {       // test hook: the staged window
+            float* d = p.dbg_win + fidx * 2 * BW * BW + line * BW + par;
+#pragma unroll
+            for (int j = 0; j < BH; ++j) {
+                d[2 * j] = x[j].x;
+                d[BW * BW + 2 * j] = x[j].y;
+            }
+        }
+        auto fadd = [](float a, float b) TPIV_LAMBDA_INLINE { return a + b; };
+        sa = block_reduce(sa, fadd, sm.redf, wave, lane);          // exact: integers below 2^24
+        sb = block_reduce(sb, fadd, sm.redf + 4, wave, lane);
+        const bool dead = (sa == 0.f) || (sb == 0.f);   // zero-mean window: 0/0 = NaN map in the reference
+        {
+            constexpr float PRE = 0.5f / (float)BW;     // 1/n^2 and the 1/4 of the cross-spectrum, exact
+            const float ma = sa * (1.0f / (BW * BW)), mb = sb * (1.0f / (BW * BW));
+            const float ka = dead ? 0.f : 1.0f / ma, kb = dead ? 0.f : 1.0f / mb;
+            const float oa = -ma * ka, ob = -mb * kb;
+            const float kas = ka * PRE, kbs = kb * PRE, oas = oa * PRE, obs = ob * PRE;
+#pragma unroll
+            for (int j = 0; j < BH; ++j) {
+                x[j].x = fmaf(x[j].x, kas, oas);
+                x[j].y = fmaf(x[j].y, kbs, obs);
+            }
+        }
+
+        // ---------------- stage 1: forward row codelet; F_par[line][k1] at x[FFT_POS<k1>]
+        fft_inreg<BH, 1>(x);
+
+        // ---------------- stage 2: transposition + row combine -> x[i] = X[2i + par][k = line]
+        {
+            float A_[BH], B_[BH];
+            __syncthreads();                                   // plane free (previous item's map)
+            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k1 = decltype(kc)::value;
+                plane[line * BP + 64 * par + k1] = x[FFT_POS<k1, BH>].x;
+            });
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < BH; ++i) {
+                const float E = plane[(2 * i + par) * BP + k1r], O = plane[(2 * i + par) * BP + 64 + k1r];
+                A_[i] = fmaf(cwr, O, E);                       // Re: E.re + wr O.re (- wi O.im later)
+                B_[i] = cwi * O;                               // Im: wi O.re (+ E.im + wr O.im later)
+            }
+            __syncthreads();
+            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k1 = decltype(kc)::value;
+                plane[line * BP + 64 * par + k1] = x[FFT_POS<k1, BH>].y;
+            });
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < BH; ++i) {
+                const float E = plane[(2 * i + par) * BP + k1r], O = plane[(2 * i + par) * BP + 64 + k1r];
+                x[i].x = fmaf(-cwi, O, A_[i]);
+                x[i].y = fmaf(cwr, O, E + B_[i]);
+            }
+        }
+
+        // ---------------- stage 3: forward column codelet; G_par[ky1] at x[FFT_POS<ky1>] (column `line`)
+        fft_inreg<BH, 1>(x);
+
+        // ---------------- stage 4: column combine, mirrored bin, cross-spectrum
+        //   thread (k, a = par) owns bins ky = ky1 + 64a:  Z = G_0 + s w^ky1 G_1,  s = a ? -1 : +1
+        {
+            if (par) {       // wave-uniform: the odd-row threads contribute w^ky1 G_1
+                static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int ky1 = decltype(kc)::value;
+                    x[FFT_POS<ky1, BH>] = twmul<ky1, BW, 1>(x[FFT_POS<ky1, BH>]);
+                });
+            }
+            const int mk = (BW - line) & (BW - 1);             // mirrored column
+            float za[BH], zc[BH];                              // Re Z(k), Re Z(-k)
+            __syncthreads();
+            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int ky1 = decltype(kc)::value;
+                plane[(ky1 + 64 * par) * BP + line] = x[FFT_POS<ky1, BH>].x;
+            });
+            __syncthreads();
+            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int ky1 = decltype(kc)::value;
+                // mirrored row index of ky = ky1 + 64 par:  mky = (128 - ky) mod 128
+                const int mky = (BW - ky1 - 64 * par) & (BW - 1);
+                const int mky1 = mky & 63;
+                const float ms = (mky >> 6) ? -1.f : 1.f;
+                za[ky1] = fmaf(sgn, plane[(64 + ky1) * BP + line], plane[ky1 * BP + line]);
+                zc[ky1] = fmaf(ms, plane[(64 + mky1) * BP + mk], plane[mky1 * BP + mk]);
+            });
+            __syncthreads();
+            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int ky1 = decltype(kc)::value;
+                plane[(ky1 + 64 * par) * BP + line] = x[FFT_POS<ky1, BH>].y;
+            });
+            __syncthreads();
+            // with Z(k) = a + ib, Z(-k) = c + id:  re = 2 (a d + b c),  im = (c^2 - a^2) + (d^2 - b^2)
+            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int ky1 = decltype(kc)::value;
+                const int mky = (BW - ky1 - 64 * par) & (BW - 1);
+                const int mky1 = mky & 63;
+                const float ms = (mky >> 6) ? -1.f : 1.f;
+                const float b_ = fmaf(sgn, plane[(64 + ky1) * BP + line], plane[ky1 * BP + line]);
+                const float d_ = fmaf(ms, plane[(64 + mky1) * BP + mk], plane[mky1 * BP + mk]);
+                const float a_ = za[ky1], c_ = zc[ky1];
+                x[ky1].x = (a_ * d_ + b_ * c_) * 2.0f;          // P[ky1 + 64 par][k], natural order
+                x[ky1].y = (c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_);
+            });
+        }
+
+        // ---------------- stage 5: inverse column transform (DIF split over the thread pair)
+        {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BH; ++q) plane[(q + 64 * par) * BP + line] = x[q].x;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BH; ++q) x[q].x = fmaf(sgn, x[q].x, plane[(q + 64 * (1 - par)) * BP + line]);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BH; ++q) plane[(q + 64 * par) * BP + line] = x[q].y;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BH; ++q) x[q].y = fmaf(sgn, x[q].y, plane[(q + 64 * (1 - par)) * BP + line]);
+            // a = 0: P[ky1] + P[ky1+64];  a = 1: P[ky1] - P[ky1+64] (own is the +64 bin: partner - own), times w^-ky1
+            if (par) {
+                static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int ky1 = decltype(kc)::value;
+                    x[ky1] = twmul<ky1, BW, -1>(x[ky1]);
+                });
+            }
+            fft_inreg<BH, -1>(x);                              // Y[2i + par][k] at x[FFT_POS<i>]
+        }
+
+        // ---------------- stage 6: transposition + inverse row transform (DIF split over k)
+        {
+            float v_re[BH];
+            __syncthreads();
+            static_for<0, BH>([&](auto ic) TPIV_LAMBDA_INLINE {
+                constexpr int i = decltype(ic)::value;
+                plane[(2 * i + par) * BP + line] = x[FFT_POS<i, BH>].x;
+            });
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BH; ++q) v_re[q] = fmaf(sgn, plane[line * BP + 64 + q], plane[line * BP + q]);
+            __syncthreads();
+            static_for<0, BH>([&](auto ic) TPIV_LAMBDA_INLINE {
+                constexpr int i = decltype(ic)::value;
+                plane[(2 * i + par) * BP + line] = x[FFT_POS<i, BH>].y;
+            });
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < BH; ++q) {
+                x[q].y = fmaf(sgn, plane[line * BP + 64 + q], plane[line * BP + q]);
+                x[q].x = v_re[q];
+            }
+            if (par) {
+                static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k1 = decltype(kc)::value;
+                    x[k1] = twmul<k1, BW, -1>(x[k1]);
+                });
+            }
+            fft_inreg<BH, -1>(x);                              // corr[line][2j + par] at x[FFT_POS<j>].x
+        }
+
+        // ---------------- stage 7: peak analysis on the map in LDS (fftshift coordinates)
+        {
+            const int ys = (line + 64) & 127;
+            const int KD = BW * BW;
+            float c[BH];                                       // c[j]: column xs(j) = ((2j + 64) & 127) + par
+            float cmin = 3.4e38f;
+            static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
+                constexpr int j = decltype(jc)::value;
+                c[j] = x[FFT_POS<j, BH>].x;
+                cmin = fminf(cmin, c[j]);
+            });
+            auto fmin_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fminf(a, b); };
+            auto fmax_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); };
+            auto imin_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
+            auto imax_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a > b ? a : b; };
+            cmin = block_reduce(cmin, fmin_, sm.redf, wave, lane);       // (also: plane reads of stage 6 done)
+            float rmax = 0.f;
+            static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
+                constexpr int j = decltype(jc)::value;
+                constexpr int xe = (2 * j + 64) & 127;
+                const float v = __fadd_rn(__fsub_rn(c[j], cmin), 1e-7f);       // B:518, B:381
+                c[j] = v;
+                plane[ys * BP + xe + par] = v;
+                rmax = fmaxf(rmax, v);
+            });
+            const float gmax = block_reduce(rmax, fmax_, sm.redf + 4, wave, lane);
+            const int ywin = block_reduce(rmax == gmax ? ys : BW - 1, imin_, sm.redi, wave, lane);   // map complete
+            const int xwin = block_reduce((t < BW && plane[ywin * BP + (t & 127)] == gmax) ? t : BW - 1, imin_,
+                                          sm.redi + 4, wave, lane);
+            const int m = ywin * BW + xwin;
+            if (p.dbg_corr != nullptr) {
+                float* d = p.dbg_corr + fidx * KD + ys * BW + par;
+                static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int xe = (2 * j + 64) & 127;
+                    d[xe] = c[j];
+                });
+            }
+            // second peak: maximum outside the flat-index neighbourhood of m (B:346-358), see peak_analysis
+            const int wv = p.val_win;
+            int smax = 0;
+            {
+                const int dj = ys - ywin;
+                unsigned long long exl = 0ull, exh = 0ull;     // excluded columns 0..63 / 64..127 of this row
+                auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
+                    lo_ = lo_ < 0 ? 0 : lo_;
+                    hi_ = hi_ > BW - 1 ? BW - 1 : hi_;
+                    for (int q = lo_; q <= hi_; ++q) {         // at most 2 wv + 1 columns
+                        if (q < 64) exl |= 1ull << q;
+                        else exh |= 1ull << (q - 64);
+                    }
+                };
+                if (dj >= -wv && dj <= wv) span(xwin - wv, xwin + wv);
+                if (dj + 1 >= -wv && dj + 1 <= wv) span(xwin - wv + BW, xwin + wv + BW);
+                if (dj - 1 >= -wv && dj - 1 <= wv) span(xwin - wv - BW, xwin + wv - BW);
+                if (ys == 0 && (m - wv - wv * BW) <= 0) exl |= 1ull;
+                if (ys == BW - 1 && (m + wv + wv * BW) >= KD - 1) exh |= 1ull << 63;
+                // this thread's columns have parity `par`: shift it away, bit positions become even constants
+                const unsigned e0 = (unsigned)(exl >> par), e1 = (unsigned)(exl >> (32 + par));
+                const unsigned e2 = (unsigned)(exh >> par), e3 = (unsigned)(exh >> (32 + par));
+                static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int xe = (2 * j + 64) & 127;
+                    constexpr int wsel = xe >> 5, bit = xe & 31;
+                    const unsigned word = wsel == 0 ? e0 : (wsel == 1 ? e1 : (wsel == 2 ? e2 : e3));
+                    const int kill = __builtin_amdgcn_sbfe((int)word, bit, 1);
+                    const int cand = __float_as_int(c[j]) | kill;
+                    smax = cand > smax ? cand : smax;
+                });
+            }
+            smax = block_reduce(smax, imax_, sm.redi, wave, lane);
+            const float second_v = smax > 0 ? __int_as_float(smax) : gmax;
+            if (t < 8) {
+                int left = m + 1, right = m - 1, top = m + BW, bot = m - BW;     // B:385-392 (flat index)
+                if (left >= KD - 1) left = m;
+                if (right <= 0) right = m;
+                if (top >= KD - 1) top = m;
+                if (bot <= 0) bot = m;
+                int q = m;
+                q = (t == 1) ? left : q;
+                q = (t == 2) ? right : q;
+                q = (t == 3) ? top : q;
+                q = (t == 4) ? bot : q;
+                float outv = plane[(q / BW) * BP + (q % BW)];
+                outv = (t == 5) ? second_v : outv;
+                outv = (t == 6) ? __int_as_float(m) : outv;
+                outv = (t == 7) ? __int_as_float(dead ? 1 : 0) : outv;
+                p.peak_raw[fidx * 8 + t] = outv;
+            }
+        }
+    }
+}
+
+inline hipError_t launch_xcorr_big128(const PassParams& p, int n_cu, hipStream_t stream) {
+    const long long items = (long long)p.batch * p.n_rows * p.n_cols;
+    if (items <= 0) return hipErrorInvalidValue;
+    long long blocks = items < (long long)n_cu * 16 ? items : (long long)n_cu * 16;
+    blocks = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(xcorr_big128_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace tpiv
