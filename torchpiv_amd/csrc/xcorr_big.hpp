@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
     float* const plane = sm.plane;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int line = t & 127;         // row y (stages 0-1, 6-7) or column k (stages 2-5)
+    const int line_c = t & 127;       // row y (stages 0-1, 6-7) or column k (stages 2-5)
     const int par = t >> 7;           // sample / line parity handled by this thread (wave-uniform)
     const float sgn = par ? -1.f : 1.f;
 
@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
     const int HW = p.H * p.W;
 
     // forward twiddle of the row combine (stage 2): w^k1 = exp(-2 pi i k1 / 128), sign of the half folded in
-    const int k1r = line & 63;
-    const float twr = (float)cospi((double)k1r / 64.0), twi = (float)(-sinpi((double)k1r / 64.0));
-    const float s2 = line < 64 ? 1.f : -1.f;
+    const int k1r_c = line_c & 63;
+    const float twr = (float)cospi((double)k1r_c / 64.0), twi = (float)(-sinpi((double)k1r_c / 64.0));
+    const float s2 = line_c < 64 ? 1.f : -1.f;
     const float cwr = s2 * twr, cwi = s2 * twi;
 
     // XCD-aware static order: workgroups b, b+8, ... share an XCD and walk one contiguous run of windows
@@ -77,6 +77,12 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
     const long long hi = lo + chunk < items ? lo + chunk : items;
 
     for (long long item = lo + slot; item < hi; item += per_xcd) {
+        // LDS addresses are rebuilt from an opaque copy of the line index at every plane pass (OPQ): the
+        // backend pairs the plane accesses into ds_read2/ds_write2 (8-bit offsets), which needs a base
+        // register per pair; left alone it computes all of them once (hoisted out of the loop or to
+        // its head) and spills ~80-130 registers.
+#define TPIV_OPQ_T() [&]() TPIV_LAMBDA_INLINE { int t_ = t; asm volatile("" : "+v"(t_)); return t_; }()
+        const int line = TPIV_OPQ_T() & 127;
         const int pair = (int)(item / N), win = (int)(item % N);
         const int y0 = (win / p.n_cols) * st, x0 = (win % p.n_cols) * st;
         const size_t fidx = (size_t)item;
@@ -140,28 +146,44 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
         {
             float A_[BH], B_[BH];
             __syncthreads();                                   // plane free (previous item's map)
-            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
-                constexpr int k1 = decltype(kc)::value;
-                plane[line * BP + 64 * par + k1] = x[FFT_POS<k1, BH>].x;
-            });
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < BH; ++i) {
-                const float E = plane[(2 * i + par) * BP + k1r], O = plane[(2 * i + par) * BP + 64 + k1r];
-                A_[i] = fmaf(cwr, O, E);                       // Re: E.re + wr O.re (- wi O.im later)
-                B_[i] = cwi * O;                               // Im: wi O.re (+ E.im + wr O.im later)
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
+                static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k1 = decltype(kc)::value;
+                    plane[ln * BP + 64 * pr + k1] = x[FFT_POS<k1, BH>].x;
+                });
             }
             __syncthreads();
-            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
-                constexpr int k1 = decltype(kc)::value;
-                plane[line * BP + 64 * par + k1] = x[FFT_POS<k1, BH>].y;
-            });
-            __syncthreads();
+            {
+                const int tq = TPIV_OPQ_T();
+                const int k1r = tq & 63, pr = tq >> 7;
 #pragma unroll
-            for (int i = 0; i < BH; ++i) {
-                const float E = plane[(2 * i + par) * BP + k1r], O = plane[(2 * i + par) * BP + 64 + k1r];
-                x[i].x = fmaf(-cwi, O, A_[i]);
-                x[i].y = fmaf(cwr, O, E + B_[i]);
+                for (int i = 0; i < BH; ++i) {
+                    const float E = plane[(2 * i + pr) * BP + k1r], O = plane[(2 * i + pr) * BP + 64 + k1r];
+                    A_[i] = fmaf(cwr, O, E);                   // Re: E.re + wr O.re (- wi O.im later)
+                    B_[i] = cwi * O;                           // Im: wi O.re (+ E.im + wr O.im later)
+                }
+            }
+            __syncthreads();
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
+                static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k1 = decltype(kc)::value;
+                    plane[ln * BP + 64 * pr + k1] = x[FFT_POS<k1, BH>].y;
+                });
+            }
+            __syncthreads();
+            {
+                const int tq = TPIV_OPQ_T();
+                const int k1r = tq & 63, pr = tq >> 7;
+#pragma unroll
+                for (int i = 0; i < BH; ++i) {
+                    const float E = plane[(2 * i + pr) * BP + k1r], O = plane[(2 * i + pr) * BP + 64 + k1r];
+                    x[i].x = fmaf(-cwi, O, A_[i]);
+                    x[i].y = fmaf(cwr, O, E + B_[i]);
+                }
             }
         }
 
@@ -177,57 +199,89 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                     x[FFT_POS<ky1, BH>] = twmul<ky1, BW, 1>(x[FFT_POS<ky1, BH>]);
                 });
             }
-            const int mk = (BW - line) & (BW - 1);             // mirrored column
             float za[BH], zc[BH];                              // Re Z(k), Re Z(-k)
             __syncthreads();
-            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
-                constexpr int ky1 = decltype(kc)::value;
-                plane[(ky1 + 64 * par) * BP + line] = x[FFT_POS<ky1, BH>].x;
-            });
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
+                static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int ky1 = decltype(kc)::value;
+                    plane[(ky1 + 64 * pr) * BP + ln] = x[FFT_POS<ky1, BH>].x;
+                });
+            }
             __syncthreads();
-            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
-                constexpr int ky1 = decltype(kc)::value;
-                // mirrored row index of ky = ky1 + 64 par:  mky = (128 - ky) mod 128
-                const int mky = (BW - ky1 - 64 * par) & (BW - 1);
-                const int mky1 = mky & 63;
-                const float ms = (mky >> 6) ? -1.f : 1.f;
-                za[ky1] = fmaf(sgn, plane[(64 + ky1) * BP + line], plane[ky1 * BP + line]);
-                zc[ky1] = fmaf(ms, plane[(64 + mky1) * BP + mk], plane[mky1 * BP + mk]);
-            });
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
+                const int mk = (BW - ln) & (BW - 1);           // mirrored column
+                static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int ky1 = decltype(kc)::value;
+                    // mirrored row of ky = ky1 + 64 par:  mky = (128 - ky) mod 128 = mky1 + 64 ma  with
+                    // mky1 = (64 - ky1) mod 64 for either parity, and  ma = par (ky1 = 0),  1 - par (else)
+                    constexpr int mky1 = (64 - ky1) & 63;
+                    const float ms = ky1 == 0 ? sgn : -sgn;
+                    za[ky1] = fmaf(sgn, plane[(64 + ky1) * BP + ln], plane[ky1 * BP + ln]);
+                    zc[ky1] = fmaf(ms, plane[(64 + mky1) * BP + mk], plane[mky1 * BP + mk]);
+                });
+            }
             __syncthreads();
-            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
-                constexpr int ky1 = decltype(kc)::value;
-                plane[(ky1 + 64 * par) * BP + line] = x[FFT_POS<ky1, BH>].y;
-            });
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
+                static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int ky1 = decltype(kc)::value;
+                    plane[(ky1 + 64 * pr) * BP + ln] = x[FFT_POS<ky1, BH>].y;
+                });
+            }
             __syncthreads();
             // with Z(k) = a + ib, Z(-k) = c + id:  re = 2 (a d + b c),  im = (c^2 - a^2) + (d^2 - b^2)
-            static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
-                constexpr int ky1 = decltype(kc)::value;
-                const int mky = (BW - ky1 - 64 * par) & (BW - 1);
-                const int mky1 = mky & 63;
-                const float ms = (mky >> 6) ? -1.f : 1.f;
-                const float b_ = fmaf(sgn, plane[(64 + ky1) * BP + line], plane[ky1 * BP + line]);
-                const float d_ = fmaf(ms, plane[(64 + mky1) * BP + mk], plane[mky1 * BP + mk]);
-                const float a_ = za[ky1], c_ = zc[ky1];
-                x[ky1].x = (a_ * d_ + b_ * c_) * 2.0f;          // P[ky1 + 64 par][k], natural order
-                x[ky1].y = (c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_);
-            });
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
+                const int mk = (BW - ln) & (BW - 1);
+                static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int ky1 = decltype(kc)::value;
+                    constexpr int mky1 = (64 - ky1) & 63;
+                    const float ms = ky1 == 0 ? sgn : -sgn;
+                    const float b_ = fmaf(sgn, plane[(64 + ky1) * BP + ln], plane[ky1 * BP + ln]);
+                    const float d_ = fmaf(ms, plane[(64 + mky1) * BP + mk], plane[mky1 * BP + mk]);
+                    const float a_ = za[ky1], c_ = zc[ky1];
+                    x[ky1].x = (a_ * d_ + b_ * c_) * 2.0f;      // P[ky1 + 64 par][k], natural order
+                    x[ky1].y = (c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_);
+                });
+            }
         }
 
         // ---------------- stage 5: inverse column transform (DIF split over the thread pair)
         {
             __syncthreads();
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
 #pragma unroll
-            for (int q = 0; q < BH; ++q) plane[(q + 64 * par) * BP + line] = x[q].x;
+                for (int q = 0; q < BH; ++q) plane[(q + 64 * pr) * BP + ln] = x[q].x;
+            }
             __syncthreads();
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
 #pragma unroll
-            for (int q = 0; q < BH; ++q) x[q].x = fmaf(sgn, x[q].x, plane[(q + 64 * (1 - par)) * BP + line]);
+                for (int q = 0; q < BH; ++q) x[q].x = fmaf(sgn, x[q].x, plane[(q + 64 * (1 - pr)) * BP + ln]);
+            }
             __syncthreads();
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
 #pragma unroll
-            for (int q = 0; q < BH; ++q) plane[(q + 64 * par) * BP + line] = x[q].y;
+                for (int q = 0; q < BH; ++q) plane[(q + 64 * pr) * BP + ln] = x[q].y;
+            }
             __syncthreads();
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
 #pragma unroll
-            for (int q = 0; q < BH; ++q) x[q].y = fmaf(sgn, x[q].y, plane[(q + 64 * (1 - par)) * BP + line]);
+                for (int q = 0; q < BH; ++q) x[q].y = fmaf(sgn, x[q].y, plane[(q + 64 * (1 - pr)) * BP + ln]);
+            }
             // a = 0: P[ky1] + P[ky1+64];  a = 1: P[ky1] - P[ky1+64] (own is the +64 bin: partner - own), times w^-ky1
             if (par) {
                 static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
@@ -242,23 +296,39 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
         {
             float v_re[BH];
             __syncthreads();
-            static_for<0, BH>([&](auto ic) TPIV_LAMBDA_INLINE {
-                constexpr int i = decltype(ic)::value;
-                plane[(2 * i + par) * BP + line] = x[FFT_POS<i, BH>].x;
-            });
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
+                static_for<0, BH>([&](auto ic) TPIV_LAMBDA_INLINE {
+                    constexpr int i = decltype(ic)::value;
+                    plane[(2 * i + pr) * BP + ln] = x[FFT_POS<i, BH>].x;
+                });
+            }
             __syncthreads();
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
 #pragma unroll
-            for (int q = 0; q < BH; ++q) v_re[q] = fmaf(sgn, plane[line * BP + 64 + q], plane[line * BP + q]);
+                for (int q = 0; q < BH; ++q) v_re[q] = fmaf(sgn, plane[ln * BP + 64 + q], plane[ln * BP + q]);
+            }
             __syncthreads();
-            static_for<0, BH>([&](auto ic) TPIV_LAMBDA_INLINE {
-                constexpr int i = decltype(ic)::value;
-                plane[(2 * i + par) * BP + line] = x[FFT_POS<i, BH>].y;
-            });
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
+                static_for<0, BH>([&](auto ic) TPIV_LAMBDA_INLINE {
+                    constexpr int i = decltype(ic)::value;
+                    plane[(2 * i + pr) * BP + ln] = x[FFT_POS<i, BH>].y;
+                });
+            }
             __syncthreads();
+            {
+                const int tq = TPIV_OPQ_T();
+                const int ln = tq & 127, pr = tq >> 7;
 #pragma unroll
-            for (int q = 0; q < BH; ++q) {
-                x[q].y = fmaf(sgn, plane[line * BP + 64 + q], plane[line * BP + q]);
-                x[q].x = v_re[q];
+                for (int q = 0; q < BH; ++q) {
+                    x[q].y = fmaf(sgn, plane[ln * BP + 64 + q], plane[ln * BP + q]);
+                    x[q].x = v_re[q];
+                }
             }
             if (par) {
                 static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
@@ -271,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
 
         // ---------------- stage 7: peak analysis on the map in LDS (fftshift coordinates)
         {
-            const int ys = (line + 64) & 127;
+            const int ys = ((TPIV_OPQ_T() & 127) + 64) & 127;
             const int KD = BW * BW;
             float c[BH];                                       // c[j]: column xs(j) = ((2j + 64) & 127) + par
             float cmin = 3.4e38f;
