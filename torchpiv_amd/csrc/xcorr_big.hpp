@@ -40,13 +40,17 @@ struct BigShared {
     int redi[8];
 };
 
+// Workgroup barrier for LDS exchanges only: __syncthreads() also waits for vmcnt(0), which would
+// drain the next window's prefetch at every one of the ~30 barriers per window.
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // reduction over the 256 threads of the workgroup; every thread gets the result
 template <typename T, typename OP>
 __device__ __forceinline__ T block_reduce(T v, OP op, T* red, int wave, int lane) {
     v = grp_reduce<64>(v, op);
-    __syncthreads();
+    wg_barrier();
     if (lane == 0) red[wave] = v;
-    __syncthreads();
+    wg_barrier();
     return op(op(red[0], red[1]), op(red[2], red[3]));
 }
 
@@ -76,6 +80,16 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
     const long long lo = (long long)xcd * chunk;
     const long long hi = lo + chunk < items ? lo + chunk : items;
 
+    // rows of the next window are fetched while the peak analysis of the current one runs
+    uint32_t da[32], db[32];
+    auto issue_loads = [&](long long it) TPIV_LAMBDA_INLINE {
+        const int pair_ = (int)(it / N), win_ = (int)(it % N);
+        const int yy0 = (win_ / p.n_cols) * st, xx0 = (win_ % p.n_cols) * st;
+        const size_t off = (size_t)pair_ * HW + (size_t)(yy0 + line_c) * p.W + xx0;
+        load_dwords<32>(p.A + off, da);
+        load_dwords<32>(p.B + off, db);
+    };
+    if (lo + slot < hi) issue_loads(lo + slot);
     for (long long item = lo + slot; item < hi; item += per_xcd) {
         // LDS addresses are rebuilt from an opaque copy of the line index at every plane pass (OPQ): the
         // backend pairs the plane accesses into ds_read2/ds_write2 (8-bit offsets), which needs a base
@@ -91,11 +105,6 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
         cf x[BH];
         float sa, sb;
         {
-            const uint8_t* __restrict__ ra = p.A + (size_t)pair * HW + (size_t)(y0 + line) * p.W + x0;
-            const uint8_t* __restrict__ rb = p.B + (size_t)pair * HW + (size_t)(y0 + line) * p.W + x0;
-            uint32_t da[32], db[32];
-            load_dwords<32>(ra, da);
-            load_dwords<32>(rb, db);
             const uint32_t mask = par ? 0xff00ff00u : 0x00ff00ffu;
             const int sh = 8 * par;
             unsigned ia = 0, ib = 0;
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
         // ---------------- stage 2: transposition + row combine -> x[i] = X[2i + par][k = line]
         {
             float A_[BH], B_[BH];
-            __syncthreads();                                   // plane free (previous item's map)
+            wg_barrier();                                   // plane free (previous item's map)
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                     plane[ln * BP + 64 * pr + k1] = x[FFT_POS<k1, BH>].x;
                 });
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int k1r = tq & 63, pr = tq >> 7;
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                     B_[i] = cwi * O;                           // Im: wi O.re (+ E.im + wr O.im later)
                 }
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                     plane[ln * BP + 64 * pr + k1] = x[FFT_POS<k1, BH>].y;
                 });
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int k1r = tq & 63, pr = tq >> 7;
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                 });
             }
             float za[BH], zc[BH];                              // Re Z(k), Re Z(-k)
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                     plane[(ky1 + 64 * pr) * BP + ln] = x[FFT_POS<ky1, BH>].x;
                 });
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                     zc[ky1] = fmaf(ms, plane[(64 + mky1) * BP + mk], plane[mky1 * BP + mk]);
                 });
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                     plane[(ky1 + 64 * pr) * BP + ln] = x[FFT_POS<ky1, BH>].y;
                 });
             }
-            __syncthreads();
+            wg_barrier();
             // with Z(k) = a + ib, Z(-k) = c + id:  re = 2 (a d + b c),  im = (c^2 - a^2) + (d^2 - b^2)
             {
                 const int tq = TPIV_OPQ_T();
@@ -254,28 +263,28 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
 
         // ---------------- stage 5: inverse column transform (DIF split over the thread pair)
         {
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
 #pragma unroll
                 for (int q = 0; q < BH; ++q) plane[(q + 64 * pr) * BP + ln] = x[q].x;
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
 #pragma unroll
                 for (int q = 0; q < BH; ++q) x[q].x = fmaf(sgn, x[q].x, plane[(q + 64 * (1 - pr)) * BP + ln]);
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
 #pragma unroll
                 for (int q = 0; q < BH; ++q) plane[(q + 64 * pr) * BP + ln] = x[q].y;
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
         // ---------------- stage 6: transposition + inverse row transform (DIF split over k)
         {
             float v_re[BH];
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
@@ -304,14 +313,14 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                     plane[(2 * i + pr) * BP + ln] = x[FFT_POS<i, BH>].x;
                 });
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
 #pragma unroll
                 for (int q = 0; q < BH; ++q) v_re[q] = fmaf(sgn, plane[ln * BP + 64 + q], plane[ln * BP + q]);
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                     plane[(2 * i + pr) * BP + ln] = x[FFT_POS<i, BH>].y;
                 });
             }
-            __syncthreads();
+            wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
                 const int ln = tq & 127, pr = tq >> 7;
@@ -350,6 +359,8 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                 c[j] = x[FFT_POS<j, BH>].x;
                 cmin = fminf(cmin, c[j]);
             });
+            // prefetch (the last iteration re-loads its own window: no branch around the loads)
+            issue_loads(item + per_xcd < hi ? item + per_xcd : item);
             auto fmin_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fminf(a, b); };
             auto fmax_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); };
             auto imin_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
