@@ -7,8 +7,8 @@ Metric (BASELINE.json): image-pairs/sec at 4 MP, wind=64 ov=32, 2-pass CWS x2.0.
 Workload (BASELINE.json configs[1]): synthetic 2048x2048 pairs, batch = 256 pairs resident in
 HBM per GPU.  A "step" = one pass of the whole hot path (pass 1 + predictor + CWS pass 2, all
 kernels of tpiv_plan_run) over that batch.  N > 1: one process per GPU (torchrun), every rank
-owns its own batch (weak scaling, no data-path collective), and ONE RCCL all-gather of the
-(u, v) fields of the last step closes the timed region.
+owns its own batch (weak scaling, no data-path collective), and ONE RCCL gather of the
+(u, v) fields of the last step onto rank 0 closes the timed region.
 
 Rank 0 prints one JSON line with `roofline` (dominant kernel, HIP-event timed on the launch
 stream during the timed steps) and, at N = 1, `cpu_baseline` (the CPU oracle on host cores).
@@ -190,7 +190,7 @@ def main():
             "config": {"workload": f"synthetic {H}x{W} pair batch={args.batch} per GPU, wind={ws} overlap={ov}, "
                                    f"{args.passes}-pass {args.mode} x2.0 (BASELINE.json configs[1])",
                        "batch_per_gpu": args.batch, "distinct_pairs": distinct,
-                       "parallelism": f"pair-sharded x{world}, one RCCL all-gather of (u,v) at the end"},
+                       "parallelism": f"pair-sharded x{world}, one RCCL gather of (u,v) onto rank 0 at the end"},
             "roofline": {
                 "bound": "hbm",
                 "kernel": f"xcorr_kernel<{g_ws}, {'PASS1' if p_idx == 0 else args.mode}> ({dom})",

@@ -51,8 +51,9 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
     ids    int64 [n_local]            dataset index of every field this rank produced
     fields       [n_local, C, R, S]   e.g. C = 2 for (u, v); same dtype/shape tail on all ranks
     Returns (ids_all, fields_all) sorted by dataset index on `dst`, (None, None) elsewhere.
-    One count all-gather (8 bytes per rank) + one padded payload all-gather: on xGMI's full mesh
-    every rank's shard goes out on all seven links at once instead of hopping round a ring.
+    One count all-gather (8 bytes per rank) + one padded payload gather onto `dst`: on xGMI's full
+    mesh the seven shards arrive over seven different links at once, and no other rank has to hold
+    the whole result (an all-gather would move and store world x more).
     """
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         order = torch.argsort(ids)
@@ -73,10 +74,16 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
     pad_i = torch.full((n_max,), -1, dtype=torch.int64, device=dev)
     pad_f[: ids.numel()] = fields
     pad_i[: ids.numel()] = ids.to(dev)
-    all_f = torch.empty((world * n_max,) + tail, dtype=fields.dtype, device=dev)
-    all_i = torch.empty(world * n_max, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_f, pad_f, group=group)
-    dist.all_gather_into_tensor(all_i, pad_i, group=group)
+    if rank == dst:
+        all_f = torch.empty((world * n_max,) + tail, dtype=fields.dtype, device=dev)
+        all_i = torch.empty(world * n_max, dtype=torch.int64, device=dev)
+        lst_f = list(all_f.view((world, n_max) + tail).unbind(0))
+        lst_i = list(all_i.view(world, n_max).unbind(0))
+    else:
+        lst_f = lst_i = None
+    dst_global = dist.get_global_rank(group, dst) if group is not None else dst
+    dist.gather(pad_f, gather_list=lst_f, dst=dst_global, group=group)
+    dist.gather(pad_i, gather_list=lst_i, dst=dst_global, group=group)
     if rank != dst:
         return None, None
     keep = all_i >= 0
