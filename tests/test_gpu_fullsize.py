@@ -37,6 +37,46 @@ def test_cfg2_against_oracle(pair, mode):
     plan.close()
 
 
+def test_cfg4_large_windows_against_oracle(pair):
+    """configs[4] geometry (2048^2, 128/64 -> 64/32, 2-pass CWS): pass 1 runs the two-threads-per-line
+    128x128 kernel.  Pass 1: every one of the 961 vectors within 1e-3 px and the same validity; final
+    field: >= 99 % within 1e-3 px with the same validity."""
+    from torchpiv_amd import engine
+    a, b = pair
+    plan = engine.Plan(2048, 2048, 128, 64, n_pass=2, mode="CWS", max_batch=1)
+    u, v, inv = plan.run(a, b)
+    an, bn = a.cpu().numpy(), b.cpu().numpy()
+    ou, ov, x, y, oval = O.pass1(an, bn, 128, 64, validate=True)
+    p1u, p1v, p1i = plan.pass_fields(0, 1)
+    e1 = max(np.abs(p1u[0].cpu().numpy() - ou).max(), np.abs(p1v[0].cpu().numpy() - ov).max())
+    print(f"cfg4 pass 1 (128x128): max err {e1:.2e} px over {ou.size} windows")
+    assert ou.shape == (31, 31) and e1 < 1e-3 and np.array_equal(p1i[0].cpu().numpy().astype(bool), oval)
+    ou, ov, x, y, oval = O.ITER["CWS"]((2048, 2048), 64, 32)(an, bn, x, y, ou, ov, oval)
+    err = np.maximum(np.abs(u[0].cpu().numpy() - ou), np.abs(v[0].cpu().numpy() - ov))
+    same = inv[0].cpu().numpy().astype(bool) == oval
+    frac = float(((err < 1e-3) & same).mean())
+    print(f"cfg4 final: {frac:.5f} within 1e-3 px, median err {np.median(err):.2e}")
+    assert u.shape[1:] == (63, 63) and frac >= 0.99
+    plan.close()
+
+
+def test_large_windows_invariances():
+    """128x128 pass 1: bit-identical fields wherever a pair sits in a batch, and cropping both frames
+    by one grid step (64 px) moves the field by exactly one cell."""
+    from torchpiv_amd import engine, synth
+    a, b = synth.make_pair(1024 + 64, 1024 + 64, 78, kind="shear", noise=2.0, device="cuda")
+    a2, b2 = synth.make_pair(1024 + 64, 1024 + 64, 79, kind="vortex", noise=2.0, device="cuda")
+    A = torch.stack([a, a2, a, a2, a2])
+    B = torch.stack([b, b2, b, b2, b2])
+    u, v, inv = engine.pass1(A, B, 128, 64)
+    assert torch.equal(u[0], u[2]) and torch.equal(v[0], v[2]) and torch.equal(inv[0], inv[2])
+    assert torch.equal(u[1], u[3]) and torch.equal(u[1], u[4]) and torch.equal(v[3], v[4])
+    u0, v0, i0 = engine.pass1(a[:1024, :1024].contiguous(), b[:1024, :1024].contiguous(), 128, 64)
+    u1, v1, i1 = engine.pass1(a[64:, 64:].contiguous(), b[64:, 64:].contiguous(), 128, 64)
+    assert torch.equal(u0[0, 1:, 1:], u1[0, :-1, :-1]) and torch.equal(v0[0, 1:, 1:], v1[0, :-1, :-1])
+    assert torch.equal(i0[0, 1:, 1:], i1[0, :-1, :-1])
+
+
 def test_batch_position_invariance(pair):
     """A pair gives bit-identical fields wherever it sits in a batch (windows are independent)."""
     from torchpiv_amd import engine, synth

@@ -43,17 +43,6 @@ struct TileGeo {
     static constexpr int NDW = WS / 4;                  // dwords per window row
 };
 
-struct ArgMaxT {
-    float v;
-    int idx;
-};
-
-__device__ __forceinline__ ArgMaxT better_t(ArgMaxT a, ArgMaxT b) {
-    // larger value wins; equal values: smaller flat index (torch.argmax returns the first)
-    const bool takeb = (b.v > a.v) || (b.v == a.v && b.idx < a.idx);
-    return takeb ? b : a;
-}
-
 // ---- reductions over the WS lanes of one window, all lanes receive the result.
 // Cross-lane steps stay in the VALU (DPP quad/row permutes, v_permlane16/32_swap): the usual
 // __shfl_xor goes through ds_bpermute, i.e. one LDS round trip per step, and five dependent
@@ -131,18 +120,6 @@ __device__ __forceinline__ float grp_sum(float v) {
 template <int WS>
 __device__ __forceinline__ float grp_min(float v) {
     return grp_reduce<WS>(v, [](float a, float b) TPIV_LAMBDA_INLINE { return fminf(a, b); });
-}
-
-template <int WS>
-__device__ __forceinline__ ArgMaxT grp_argmax(ArgMaxT a) {
-    return grp_reduce<WS>(a, [](ArgMaxT p, ArgMaxT q) TPIV_LAMBDA_INLINE { return better_t(p, q); });
-}
-
-__device__ __forceinline__ double nan_to_num_t(double x) {      // torch.nan_to_num_ defaults, B:418-419
-    if (x != x) return 0.0;
-    if (x > 1.7976931348623157e308) return 1.7976931348623157e308;
-    if (x < -1.7976931348623157e308) return -1.7976931348623157e308;
-    return x;
 }
 
 __device__ __forceinline__ float fetch_clamped_t(const uint8_t* __restrict__ f, long long q, int HW) {
