@@ -162,13 +162,25 @@ def main():
         t_dom = timing[dom] * 1e-3
         achieved = b_launch / t_dom / 1e9
         traffic = None
+        valu_issue = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         # the PMC passes were taken on the default workload only
         default_cfg = (args.batch, args.size, args.ws, args.passes, args.mode) == (256, 2048, 64, 2, "CWS")
         if default_cfg and os.path.exists(tpath):
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get(dom)
+                    pmc = json.load(f)
+                traffic = pmc.get(dom)
+                insts = pmc.get(dom + "_valu_insts")
+                if insts:
+                    # wave-level VALU instructions per launch (SQ_INSTS_VALU, committed PMC pass) over the
+                    # live kernel time, against one wave-instruction per SIMD every 2 cycles at 2.4 GHz
+                    peak = 256 * 4 * 2.4 / 2.0              # G wave-instructions/s
+                    valu_issue = {"insts_per_launch": insts, "achieved": insts / t_dom / 1e9, "peak": peak,
+                                  "unit": "G wave-instr/s", "frac": insts / t_dom / 1e9 / peak,
+                                  "practical_ceiling": 900.0,
+                                  "note": "binding resource; ceiling measured with the FFT codelets alone "
+                                          "(tools/micro/fft_issue.hip)"}
             except Exception:
                 traffic = None
         b_pair = sum(alg_bytes(H, W, g[2] * g[3], i == 0) for i, g in enumerate(plan.geometry))
@@ -203,7 +215,9 @@ def main():
                 "launch_ms": timing[dom],
                 "launches_timed": n_runs,
                 "valu_frac": f_launch / t_dom / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                "note": "the path is VALU/LDS-bound (SURVEY.md 8d): valu_frac is the binding fraction",
+                "valu_issue": valu_issue,
+                "note": "the path is VALU-issue-bound (SURVEY.md 8d, DESIGN.md 5): valu_issue.frac is the binding "
+                        "fraction, valu_frac the same in SURVEY 8d flops / 157.3 TFLOP/s",
             },
             "kernel_ms": timing,
             "whole_path": {"alg_bytes_per_pair": b_pair, "hbm_frac": b_pair * value / world / 1e9 / HBM_PEAK_GBS,
