@@ -156,6 +156,19 @@ __device__ __forceinline__ float bilerp_ref(float f11, float f21, float f12, flo
     return degenerate ? f11 : r;          // B:170, B:193: either coordinate integral -> f(floor y, floor x)
 }
 
+// The same with the quirk as a per-lane bit mask (0 or ~0): one v_bfi_b32 instead of a select through
+// an SGPR lane mask (a select costs two plain instructions on MI355X).
+__device__ __forceinline__ float bilerp_ref_m(float f11, float f21, float f12, float f22, float wx_up,
+                                              float wx_dn, float wy_up, float wy_dn, unsigned degenerate_mask) {
+#pragma clang fp contract(off)
+    float r = (f11 * wx_up) * wy_up;
+    r = r + (f21 * wx_dn) * wy_up;
+    r = r + (f12 * wx_up) * wy_dn;
+    r = r + (f22 * wx_dn) * wy_dn;
+    const unsigned bits = (degenerate_mask & __float_as_uint(f11)) | (~degenerate_mask & __float_as_uint(r));
+    return __uint_as_float(bits);
+}
+
 // ---- diagnostic build only: in-kernel phase stamps (s_memtime), summed per wavefront in scalar
 // registers and added to p.stamps at the end.  Compiled out of the production library.
 #ifdef TPIV_STAMPS
@@ -600,15 +613,17 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                 wbuf[r] = make_float4(uxa_f - nxa, nxa - dxa_f, uxb_f - nxb, nxb - dxb_f);
                 wave_sync();
             }
+            unsigned dmask_a = c.ydeg_a ? ~0u : 0u, dmask_b = c.ydeg_b ? ~0u : 0u;
+            asm volatile("" : "+v"(dmask_a), "+v"(dmask_b));       // keep them masks (not re-derived selects)
             static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int k = decltype(kc)::value;
                 // keep the scheduler from hoisting all WS weight reads (4 VGPRs each) to the top
                 if constexpr (k % 8 == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
                 const float4 wx = wbuf[k];
-                x[k].x = bilerp_ref(byte_f<k, NB>(raw.a0), byte_f<k + 1, NB>(raw.a0), byte_f<k, NB>(raw.a1),
-                                    byte_f<k + 1, NB>(raw.a1), wx.x, wx.y, c.wya_up, c.wya_dn, c.ydeg_a != 0);
-                x[k].y = bilerp_ref(byte_f<k, NB>(raw.b0), byte_f<k + 1, NB>(raw.b0), byte_f<k, NB>(raw.b1),
-                                    byte_f<k + 1, NB>(raw.b1), wx.z, wx.w, c.wyb_up, c.wyb_dn, c.ydeg_b != 0);
+                x[k].x = bilerp_ref_m(byte_f<k, NB>(raw.a0), byte_f<k + 1, NB>(raw.a0), byte_f<k, NB>(raw.a1),
+                                      byte_f<k + 1, NB>(raw.a1), wx.x, wx.y, c.wya_up, c.wya_dn, dmask_a);
+                x[k].y = bilerp_ref_m(byte_f<k, NB>(raw.b0), byte_f<k + 1, NB>(raw.b0), byte_f<k, NB>(raw.b1),
+                                      byte_f<k + 1, NB>(raw.b1), wx.z, wx.w, c.wyb_up, c.wyb_dn, dmask_b);
             });
             wave_sync();
         } else {          // generic per-pixel gather with the flat-index clamp (rare: rolled loops
