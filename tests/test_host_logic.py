@@ -154,8 +154,19 @@ template<int N, int DIR> void run() {
   for (int k = 0; k < N; ++k) printf(" %.9g %.9g", x[fft_pos(k,N)].x, x[fft_pos(k,N)].y);
   printf("\n");
 }
+template<int N, int DIR> void runr() {      // twiddles from a TwRegs table instead of literals
+  cf x[N];
+  for (int i = 0; i < N; ++i) { x[i].x = (float)((i*37+11)%101) - 50.f; x[i].y = (float)((i*53+7)%89) - 44.f; }
+  TwRegs<N> tw; tw.init();
+  fft_inreg<N, DIR>(x, tw);
+  printf("%d %d", N, DIR);
+  for (int k = 0; k < N; ++k) printf(" %.9g %.9g", x[fft_pos(k,N)].x, x[fft_pos(k,N)].y);
+  printf("\n");
+}
 int main(){ run<8,1>(); run<16,1>(); run<32,1>(); run<64,1>(); run<128,1>();
-            run<8,-1>(); run<16,-1>(); run<32,-1>(); run<64,-1>(); run<128,-1>(); }
+            run<8,-1>(); run<16,-1>(); run<32,-1>(); run<64,-1>(); run<128,-1>();
+            runr<8,1>(); runr<16,1>(); runr<32,1>(); runr<64,1>(); runr<128,1>();
+            runr<8,-1>(); runr<16,-1>(); runr<32,-1>(); runr<64,-1>(); runr<128,-1>(); }
 ''')
     exe = tmp_path / "t"
     subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "torchpiv_amd", "csrc"), str(src),

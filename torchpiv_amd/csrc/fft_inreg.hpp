@@ -73,9 +73,62 @@ TPIV_HD cf twmul(cf a) {
     }
 }
 
-template <int N, int OFF, int DIR, int TOTAL>
+// ---- where the twiddle constants live ------------------------------------------------------------
+// TwLiteral: as 32-bit literals inside the instructions (8-byte encodings; a constant used by several
+// instructions is moved to an SGPR by the compiler, and an SGPR operand halves the issue rate on
+// MI355X).  TwRegs<NTOP>: the N/4 - 1 non-trivial first-quadrant magnitudes cos(2 pi k / NTOP) and
+// their negatives in VGPRs, so that every twiddle product is a plain 4-byte v_mul_f32 / v_fmac_f32.
+struct TwLiteral {};
+
+template <int NTOP>
+struct TwRegs {
+    static constexpr int STEP = 128 / NTOP;             // stride in the 128-entry table
+    static constexpr int NV = NTOP / 4 - 1;             // table entries STEP, 2 STEP, ..., 32 - STEP
+    float pos[NV > 0 ? NV : 1], neg[NV > 0 ? NV : 1];
+    TPIV_HD void init() {
+        static_for<0, NV>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int i = decltype(ic)::value;
+            pos[i] = TW_COS[(i + 1) * STEP];
+            neg[i] = -TW_COS[(i + 1) * STEP];
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(pos[i]), "+v"(neg[i]));      // opaque: stays a register operand
+#endif
+        });
+    }
+    template <int R, bool NEG>
+    TPIV_HD float m() const {                            // (+-) cos(2 pi R / 128), R a multiple of STEP in 1..31
+        static_assert(R % STEP == 0 && R > 0 && R < 32, "not a twiddle of this transform");
+        return NEG ? neg[R / STEP - 1] : pos[R / STEP - 1];
+    }
+};
+
+template <int K, int N, int DIR, typename TW>
+TPIV_HD cf twmul_t(cf a, const TW& tw) {
+    constexpr int idx = ((K % N) * (128 / N)) % 128;
+    if constexpr (std::is_same<TW, TwLiteral>::value || idx % 32 == 0) {
+        return twmul<K, N, DIR>(a);
+    } else {
+        // cos = (+-) M[rc], sin = (+-) M[rs] with M[r] = cos(2 pi r / 128) = sin(2 pi (32 - r) / 128)
+        constexpr int q = idx / 32, r = idx % 32;
+        constexpr int rc = (q % 2 == 0) ? r : 32 - r;
+        constexpr int rs = (q % 2 == 0) ? 32 - r : r;
+        constexpr bool cneg = (q == 1 || q == 2);
+        constexpr bool sneg0 = (q == 2 || q == 3);
+        constexpr bool sneg = DIR > 0 ? !sneg0 : sneg0;   // multiply by exp(-DIR * i * theta)
+        const float C = tw.template m<rc, cneg>();
+        const float S = tw.template m<rs, sneg>();
+        const float nS = tw.template m<rs, !sneg>();
+#if defined(__HIP_DEVICE_COMPILE__)
+        return cf{__builtin_fmaf(a.y, nS, a.x * C), __builtin_fmaf(a.y, C, a.x * S)};
+#else
+        return cf{a.x * C + a.y * nS, a.x * S + a.y * C};
+#endif
+    }
+}
+
+template <int N, int OFF, int DIR, int TOTAL, typename TW = TwLiteral>
 struct FFTStage {
-    static TPIV_HD void run(cf (&x)[TOTAL]) {
+    static TPIV_HD void run(cf (&x)[TOTAL], const TW& tw = TW{}) {
         if constexpr (N == 2) {
             cf a = x[OFF], b = x[OFF + 1];
             x[OFF] = cadd(a, b);
@@ -85,10 +138,10 @@ struct FFTStage {
                 constexpr int j = decltype(jc)::value;
                 cf a = x[OFF + j], b = x[OFF + j + N / 2];
                 x[OFF + j] = cadd(a, b);
-                x[OFF + j + N / 2] = twmul<j, N, DIR>(csub(a, b));
+                x[OFF + j + N / 2] = twmul_t<j, N, DIR>(csub(a, b), tw);
             });
-            FFTStage<N / 2, OFF, DIR, TOTAL>::run(x);
-            FFTStage<N / 2, OFF + N / 2, DIR, TOTAL>::run(x);
+            FFTStage<N / 2, OFF, DIR, TOTAL, TW>::run(x, tw);
+            FFTStage<N / 2, OFF + N / 2, DIR, TOTAL, TW>::run(x, tw);
         } else if constexpr (N >= 4) {
             static_for<0, N / 4>([&](auto jc) TPIV_LAMBDA_INLINE {
                 constexpr int j = decltype(jc)::value;
@@ -98,15 +151,15 @@ struct FFTStage {
                 // forward: t3 = -i (b - d); inverse: t3 = +i (b - d)
                 cf t3 = DIR > 0 ? cf{bd.y, -bd.x} : cf{-bd.y, bd.x};
                 x[OFF + j] = cadd(t0, t2);
-                x[OFF + j + N / 4] = twmul<j, N, DIR>(cadd(t1, t3));
-                x[OFF + j + N / 2] = twmul<2 * j, N, DIR>(csub(t0, t2));
-                x[OFF + j + 3 * N / 4] = twmul<3 * j, N, DIR>(csub(t1, t3));
+                x[OFF + j + N / 4] = twmul_t<j, N, DIR>(cadd(t1, t3), tw);
+                x[OFF + j + N / 2] = twmul_t<2 * j, N, DIR>(csub(t0, t2), tw);
+                x[OFF + j + 3 * N / 4] = twmul_t<3 * j, N, DIR>(csub(t1, t3), tw);
             });
             if constexpr (N > 4) {
-                FFTStage<N / 4, OFF, DIR, TOTAL>::run(x);
-                FFTStage<N / 4, OFF + N / 4, DIR, TOTAL>::run(x);
-                FFTStage<N / 4, OFF + N / 2, DIR, TOTAL>::run(x);
-                FFTStage<N / 4, OFF + 3 * N / 4, DIR, TOTAL>::run(x);
+                FFTStage<N / 4, OFF, DIR, TOTAL, TW>::run(x, tw);
+                FFTStage<N / 4, OFF + N / 4, DIR, TOTAL, TW>::run(x, tw);
+                FFTStage<N / 4, OFF + N / 2, DIR, TOTAL, TW>::run(x, tw);
+                FFTStage<N / 4, OFF + 3 * N / 4, DIR, TOTAL, TW>::run(x, tw);
             }
         }
     }
@@ -116,6 +169,11 @@ struct FFTStage {
 template <int N, int DIR>
 TPIV_HD void fft_inreg(cf (&x)[N]) {
     FFTStage<N, 0, DIR, N>::run(x);
+}
+// the same with the twiddle constants taken from `tw` (TwRegs<N>, or TwLiteral{} for the form above)
+template <int N, int DIR, typename TW>
+TPIV_HD void fft_inreg(cf (&x)[N], const TW& tw) {
+    FFTStage<N, 0, DIR, N, TW>::run(x, tw);
 }
 
 // (Not used by the tile kernels at present: measured there it trades ~3 % fewer VALU instructions for

@@ -795,6 +795,12 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
                   "slow-path row buffer (shifted passes) must fit the tile LDS");
     __shared__ float tile[G::LDS_FLOATS];
 
+    // 32x32 and 16x16 have registers to spare: their twiddle constants live in VGPRs (plain 4-byte
+    // VOP2 multiplies instead of 8-byte literal forms and half-rate SGPR operands)
+    using TW = std::conditional_t<(WS == 32 || WS == 16), TwRegs<WS>, TwLiteral>;
+    TW tw;
+    if constexpr (!std::is_same<TW, TwLiteral>::value) tw.init();
+
     const int N = p.n_rows * p.n_cols;
     const int groups = (N + G::WPW - 1) / G::WPW;
     const int items = p.batch * groups;               // < 2^31 (checked by the launcher)
@@ -950,11 +956,11 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
 
         TPIV_STAMP(2);      // mean reduction + normalisation
         // ---- forward 2-D transform of a + i*b: rows in registers, transpose, columns in registers
-        fft_inreg<WS, 1>(x);                              // over x; bin kx at x[FFT_POS<kx>]
+        fft_inreg<WS, 1>(x, tw);                          // over x; bin kx at x[FFT_POS<kx>]
         TPIV_STAMP(3);      // forward row FFT
         transpose_tile<WS, true, PLANAR>(x, tile, fresh_lane());  // lane = kx, x[y] natural
         TPIV_STAMP(4);      // transposition 1
-        fft_inreg<WS, 1>(x);                              // over y; Z(ky, kx = lane) at x[FFT_POS<ky>]
+        fft_inreg<WS, 1>(x, tw);                          // over y; Z(ky, kx = lane) at x[FFT_POS<ky>]
         TPIV_STAMP(5);      // forward column FFT
 
         // ---- cross-spectrum.  A = (Z(k) + conj Z(-k))/2, B = (Z(k) - conj Z(-k))/(2i),
@@ -1003,11 +1009,11 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             constexpr int ky = decltype(kc)::value;
             t[ky] = x[FFT_POS<ky, WS>];
         });
-        fft_inreg<WS, -1>(t);                             // over ky; row y at t[FFT_POS<y>]
+        fft_inreg<WS, -1>(t, tw);                         // over ky; row y at t[FFT_POS<y>]
         TPIV_STAMP(7);      // inverse column FFT
         transpose_tile<WS, true, PLANAR>(t, tile, fresh_lane());  // lane = y, t[kx] natural
         TPIV_STAMP(8);      // transposition 2
-        fft_inreg<WS, -1>(t);                             // over kx; corr(y = lane, x) at t[FFT_POS<x>].x
+        fft_inreg<WS, -1>(t, tw);                         // over kx; corr(y = lane, x) at t[FFT_POS<x>].x
         wave_sync();                                  // tile reads done: it becomes the map
         TPIV_STAMP(9);      // inverse row FFT
 
