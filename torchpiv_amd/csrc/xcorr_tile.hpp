@@ -8,16 +8,17 @@
 //
 // Mapping (one 64-lane wavefront = one workgroup = 64/WS windows):
 //   * lane = one image ROW of one window.  The row (WS bytes per frame) is fetched with
-//     16-byte loads straight into VGPRs; overlapping windows re-read through L2 (the item order
-//     keeps neighbouring windows on one XCD).  Both frames are packed as a + i*b.
+//     16-byte loads straight into VGPRs; overlapping windows re-read through L2 (a per-XCD work
+//     queue keeps the wavefronts of an XCD on adjacent windows).  Both frames are packed as a + i*b.
 //   * all 1-D FFTs (WS points) run per lane, entirely in registers (fft_inreg.hpp).
 //   * LDS is used only to transpose between the row and the column transform, in 32x33 (or
-//     WSx(WS+1)) complex tiles; a 64x64 tile is transposed as four 32x32 blocks after a
-//     v_permlane32_swap of the off-diagonal blocks, so a wavefront needs 16.9 KB of LDS
-//     instead of 33 KB and two wavefronts fit per SIMD.
+//     WSx(WS+1)) tiles; a 64x64 tile is transposed as four 32x32 blocks after a
+//     v_permlane32_swap of the off-diagonal blocks.  Kernels at three wavefronts per SIMD move one
+//     float plane at a time (8.4 KB per wavefront), the others complex elements (16.9 KB).
 //   * the k <-> -k partner of the packed spectrum is fetched with ds_bpermute (no LDS memory).
-//   * peak search / validation reduce with wavefront shuffles; the map is parked in LDS for
-//     the five neighbour reads of the sub-pixel fit.
+//   * peak search: plain max scans per lane, DPP / permlane reductions, one LDS row lookup for the
+//     arg-max position, sign-bit exclusion for the second peak (compares and selects cost twice a
+//     plain fp32 instruction on MI355X); an 8-float record per window goes to finalize_kernel.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
