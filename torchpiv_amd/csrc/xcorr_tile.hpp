@@ -543,6 +543,10 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
     const uint8_t* __restrict__ fa = p.A + (size_t)g.pair * HW;
     const uint8_t* __restrict__ fb = p.B + (size_t)g.pair * HW;
     float* rowbuf = lds + lane * (WS + 1);     // slow paths only
+    // The rare per-pixel paths must not set the register budget of the small tiles (unrolled, their
+    // gathers keep a 64-bit address per load in flight: 135 VGPRs for an 8x8 kernel whose fast path
+    // needs about 60), so they are fully rolled there.
+    constexpr int UNR_DWS = WS <= 16 ? 1 : 4, UNR_CWS = WS <= 16 ? 1 : 2;
     if constexpr (MODE == MODE_PASS1) {
         unsigned ia = 0, ib = 0;
 #pragma unroll
@@ -571,11 +575,11 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         } else {          // a row touches the first/last pixel of the frame: per-pixel clamp.
             // Rare: kept as a rolled loop that parks the row in LDS (no code blow-up).
             wave_sync();
-#pragma unroll 4
+#pragma unroll UNR_DWS
             for (int k = 0; k < WS; ++k) rowbuf[k] = fetch_clamped_t(fa, raw.qa + k, HW);
 #pragma unroll
             for (int k = 0; k < WS; ++k) x[k].x = rowbuf[k];
-#pragma unroll 4
+#pragma unroll UNR_DWS
             for (int k = 0; k < WS; ++k) rowbuf[k] = fetch_clamped_t(fb, raw.qb + k, HW);
 #pragma unroll
             for (int k = 0; k < WS; ++k) x[k].y = rowbuf[k];
@@ -630,7 +634,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         } else {          // generic per-pixel gather with the flat-index clamp (rare: rolled loops
                           // that park the row in LDS)
             wave_sync();
-#pragma unroll 2
+#pragma unroll UNR_CWS
             for (int k = 0; k < WS; ++k) {
                 const float nxa = (gx0f + (float)k) - vx;
                 const float uxa_f = ceilf(nxa), dxa_f = floorf(nxa);
@@ -643,7 +647,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
             }
 #pragma unroll
             for (int k = 0; k < WS; ++k) x[k].x = rowbuf[k];
-#pragma unroll 2
+#pragma unroll UNR_CWS
             for (int k = 0; k < WS; ++k) {
                 const float nxb = (gx0f + (float)k) + vx;
                 const float uxb_f = ceilf(nxb), dxb_f = floorf(nxb);
@@ -1108,12 +1112,14 @@ static hipError_t launch_tile(const PassParams& p_in, int n_cu, hipStream_t stre
     // 32x32 DWS pass 33.6 -> 27.4 us/pair, 32x32 CWS pass 48.0 -> 43.9, 16x16 CWS pass (4096^2)
     // 213.9 -> 189.6, 64x64 pass 1 32.3 -> 29.1; four (possible for 32x32 pass 1 / DWS and 16x16 since
     // the peak search stopped using compare/select chains) gains nothing more: the VALU is saturated.
-    // 8x8 stays at two.  TPIV_OCC=2|3|4 overrides for experiments.
+    // 16x16 is built for four (its CWS variant needs 129 VGPRs unconstrained, one more than four
+    // wavefronts allow: 165 -> 155 us/pair at 4096^2); 8x8 is built for two but small enough (107
+    // VGPRs) to run four.  TPIV_OCC=2|3|4 overrides for experiments.
     static const int occ_env = [] {
         const char* e = getenv("TPIV_OCC");
         return e ? atoi(e) : 0;
     }();
-    const int occ = occ_env ? occ_env : ((WS == 32 || WS == 16 || (WS == 64 && MODE == MODE_PASS1)) ? 3 : 2);
+    const int occ = occ_env ? occ_env : (WS == 16 ? 4 : ((WS == 32 || (WS == 64 && MODE == MODE_PASS1)) ? 3 : 2));
     if constexpr (WS == 64 && MODE == MODE_PASS1) {
         // 64x64 pass 1 (no shifted-window slow paths, so the small planar LDS layout is enough)
         if (occ == 3) {
