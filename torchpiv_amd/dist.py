@@ -82,8 +82,18 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
     else:
         lst_f = lst_i = None
     dst_global = dist.get_global_rank(group, dst) if group is not None else dst
-    dist.gather(pad_f, gather_list=lst_f, dst=dst_global, group=group)
-    dist.gather(pad_i, gather_list=lst_i, dst=dst_global, group=group)
+    try:
+        dist.gather(pad_f, gather_list=lst_f, dst=dst_global, group=group)
+        dist.gather(pad_i, gather_list=lst_i, dst=dst_global, group=group)
+    except (NotImplementedError, RuntimeError) as exc:
+        # a backend without gather rejects the call on every rank before any communication:
+        # fall back to the all-gather every backend has (world x the traffic, same result on dst)
+        if "gather" not in str(exc).lower() and "support" not in str(exc).lower():
+            raise
+        all_f = torch.empty((world * n_max,) + tail, dtype=fields.dtype, device=dev)
+        all_i = torch.empty(world * n_max, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_f, pad_f, group=group)
+        dist.all_gather_into_tensor(all_i, pad_i, group=group)
     if rank != dst:
         return None, None
     keep = all_i >= 0
