@@ -235,9 +235,9 @@ struct tpiv_plan {
     std::vector<uint8_t*> val;
     std::vector<double*> Ay, Ax;         // per pass p >= 1: dense operators from pass p-1 to p (debug)
     // banded form used by tpiv_plan_run (piv_kernels.h: BandedPredictParams)
-    std::vector<double*> Wy, AxT;
+    std::vector<double*> Wy, AxT, AxG;
     std::vector<int*> k0y, startx;
-    std::vector<int> ku, bwx;
+    std::vector<int> ku, bwx, bwg, seg_len;
     double *u0 = nullptr, *v0 = nullptr, *u2 = nullptr, *v2 = nullptr, *T = nullptr;
     float* peak_raw = nullptr;           // [max_batch, max N_p, 8] hand-off tile kernel -> finalize
     std::vector<void*> allocs;
@@ -325,6 +325,19 @@ int build_banded(tpiv_plan* pl, int p, int nrc, int ncc, int nrf, int ncf, const
         const int f1 = f0 + 255 < ncf ? f0 + 255 : ncf - 1;
         if (sx[f1] + bwx - sx[f0] > 512) return fail(TPIV_EUNSUPPORTED, "predictor band stretch exceeds the LDS stage");
     }
+    // group-aligned copy: the 4 fine columns of a group read the SAME staged values (base startx[4g]),
+    // each with its weights shifted by its own start offset (zero-padded): one thread then forms 4
+    // outputs from one LDS read per tap (the per-column form was LDS-bandwidth-bound)
+    const int ncf4 = (ncf + 3) / 4 * 4;
+    int dmax = 0;
+    for (int f = 0; f < ncf; ++f) dmax = std::max(dmax, sx[f] - sx[f / 4 * 4]);
+    if (dmax > 8) return fail(TPIV_EUNSUPPORTED, "predictor column groups span more than 8 coarse columns");
+    const int bwg = bwx + dmax;
+    std::vector<double> axG((size_t)bwg * ncf4, 0.0);
+    for (int f = 0; f < ncf; ++f) {
+        const int d = sx[f] - sx[f / 4 * 4];
+        for (int kk = 0; kk < bwx; ++kk) axG[(size_t)(kk + d) * ncf4 + f] = axT[(size_t)kk * ncf + f];
+    }
     // ---- row operator: blocks of PRED_RB fine rows over the union of their bands
     const int RB = tpiv::PRED_RB;
     const int bwy = nrc < PRED_BW ? nrc : PRED_BW;
@@ -360,8 +373,16 @@ int build_banded(tpiv_plan* pl, int p, int nrc, int ncc, int nrf, int ncf, const
     if (leak > 1e-17) return fail(TPIV_EUNSUPPORTED, "spline operator does not fit the 65-tap band");
     pl->ku[p] = ku;
     pl->bwx[p] = bwx;
+    pl->bwg[p] = bwg;
+    int seg_len = 0;
+    for (int f0 = 0; f0 < ncf; f0 += 256) {
+        const int f1 = f0 + 255 < ncf ? f0 + 255 : ncf - 1;
+        seg_len = std::max(seg_len, sx[f1] + bwx - sx[f0] + dmax);
+    }
+    pl->seg_len[p] = (seg_len + 1) / 2 * 2;
     int rc = upload(pl, &pl->Wy[p], wy);
     if (!rc) rc = upload(pl, &pl->AxT[p], axT);
+    if (!rc) rc = upload(pl, &pl->AxG[p], axG);
     if (!rc) rc = upload(pl, &pl->k0y[p], k0);
     if (!rc) rc = upload(pl, &pl->startx[p], sx);
     return rc;
@@ -601,10 +622,13 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
     pl->Ax.assign(n_pass, nullptr);
     pl->Wy.assign(n_pass, nullptr);
     pl->AxT.assign(n_pass, nullptr);
+    pl->AxG.assign(n_pass, nullptr);
     pl->k0y.assign(n_pass, nullptr);
     pl->startx.assign(n_pass, nullptr);
     pl->ku.assign(n_pass, 0);
     pl->bwx.assign(n_pass, 0);
+    pl->bwg.assign(n_pass, 0);
+    pl->seg_len.assign(n_pass, 0);
     pl->u.assign(n_pass, nullptr);
     pl->v.assign(n_pass, nullptr);
     pl->val.assign(n_pass, nullptr);
@@ -703,6 +727,10 @@ static int run_banded_predict(tpiv_plan* plan, int p, int batch, const double* u
     q.bwx = plan->bwx[p];
     q.AxT = plan->AxT[p];
     q.startx = plan->startx[p];
+    q.bwg = plan->bwg[p];
+    q.ncf4 = (g.n_cols + 3) / 4 * 4;
+    q.AxG = plan->AxG[p];
+    q.seg_len = plan->seg_len[p];
     q.u_c = u_c;
     q.v_c = v_c;
     q.val_c = val_c;

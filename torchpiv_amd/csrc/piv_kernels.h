@@ -69,6 +69,11 @@ struct BandedPredictParams {
     int bwx;
     const double* AxT;            // [bwx][ncf]
     const int* startx;            // [ncf], non-decreasing
+    // the same weights re-aligned for groups of 4 fine columns: column c of group g uses taps
+    // basex = startx[4g] + kk, kk = 0..bwg-1 (zero-padded by its own offset startx[c] - startx[4g])
+    int bwg, ncf4;                // taps per group, ncf rounded up to a multiple of 4
+    int seg_len;                  // longest staged stretch of a T1 row per 256 fine columns (+ padding taps)
+    const double* AxG;            // [bwg][ncf4]
     const double* u_c;            // [batch, nrc, ncc]
     const double* v_c;
     const uint8_t* val_c;

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void predict_band_rows_kernel(BandedPredictPar
     const int kn = (k0 + q.ku <= q.nrc) ? q.ku : q.nrc - k0;
     if (f == 2) {
         const uint8_t* __restrict__ z = q.val_c + zoff;
+#pragma unroll 4
         for (int kk = 0; kk < kn; ++kk) {
             const double zv = (double)z[(size_t)(k0 + kk) * q.ncc];
 #pragma unroll
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) void predict_band_rows_kernel(BandedPredictPar
         }
     } else {
         const double* __restrict__ z = (f == 0 ? q.u_c : q.v_c) + zoff;
+#pragma unroll 4
         for (int kk = 0; kk < kn; ++kk) {
             const double zv = z[(size_t)(k0 + kk) * q.ncc];
 #pragma unroll
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(256) void predict_band_cols_kernel(BandedPredictPar
     if (cf >= q.ncf) return;
     const int s0 = q.startx[cf] - kmin;
     double u0 = 0.0, v0 = 0.0, vm = 0.0;
+#pragma unroll 5
     for (int kk = 0; kk < q.bwx; ++kk) {
         const double a = q.AxT[(size_t)kk * q.ncf + cf];
         u0 += a * seg[0][s0 + kk];
@@ -290,6 +293,97 @@ __global__ __launch_bounds__(256) void predict_band_cols_kernel(BandedPredictPar
     q.v2[o] = v2;
 }
 
+// Column operator, 4 fine columns and PRED_CR fine rows per thread: one wavefront = 256 fine columns.
+// The staged stretch of the T1 rows is read ONCE per tap for the 4 columns (group-aligned weights,
+// BandedPredictParams::AxG), so the kernel is bound by the float64 FMAs, not by LDS bandwidth.
+constexpr int PRED_CR = 2;
+__global__ __launch_bounds__(64) void predict_band_cols4_kernel(BandedPredictParams q) {
+    extern __shared__ double seg_dyn[];                        // [PRED_CR][3][seg_len]
+    const int SL = q.seg_len;
+    const int lane = threadIdx.x;
+    const int cf0 = blockIdx.x * 256;
+    const int rf0 = blockIdx.y * PRED_CR, b = blockIdx.z;
+    const int cf_last = (cf0 + 255 < q.ncf) ? cf0 + 255 : q.ncf - 1;
+    const int kmin = q.startx[cf0];
+    const int len = q.startx[cf_last] + q.bwx - kmin;          // <= 512 (checked on the host)
+    const int len_pad = len + (q.bwg - q.bwx);                 // taps beyond `len` carry zero weights
+#pragma unroll
+    for (int r = 0; r < PRED_CR; ++r) {
+        const bool row_ok = rf0 + r < q.nrf;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const double* __restrict__ src = q.T1 + (((size_t)b * 3 + f) * q.nrf + (row_ok ? rf0 + r : 0)) * q.ncc + kmin;
+            for (int i = lane; i < len_pad; i += 64) seg_dyn[(r * 3 + f) * SL + i] = (row_ok && i < len) ? src[i] : 0.0;
+        }
+    }
+    __syncthreads();
+    const int cfb = cf0 + 4 * lane;
+    if (cfb >= q.ncf) return;
+    const int s0 = q.startx[cfb] - kmin;
+    double acc[PRED_CR][3][4];
+#pragma unroll
+    for (int r = 0; r < PRED_CR; ++r)
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][f][c] = 0.0;
+    const double4* __restrict__ wg = reinterpret_cast<const double4*>(q.AxG) + (cfb >> 2);
+    const int wstride = q.ncf4 >> 2;
+#pragma unroll 8
+    for (int kk = 0; kk < q.bwg; ++kk) {
+        const double4 w = wg[(size_t)kk * wstride];
+#pragma unroll
+        for (int r = 0; r < PRED_CR; ++r)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const double z = seg_dyn[(r * 3 + f) * SL + s0 + kk];
+                acc[r][f][0] += w.x * z;
+                acc[r][f][1] += w.y * z;
+                acc[r][f][2] += w.z * z;
+                acc[r][f][3] += w.w * z;
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < PRED_CR; ++r) {
+        if (rf0 + r >= q.nrf) break;
+        double o_u0[4], o_v0[4], o_u2[4], o_v2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double u0 = acc[r][0][c], v0 = acc[r][1][c];
+            const bool val = acc[r][2][c] >= 0.5;       // B:711 / B:778
+            double u2 = 0.0, v2 = 0.0;
+            if (q.mode == MODE_CWS) {                   // B:705-706: halves taken BEFORE the zeroing
+                u2 = u0 / 2;
+                v2 = v0 / 2;
+            }
+            if (val) {
+                u0 = 0.0;
+                v0 = 0.0;
+            }
+            if (q.mode == MODE_DWS) {                   // B:782-785: AFTER the zeroing, half-even
+                u2 = rint(u0 / 2);
+                v2 = rint(v0 / 2);
+            }
+            o_u0[c] = u0;
+            o_v0[c] = v0;
+            o_u2[c] = u2;
+            o_v2[c] = v2;
+        }
+        const size_t o = ((size_t)b * q.nrf + rf0 + r) * q.ncf + cfb;
+        // (8-byte stores: rows of the odd-sized grids are not 16-byte aligned, and unaligned 16-byte
+        //  stores measured 20 % slower here)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (cfb + c < q.ncf) {
+                q.u0[o + c] = o_u0[c];
+                q.v0[o + c] = o_v0[c];
+                q.u2[o + c] = o_u2[c];
+                q.v2[o + c] = o_v2[c];
+            }
+        }
+    }
+}
+
 hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t stream) {
     const int nblk = (q.nrf + PRED_RB - 1) / PRED_RB;
     const int tx = q.ncc >= 256 ? 256 : (q.ncc >= 128 ? 128 : 64);
@@ -297,6 +391,12 @@ hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t strea
                        stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (q.AxG != nullptr) {
+        const size_t lds = (size_t)PRED_CR * 3 * q.seg_len * sizeof(double);
+        hipLaunchKernelGGL(predict_band_cols4_kernel, dim3((q.ncf + 255) / 256, (q.nrf + PRED_CR - 1) / PRED_CR, q.batch),
+                           dim3(64), lds, stream, q);
+        return hipGetLastError();
+    }
     const int tc = q.ncf >= 256 ? 256 : (q.ncf >= 128 ? 128 : 64);
     hipLaunchKernelGGL(predict_band_cols_kernel, dim3((q.ncf + tc - 1) / tc, q.nrf, q.batch), dim3(tc), 0,
                        stream, q);
