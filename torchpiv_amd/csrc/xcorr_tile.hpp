@@ -800,9 +800,14 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
                   "slow-path row buffer (shifted passes) must fit the tile LDS");
     __shared__ float tile[G::LDS_FLOATS];
 
-    // 32x32 and 16x16 have registers to spare: their twiddle constants live in VGPRs (plain 4-byte
-    // VOP2 multiplies instead of 8-byte literal forms and half-rate SGPR operands)
-    using TW = std::conditional_t<(WS == 32 || WS == 16), TwRegs<WS>, TwLiteral>;
+    // 16x16 has registers to spare: its twiddle constants live in VGPRs (plain 4-byte VOP2 multiplies
+    // instead of 8-byte literal forms and half-rate SGPR operands): 169 -> 158 us/pair
+    // for the 16x16 CWS pass at 4096^2.  For 32x32 the same change measured 1.3 % SLOWER in a
+    // same-box A/B (36.1 vs 35.6 us/pair; 14 more live VGPRs), so it stays off there.
+#ifndef TPIV_TWREG32
+#define TPIV_TWREG32 0
+#endif
+    using TW = std::conditional_t<((WS == 32 && TPIV_TWREG32) || WS == 16), TwRegs<WS>, TwLiteral>;
     TW tw;
     if constexpr (!std::is_same<TW, TwLiteral>::value) tw.init();
 
