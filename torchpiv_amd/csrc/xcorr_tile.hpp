@@ -40,6 +40,8 @@ struct TileGeo {
     // the LDS per wavefront (8.4 KB), which is what lets a third wavefront fit per SIMD.
     static constexpr bool PLANAR = PLANAR_;
     static constexpr int LDS_FLOATS = NT * TILE * (PLANAR ? 1 : 2);
+    static constexpr int HROWS = WS / 2 + 1;            // spectrum columns 0..WS/2 (c2r last transform)
+    static constexpr int HTILE = HROWS * PITCH;         // elements per half-transposition tile (WS <= 32)
     static constexpr int MAP_PITCH = WS + 1;            // floats per row of the correlation map
     static constexpr int NDW = WS / 4;                  // dwords per window row
 };
@@ -370,6 +372,53 @@ __device__ __forceinline__ void transpose_tile(cf (&a)[WS], float* lds, int lane
     }
 }
 
+// ---- half transposition for a real (c2r) last transform, WS <= 32 ----------------------------------
+// in:  lane (w, kx) holds column kx of its window's half-transformed spectrum, row y at in[FFT_POS<y>]
+// out: lane (w, y) holds g[kx] = element (row y, column kx) for kx = 0..WS/2 only (the spectrum of a
+//      real row is Hermitian).  Only lanes kx <= WS/2 write.
+template <int WS, bool PLANAR>
+__device__ __forceinline__ void transpose_half(const cf (&a)[WS], cf (&g)[WS / 2 + 1], float* lds, int lane) {
+    static_assert(WS <= 32, "one tile per window");
+    using G = TileGeo<WS, PLANAR>;
+    constexpr int P = G::PITCH, M = WS / 2;
+    const int i = lane % WS;
+    if constexpr (PLANAR) {
+        float* t = lds + (lane / WS) * G::HTILE;
+        wave_sync();
+        if (i <= M) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                t[i * P + k] = a[FFT_POS<k, WS>].x;
+            });
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r <= M; ++r) g[r].x = t[r * P + i];
+        wave_sync();
+        if (i <= M) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                t[i * P + k] = a[FFT_POS<k, WS>].y;
+            });
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r <= M; ++r) g[r].y = t[r * P + i];
+    } else {
+        cf* t = reinterpret_cast<cf*>(lds) + (lane / WS) * G::HTILE;
+        wave_sync();
+        if (i <= M) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                t[i * P + k] = a[FFT_POS<k, WS>];
+            });
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r <= M; ++r) g[r] = t[r * P + i];
+    }
+}
+
 // ---- stage 0: window rows, split into "issue the loads" and "turn them into samples" so that
 //      the loads of item i+1 can be in flight while item i is transformed (software prefetch)
 struct ItemGeom {
@@ -673,10 +722,10 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
 }
 
 // ---- peak analysis of one correlation row per lane (B:346-358, B:381-392, B:518) -----------------
-// in: lane (w, r) holds row y = r of its window's circular correlation, value at column x in
-// t[FFT_POS<x>].x (un-shifted coordinates).  Writes the window's 8-float record for finalize_kernel.
+// in: lane (w, r) holds row y = r of its window's circular correlation, value at column x in row[x]
+// (un-shifted coordinates; the callers' copies into `row` are register renames).  Writes the window's 8-float record for finalize_kernel.
 template <int WS, bool PLANAR>
-__device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], float* tile, int w, int r,
+__device__ __forceinline__ void peak_analysis(const PassParams& p, const float (&row)[WS], float* tile, int w, int r,
                                               bool active, bool dead, size_t fidx) {
     using G = TileGeo<WS, PLANAR>;
     // ---- correlation map in fftshift coordinates: y' = (r + WS/2) % WS, x' = (x + WS/2) % WS
@@ -687,10 +736,8 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
     float* my_map = tile + w * ((SMALLMAP ? 3 : WS) * G::MAP_PITCH);
     const int ys = (r + WS / 2) % WS;
     float cmin = 3.4e38f;
-    static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-        constexpr int k = decltype(kc)::value;
-        cmin = fminf(cmin, t[FFT_POS<k, WS>].x);
-    });
+#pragma unroll
+    for (int k = 0; k < WS; ++k) cmin = fminf(cmin, row[k]);
     cmin = grp_min<WS>(cmin);
     // Instruction-cost note (tools/micro/gen_issue_rate.py, MI355X): fp32 add/mul/max issue in ~2.1
     // cycles per wavefront, but every compare (SGPR result) and every select (SGPR mask) costs ~4.3.
@@ -702,7 +749,7 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, cf (&t)[WS], 
         constexpr int xsft = decltype(kc)::value;     // ascending shifted column
         constexpr int xo = (xsft + WS / 2) % WS;
         // B:518 corr - min; B:381 corr += eps (float32 arithmetic in passes >= 2)
-        const float v = __fadd_rn(__fsub_rn(t[FFT_POS<xo, WS>].x, cmin), 1e-7f);
+        const float v = __fadd_rn(__fsub_rn(row[xo], cmin), 1e-7f);
         c[xsft] = v;
         if constexpr (!SMALLMAP) my_map[ys * G::MAP_PITCH + xsft] = v;
         rmax = fmaxf(rmax, v);
@@ -1021,9 +1068,30 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         });
         fft_inreg<WS, -1>(t, tw);                         // over ky; row y at t[FFT_POS<y>]
         TPIV_STAMP(7);      // inverse column FFT
-        transpose_tile<WS, true, PLANAR>(t, tile, fresh_lane());  // lane = y, t[kx] natural
-        TPIV_STAMP(8);      // transposition 2
-        fft_inreg<WS, -1>(t, tw);                         // over kx; corr(y = lane, x) at t[FFT_POS<x>].x
+#ifndef TPIV_C2R
+#define TPIV_C2R 1
+#endif
+        float crow[WS];
+        if constexpr (TPIV_C2R && WS <= 32) {
+            // the map rows are real: only spectrum columns 0..WS/2 cross the LDS and a WS/2-point complex
+            // transform yields the row as z[m] = corr(y, 2m) + i corr(y, 2m + 1)  (c2r_inreg)
+            cf hs[WS / 2 + 1], z[WS / 2];
+            transpose_half<WS, PLANAR>(t, hs, tile, fresh_lane());
+            TPIV_STAMP(8);      // transposition 2
+            c2r_inreg<WS>(hs, z);
+            static_for<0, WS>([&](auto xc) TPIV_LAMBDA_INLINE {
+                constexpr int x_ = decltype(xc)::value;
+                crow[x_] = (x_ & 1) ? z[FFT_POS<x_ / 2, WS / 2>].y : z[FFT_POS<x_ / 2, WS / 2>].x;
+            });
+        } else {
+            transpose_tile<WS, true, PLANAR>(t, tile, fresh_lane());  // lane = y, t[kx] natural
+            TPIV_STAMP(8);      // transposition 2
+            fft_inreg<WS, -1>(t, tw);                     // over kx; corr(y = lane, x) at t[FFT_POS<x>].x
+            static_for<0, WS>([&](auto xc) TPIV_LAMBDA_INLINE {
+                constexpr int x_ = decltype(xc)::value;
+                crow[x_] = t[FFT_POS<x_, WS>].x;
+            });
+        }
         wave_sync();                                  // tile reads done: it becomes the map
         TPIV_STAMP(9);      // inverse row FFT
 
@@ -1046,9 +1114,9 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             const bool active_e = win_raw_e < N;
             const int win_e = active_e ? win_raw_e : N - 1;
             const size_t fidx_e = (size_t)pair_e * N + win_e;
-            peak_analysis<WS, PLANAR>(p, t, tile, w_e, r_e, active_e, dead, fidx_e);
+            peak_analysis<WS, PLANAR>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e);
         } else {
-            peak_analysis<WS, PLANAR>(p, t, tile, w, r, active, dead, fidx);
+            peak_analysis<WS, PLANAR>(p, crow, tile, w, r, active, dead, fidx);
         }
         wave_sync();
         if constexpr (WS < 64) nnitem = q_take(q_raw);
@@ -1069,15 +1137,11 @@ __global__ __launch_bounds__(64, 2) void peak_debug_kernel(PassParams p, const f
     const int win_raw = blockIdx.x * G::WPW + w;
     const bool active = win_raw < n_maps;
     const int win = active ? win_raw : n_maps - 1;
-    cf t[WS];
+    float crow[WS];
     const int ys = (r + WS / 2) % WS;
-    static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-        constexpr int xo = decltype(kc)::value;
-        constexpr int xs = (xo + WS / 2) % WS;
-        t[FFT_POS<xo, WS>].x = maps[((size_t)win * WS + ys) * WS + xs];
-        t[FFT_POS<xo, WS>].y = 0.f;
-    });
-    peak_analysis<WS, false>(p, t, tile, w, r, active, false, (size_t)win);
+#pragma unroll
+    for (int xo = 0; xo < WS; ++xo) crow[xo] = maps[((size_t)win * WS + ys) * WS + (xo + WS / 2) % WS];
+    peak_analysis<WS, false>(p, crow, tile, w, r, active, false, (size_t)win);
 }
 
 template <int WS>
