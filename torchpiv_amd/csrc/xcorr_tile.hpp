@@ -40,12 +40,8 @@ struct TileGeo {
     // the LDS per wavefront (8.4 KB), which is what lets a third wavefront fit per SIMD.
     static constexpr bool PLANAR = PLANAR_;
     static constexpr int HROWS = WS / 2 + 1;            // spectrum columns 0..WS/2 (c2r last transform)
-    static constexpr int HTILE = HROWS * PITCH;         // elements per half-transposition tile
-    static constexpr int LDS_FULL = NT * TILE * (PLANAR ? 1 : 2);
-    // 64x64 (complex tiles only): the half transposition uses two 33x33 tiles, a little more than
-    // the two 32x33 ones of the full transposition
-    static constexpr int LDS_HALF = (WS > 32 && !PLANAR) ? 2 * HTILE * 2 : 0;
-    static constexpr int LDS_FLOATS = LDS_FULL > LDS_HALF ? LDS_FULL : LDS_HALF;
+    static constexpr int HTILE = HROWS * PITCH;         // elements per half-transposition tile (WS <= 32)
+    static constexpr int LDS_FLOATS = NT * TILE * (PLANAR ? 1 : 2);
     static constexpr int MAP_PITCH = WS + 1;            // floats per row of the correlation map
     static constexpr int NDW = WS / 4;                  // dwords per window row
 };
@@ -382,26 +378,11 @@ __device__ __forceinline__ void transpose_tile(cf (&a)[WS], float* lds, int lane
 //      real row is Hermitian).  Only lanes kx <= WS/2 write.
 template <int WS, bool PLANAR>
 __device__ __forceinline__ void transpose_half(const cf (&a)[WS], cf (&g)[WS / 2 + 1], float* lds, int lane) {
-    static_assert(WS <= 32 || !PLANAR, "64x64: complex tiles only");
+    static_assert(WS <= 32, "one tile per window");
     using G = TileGeo<WS, PLANAR>;
     constexpr int P = G::PITCH, M = WS / 2;
     const int i = lane % WS;
-    if constexpr (WS > 32) {
-        // 64x64: lanes kx = 0..32 fill both 33x33 tiles (row y goes to tile y / 32), every lane then
-        // reads its own column of one tile -- no lane-half swaps, one LDS phase instead of two
-        cf* t = reinterpret_cast<cf*>(lds);
-        wave_sync();
-        if (i <= M) {
-            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-                constexpr int k = decltype(kc)::value;
-                t[(k >> 5) * G::HTILE + i * P + (k & 31)] = a[FFT_POS<k, WS>];
-            });
-        }
-        wave_sync();
-        const cf* tr = t + (lane >> 5) * G::HTILE + (lane & 31);
-#pragma unroll
-        for (int r = 0; r <= M; ++r) g[r] = tr[r * P];
-    } else if constexpr (PLANAR) {
+    if constexpr (PLANAR) {
         float* t = lds + (lane / WS) * G::HTILE;
         wave_sync();
         if (i <= M) {
@@ -1091,12 +1072,10 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
 #define TPIV_C2R 1
 #endif
         float crow[WS];
-        // (64x64 with complex tiles can take the same path, -DTPIV_C2R64=1, but it needs ~90 more live
-        //  registers there: same-box A/B 64x64 CWS pass 44.3 -> 49.4 us/pair (spills), DWS 35.4 -> 34.8)
-#ifndef TPIV_C2R64
-#define TPIV_C2R64 0
-#endif
-        if constexpr (TPIV_C2R && (WS <= 32 || (TPIV_C2R64 && !PLANAR))) {
+        // (64x64 was tried too, same-box A/B: with complex tiles it needs ~90 more live registers --
+        //  64x64 CWS pass 44.3 -> 49.4 us/pair, DWS 35.4 -> 34.8; the planar three-wavefront variant
+        //  spills 34 registers at its 168-VGPR cap -- pass 1 26.7 -> 29.4 us/pair.  Not kept.)
+        if constexpr (TPIV_C2R && WS <= 32) {
             // the map rows are real: only spectrum columns 0..WS/2 cross the LDS and a WS/2-point complex
             // transform yields the row as z[m] = corr(y, 2m) + i corr(y, 2m + 1)  (c2r_inreg)
             cf hs[WS / 2 + 1], z[WS / 2];
