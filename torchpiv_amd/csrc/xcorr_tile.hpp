@@ -729,22 +729,22 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
                                               bool active, bool dead, size_t fidx) {
     using G = TileGeo<WS, PLANAR>;
     // ---- correlation map in fftshift coordinates: y' = (r + WS/2) % WS, x' = (x + WS/2) % WS
-    // SMALLMAP (planar 64x64, 8.4 KB of LDS): only the rows ywin-5..ywin+5 around the peak are parked in
+    // SMALLMAP (planar 64x64, 8.4 KB of LDS): only the rows ywin-1..ywin+1 around the peak are parked in
     // LDS (everything the lookups below touch); otherwise the whole map is, written during the scan.
     constexpr bool SMALLMAP = G::WPW * WS * G::MAP_PITCH > G::LDS_FLOATS;
-    constexpr int SM_HALF = 5;                    // SMALLMAP keeps rows ywin-5..ywin+5 (validation windows <= 4)
-    constexpr int SM_ROWS = 2 * SM_HALF + 1;
-    static_assert(!SMALLMAP || G::WPW * SM_ROWS * G::MAP_PITCH <= G::LDS_FLOATS, "map rows must fit the tile LDS");
-    float* my_map = tile + w * ((SMALLMAP ? SM_ROWS : WS) * G::MAP_PITCH);
+    static_assert(G::WPW * 3 * G::MAP_PITCH <= G::LDS_FLOATS, "map rows must fit the tile LDS");
+    float* my_map = tile + w * ((SMALLMAP ? 3 : WS) * G::MAP_PITCH);
     const int ys = (r + WS / 2) % WS;
     float cmin = 3.4e38f;
 #pragma unroll
     for (int k = 0; k < WS; ++k) cmin = fminf(cmin, row[k]);
     cmin = grp_min<WS>(cmin);
-    // Instruction-cost note (tools/micro/gen_issue_rate.py, MI355X): fp32 add/mul/max issue in ~2.1
-    // cycles per wavefront, but every compare (SGPR result) and every select (SGPR mask) costs ~4.3.
-    // The scans below therefore avoid per-element compare/select: the arg-max is a plain max per
-    // row, and its position is found afterwards with one row of the LDS map spread over the lanes.
+    // The scans below avoid per-element compare/select chains (SGPR-pair results and masks, and the
+    // registers that tracking an index per lane costs): the arg-max is a plain max per row, and its
+    // position is found afterwards with one row of the LDS map spread over the lanes.  (A further
+    // variant that also replaced the integer sign-bit scan of the second peak by a lane = column pass
+    // over the 2 wv + 1 band rows measured no faster in a same-box A/B: integer ops interleaved with
+    // fp32 ops issue for free on MI355X, tools/micro/gen_issue_rate.py.)
     float c[WS];                                      // shifted row: c[x'] = corr - min + eps
     float rmax = 0.f;                                 // every c is >= 1e-7 > 0
     static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
@@ -761,11 +761,11 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
     // arg-max = FIRST flat index holding the maximum (torch.argmax, B:383): the smallest row y' whose
     // maximum equals it, then the smallest column of that row
     const int ywin = grp_reduce<WS>(rmax == gmax ? ys : WS - 1, imin);      // (WS - 1: NaN maps stay in range)
-    const int row0 = SMALLMAP ? ywin - SM_HALF : 0;     // map row held in LDS row 0
+    const int row0 = SMALLMAP ? ywin - 1 : 0;     // map row held in LDS row 0
     if constexpr (SMALLMAP) {
         wave_sync();
         const int slot = ys - row0;
-        if (slot >= 0 && slot < SM_ROWS) {
+        if (slot >= 0 && slot <= 2) {
 #pragma unroll
             for (int k = 0; k < WS; ++k) my_map[slot * G::MAP_PITCH + k] = c[k];
         }
@@ -789,24 +789,6 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
     const int KD = WS * WS;
     const int wv = p.val_win;
     const int my_ = ywin, mx_ = xwin;
-    // Fast path (the peak at least wv + 1 cells from every edge of the map: no row wrap, no clamps,
-    // the rule for practically every window): the excluded cells are the square (my+-wv, mx+-wv).
-    // Rows outside the band contribute their plain row maximum (already known); the 2 wv + 1 band
-    // rows are re-read from the LDS map with lane = column and multiplied by a 0/1 column mask --
-    // fp32 multiplies and maxima only, which issue at full rate, whereas 32-bit integer and bit-field
-    // instructions are half rate on MI355X (tools/micro/gen_issue_rate.py: v_max_i32 4.1, v_bfe_i32
-    // 4.2, v_bfi_b32 4.3 cycles): ~70 cycles per window instead of 12 per ELEMENT.
-    const bool interior = my_ > wv && my_ < WS - 1 - wv && mx_ > wv && mx_ < WS - 1 - wv && wv >= 0 &&
-                          wv <= (SMALLMAP ? SM_HALF - 1 : WS);
-    float second_v;
-    if (__all(interior)) {
-        const int dj = ys - my_;
-        float sv = (dj < -wv || dj > wv) ? rmax : 0.f;
-        const float keep = (r < mx_ - wv || r > mx_ + wv) ? 1.f : 0.f;
-        const float* band = my_map + (my_ - wv - row0) * G::MAP_PITCH + r;
-        for (int j = 0; j <= 2 * wv; ++j) sv = fmaxf(sv, band[j * G::MAP_PITCH] * keep);
-        second_v = grp_reduce<WS>(sv, [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); });
-    } else {
     int smax = 0;                                     // float bits; positive floats order like ints
     {
         const int dj = ys - my_;
@@ -833,8 +815,7 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
         });
     }
     smax = grp_reduce<WS>(smax, [](int a, int b) TPIV_LAMBDA_INLINE { return a > b ? a : b; });
-    second_v = smax > 0 ? __int_as_float(smax) : gmax;
-    }
+    const float second_v = smax > 0 ? __int_as_float(smax) : gmax;
 
     // ---- hand-off to finalize_kernel (piv_launch.hip): the float64 logarithms, divisions and the
     //      multipass combine of B:385-422 / B:728-738 need ONE lane per window, so they run in a
@@ -850,7 +831,7 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
         q = (r == 2) ? right : q;
         q = (r == 3) ? top : q;
         q = (r == 4) ? bot : q;
-        float outv = my_map[(q / WS - row0) * G::MAP_PITCH + (q % WS)];     // (rows ywin-1..ywin+1)
+        float outv = my_map[(q / WS - row0) * G::MAP_PITCH + (q % WS)];     // rows ywin-1..ywin+1 only
         outv = (r == 5) ? second_v : outv;
         outv = (r == 6) ? __int_as_float(m) : outv;
         outv = (r == 7) ? __int_as_float(dead ? 1 : 0) : outv;
