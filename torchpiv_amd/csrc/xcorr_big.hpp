@@ -19,7 +19,7 @@
 //                      u = P[ky1] + P[ky1+64]  (even rows, a = 0),  (P[ky1] - P[ky1+64]) w^-ky1  (odd rows)
 //                      and a 64-point inverse FFT  ->  Y[2i + a][k]
 //   stage 6   T2 + rows^-1: plane[2i + a][k] <- Y;  thread (y, h) reads its row, forms the DIF
-//                      split over k and runs the last 64-point inverse FFT -> corr[y][2j + h]
+//                      split over k (bins 0..32 only: Hermitian) and runs a c2r codelet -> corr[y][2j + h]
 //   stage 7   peak analysis of the 128x128 map in LDS (same record for finalize_kernel as the tile
 //                      kernel: B:346-358, B:381-392, B:518)
 //
@@ -302,8 +302,11 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
         }
 
         // ---------------- stage 6: transposition + inverse row transform (DIF split over k)
+        //   v[k1] = Y[k1] +- Y[k1 + 64] (odd samples: times w^-k1) is Hermitian in k1 because the row is
+        //   real, so bins 0..32 suffice and the last transform is a c2r one (32-point complex codelet)
+        cf zc[BH / 2];
         {
-            float v_re[BH];
+            cf hs[BH / 2 + 1];
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
@@ -316,9 +319,9 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127;
 #pragma unroll
-                for (int q = 0; q < BH; ++q) v_re[q] = fmaf(sgn, plane[ln * BP + 64 + q], plane[ln * BP + q]);
+                for (int q = 0; q <= BH / 2; ++q) hs[q].x = fmaf(sgn, plane[ln * BP + 64 + q], plane[ln * BP + q]);
             }
             wg_barrier();
             {
@@ -332,20 +335,17 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127;
 #pragma unroll
-                for (int q = 0; q < BH; ++q) {
-                    x[q].y = fmaf(sgn, plane[ln * BP + 64 + q], plane[ln * BP + q]);
-                    x[q].x = v_re[q];
-                }
+                for (int q = 0; q <= BH / 2; ++q) hs[q].y = fmaf(sgn, plane[ln * BP + 64 + q], plane[ln * BP + q]);
             }
             if (par) {
-                static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
+                static_for<0, BH / 2 + 1>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int k1 = decltype(kc)::value;
-                    x[k1] = twmul<k1, BW, -1>(x[k1]);
+                    hs[k1] = twmul<k1, BW, -1>(hs[k1]);
                 });
             }
-            fft_inreg<BH, -1>(x);                              // corr[line][2j + par] at x[FFT_POS<j>].x
+            c2r_inreg<BH>(hs, zc);          // corr[line][2 (2m) + par], corr[line][2 (2m+1) + par] = zc[FFT_POS<m, 32>].x, .y
         }
 
         // ---------------- stage 7: peak analysis on the map in LDS (fftshift coordinates)
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
             float cmin = 3.4e38f;
             static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
                 constexpr int j = decltype(jc)::value;
-                c[j] = x[FFT_POS<j, BH>].x;
+                c[j] = (j & 1) ? zc[FFT_POS<j / 2, BH / 2>].y : zc[FFT_POS<j / 2, BH / 2>].x;
                 cmin = fminf(cmin, c[j]);
             });
             // prefetch (the last iteration re-loads its own window: no branch around the loads)
