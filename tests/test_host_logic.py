@@ -212,3 +212,24 @@ int main(){ run<8>(); run<16>(); run<32>(); run<64>(); }
         Y = ((i * 37 + 11) % 101 - 50.0) + 1j * ((i * 53 + 7) % 89 - 44.0)
         ref = np.fft.irfft(Y, n=N) * N
         assert np.abs(got - ref).max() / np.abs(ref).max() < 3e-7, N
+
+
+def test_image_decode_follows_opencv_rules(tmp_path):
+    """Non-BMP inputs: 16-bit grey is scaled (>> 8) and colour uses OpenCV's fixed-point BGR2GRAY
+    weights, as cv2.imdecode(..., IMREAD_GRAYSCALE) does in the reference (PIVbackend.py:136-137)."""
+    from PIL import Image
+    from torchpiv_amd import io as tio
+    rng = np.random.default_rng(5)
+    g16 = rng.integers(0, 65536, size=(20, 24), dtype=np.uint16)
+    Image.fromarray(g16).save(tmp_path / "g16.png")
+    got = tio.imdecode_gray(str(tmp_path / "g16.png"))
+    assert got.dtype == np.uint8 and np.array_equal(got, (g16 >> 8).astype(np.uint8))
+    rgb = rng.integers(0, 256, size=(20, 24, 3), dtype=np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.png")
+    got = tio.imdecode_gray(str(tmp_path / "c.png"))
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    want = ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(got, want)
+    g8 = rng.integers(0, 256, size=(20, 24), dtype=np.uint8)
+    Image.fromarray(g8, "L").save(tmp_path / "g8.tif")
+    assert np.array_equal(tio.imdecode_gray(str(tmp_path / "g8.tif")), g8)

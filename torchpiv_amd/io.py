@@ -5,7 +5,7 @@ Mirrors PIVDataset / ToTensor (PIVbackend.py:103-144) and natural_keys
 cv2.imdecode(np.fromfile(path), IMREAD_GRAYSCALE); OpenCV is not a dependency here, so
 8/24/32-bit uncompressed BMP (what PIV cameras write, and the reference's test_images
 format) is decoded by hand with OpenCV's BGR->gray fixed-point weights, and other
-formats go through Pillow's 'L' conversion.
+formats are opened with Pillow and converted with OpenCV's rules (16-bit >> 8, fixed-point BGR2GRAY).
 """
 from __future__ import annotations
 
@@ -83,6 +83,17 @@ def imdecode_gray(path: str):
 
         from PIL import Image
         with Image.open(_io.BytesIO(buf)) as im:
+            # cv2.imdecode(..., IMREAD_GRAYSCALE) semantics rather than Pillow's "L" conversion:
+            # 16-bit samples are scaled down (>> 8; Pillow would clip at 255), colour goes through
+            # OpenCV's fixed-point BGR2GRAY weights (Pillow's ITU-R 601 integers differ by one grey
+            # level here and there)
+            if im.mode in ("I;16", "I;16L", "I;16B", "I;16N"):
+                return (np.asarray(im).astype(np.uint16) >> 8).astype(np.uint8)
+            if im.mode == "L":
+                return np.array(im, dtype=np.uint8)
+            if im.mode in ("RGB", "RGBA", "P", "CMYK", "YCbCr"):
+                rgb = np.asarray(im.convert("RGB"))
+                return _bgr_to_gray(rgb[..., 2], rgb[..., 1], rgb[..., 0])
             return np.array(im.convert("L"), dtype=np.uint8)
     except Exception:
         return None
