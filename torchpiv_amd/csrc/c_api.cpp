@@ -377,7 +377,7 @@ int build_banded(tpiv_plan* pl, int p, int nrc, int ncc, int nrf, int ncf, const
     int seg_len = 0;
     for (int f0 = 0; f0 < ncf; f0 += 256) {
         const int f1 = f0 + 255 < ncf ? f0 + 255 : ncf - 1;
-        seg_len = std::max(seg_len, sx[f1] + bwx - sx[f0] + dmax);
+        seg_len = std::max(seg_len, sx[f1] + bwx - sx[f0] + dmax + 8);
     }
     pl->seg_len[p] = (seg_len + 1) / 2 * 2;
     int rc = upload(pl, &pl->Wy[p], wy);

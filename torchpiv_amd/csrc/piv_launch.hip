@@ -306,7 +306,8 @@ __global__ __launch_bounds__(64) void predict_band_cols4_kernel(BandedPredictPar
     const int cf_last = (cf0 + 255 < q.ncf) ? cf0 + 255 : q.ncf - 1;
     const int kmin = q.startx[cf0];
     const int len = q.startx[cf_last] + q.bwx - kmin;          // <= 512 (checked on the host)
-    const int len_pad = len + (q.bwg - q.bwx);                 // taps beyond `len` carry zero weights
+    const int len_pad = len + (q.bwg - q.bwx) + 8;             // taps beyond `len` carry zero weights
+                                                               // (+8: the tap loop runs in groups of 8)
 #pragma unroll
     for (int r = 0; r < PRED_CR; ++r) {
         const bool row_ok = rf0 + r < q.nrf;
@@ -317,8 +318,8 @@ __global__ __launch_bounds__(64) void predict_band_cols4_kernel(BandedPredictPar
         }
     }
     __syncthreads();
-    const int cfb = cf0 + 4 * lane;
-    if (cfb >= q.ncf) return;
+    const int cfb_raw = cf0 + 4 * lane;
+    const int cfb = cfb_raw < q.ncf ? cfb_raw : (q.ncf - 1) / 4 * 4;     // idle lanes redo the last group
     const int s0 = q.startx[cfb] - kmin;
     double acc[PRED_CR][3][4];
 #pragma unroll
@@ -329,24 +330,38 @@ __global__ __launch_bounds__(64) void predict_band_cols4_kernel(BandedPredictPar
             for (int c = 0; c < 4; ++c) acc[r][f][c] = 0.0;
     const double4* __restrict__ wg = reinterpret_cast<const double4*>(q.AxG) + (cfb >> 2);
     const int wstride = q.ncf4 >> 2;
-#pragma unroll 8
-    for (int kk = 0; kk < q.bwg; ++kk) {
-        const double4 w = wg[(size_t)kk * wstride];
+    // taps in groups of 8 with all eight weight loads issued up front: left to the compiler every load
+    // was followed by s_waitcnt vmcnt(0), i.e. one L2 round trip per tap
+    for (int kk0 = 0; kk0 < q.bwg; kk0 += 8) {
+        double4 w[8];
 #pragma unroll
-        for (int r = 0; r < PRED_CR; ++r)
+        for (int u = 0; u < 8; ++u) {
+            const int kk = kk0 + u < q.bwg ? kk0 + u : q.bwg - 1;
+            w[u] = wg[(size_t)kk * wstride];
+        }
 #pragma unroll
-            for (int f = 0; f < 3; ++f) {
-                const double z = seg_dyn[(r * 3 + f) * SL + s0 + kk];
-                acc[r][f][0] += w.x * z;
-                acc[r][f][1] += w.y * z;
-                acc[r][f][2] += w.z * z;
-                acc[r][f][3] += w.w * z;
-            }
+        for (int u = 0; u < 8; ++u) {
+            const bool live = kk0 + u < q.bwg;                 // tail taps: weight 0 on a zero-filled cell
+            const double4 wu = live ? w[u] : make_double4(0.0, 0.0, 0.0, 0.0);
+#pragma unroll
+            for (int r = 0; r < PRED_CR; ++r)
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const double z = seg_dyn[(r * 3 + f) * SL + s0 + kk0 + u];
+                    acc[r][f][0] += wu.x * z;
+                    acc[r][f][1] += wu.y * z;
+                    acc[r][f][2] += wu.z * z;
+                    acc[r][f][3] += wu.w * z;
+                }
+        }
     }
+    // Outputs go through LDS so that every store instruction writes 64 CONSECUTIVE doubles (a thread
+    // owns 4 adjacent columns: stored directly, each instruction would touch every fourth double of
+    // a 2 KB stretch, four partial passes over every cache line).
+    __syncthreads();                                           // the staged T1 rows are no longer needed
+    double* stage = seg_dyn;                                   // [4 arrays][PRED_CR][256]
 #pragma unroll
     for (int r = 0; r < PRED_CR; ++r) {
-        if (rf0 + r >= q.nrf) break;
-        double o_u0[4], o_v0[4], o_u2[4], o_v2[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             double u0 = acc[r][0][c], v0 = acc[r][1][c];
@@ -364,21 +379,25 @@ __global__ __launch_bounds__(64) void predict_band_cols4_kernel(BandedPredictPar
                 u2 = rint(u0 / 2);
                 v2 = rint(v0 / 2);
             }
-            o_u0[c] = u0;
-            o_v0[c] = v0;
-            o_u2[c] = u2;
-            o_v2[c] = v2;
+            const int col = 4 * lane + c;
+            stage[(0 * PRED_CR + r) * 256 + col] = u0;
+            stage[(1 * PRED_CR + r) * 256 + col] = v0;
+            stage[(2 * PRED_CR + r) * 256 + col] = u2;
+            stage[(3 * PRED_CR + r) * 256 + col] = v2;
         }
-        const size_t o = ((size_t)b * q.nrf + rf0 + r) * q.ncf + cfb;
-        // (8-byte stores: rows of the odd-sized grids are not 16-byte aligned, and unaligned 16-byte
-        //  stores measured 20 % slower here)
+    }
+    __syncthreads();
+    double* const outs[4] = {q.u0, q.v0, q.u2, q.v2};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (cfb + c < q.ncf) {
-                q.u0[o + c] = o_u0[c];
-                q.v0[o + c] = o_v0[c];
-                q.u2[o + c] = o_u2[c];
-                q.v2[o + c] = o_v2[c];
+    for (int arr = 0; arr < 4; ++arr) {
+#pragma unroll
+        for (int r = 0; r < PRED_CR; ++r) {
+            if (rf0 + r >= q.nrf) break;
+            double* __restrict__ dst = outs[arr] + ((size_t)b * q.nrf + rf0 + r) * q.ncf + cf0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int col = j * 64 + lane;
+                if (cf0 + col < q.ncf) dst[col] = stage[(arr * PRED_CR + r) * 256 + col];
             }
         }
     }
@@ -392,7 +411,8 @@ hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t strea
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (q.AxG != nullptr) {
-        const size_t lds = (size_t)PRED_CR * 3 * q.seg_len * sizeof(double);
+        const size_t seg_d = (size_t)PRED_CR * 3 * q.seg_len, out_d = (size_t)4 * PRED_CR * 256;
+        const size_t lds = (seg_d > out_d ? seg_d : out_d) * sizeof(double);
         hipLaunchKernelGGL(predict_band_cols4_kernel, dim3((q.ncf + 255) / 256, (q.nrf + PRED_CR - 1) / PRED_CR, q.batch),
                            dim3(64), lds, stream, q);
         return hipGetLastError();
