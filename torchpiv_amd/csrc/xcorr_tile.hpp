@@ -584,18 +584,21 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
 }
 
 // raw rows -> float samples x[k] = (a, b) and the lane's partial sums
-template <int WS, int MODE>
+// RBH: the per-pixel slow paths park a row in LDS in RBH pieces (2 when the planar 64x64 layout
+// leaves only 64 x 33 floats)
+template <int WS, int MODE, int RBH = 1>
 __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom& g, int r, int lane, float vx,
                                              float vy, RawRows<WS, MODE>& raw, cf (&x)[WS], float& sa,
                                              float& sb, float* lds) {
     const int HW = p.H * p.W;
     const uint8_t* __restrict__ fa = p.A + (size_t)g.pair * HW;
     const uint8_t* __restrict__ fb = p.B + (size_t)g.pair * HW;
-    float* rowbuf = lds + lane * (WS + 1);     // slow paths only
+    static constexpr int RBL = WS / RBH;       // row-buffer length
+    float* rowbuf = lds + lane * (RBL + 1);    // slow paths only
     // The rare per-pixel paths must not set the register budget of the small tiles (unrolled, their
     // gathers keep a 64-bit address per load in flight: 135 VGPRs for an 8x8 kernel whose fast path
     // needs about 60), so they are fully rolled there.
-    constexpr int UNR_DWS = WS <= 16 ? 1 : 4, UNR_CWS = WS <= 16 ? 1 : 2;
+    static constexpr int UNR_DWS = WS <= 16 ? 1 : 4, UNR_CWS = WS <= 16 ? 1 : 2;
     if constexpr (MODE == MODE_PASS1) {
         unsigned ia = 0, ib = 0;
 #pragma unroll
@@ -624,14 +627,17 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         } else {          // a row touches the first/last pixel of the frame: per-pixel clamp.
             // Rare: kept as a rolled loop that parks the row in LDS (no code blow-up).
             wave_sync();
+            static_for<0, RBH>([&](auto hc) TPIV_LAMBDA_INLINE {
+                constexpr int k0 = decltype(hc)::value * RBL;
 #pragma unroll UNR_DWS
-            for (int k = 0; k < WS; ++k) rowbuf[k] = fetch_clamped_t(fa, raw.qa + k, HW);
+                for (int k = 0; k < RBL; ++k) rowbuf[k] = fetch_clamped_t(fa, raw.qa + k0 + k, HW);
 #pragma unroll
-            for (int k = 0; k < WS; ++k) x[k].x = rowbuf[k];
+                for (int k = 0; k < RBL; ++k) x[k0 + k].x = rowbuf[k];
 #pragma unroll UNR_DWS
-            for (int k = 0; k < WS; ++k) rowbuf[k] = fetch_clamped_t(fb, raw.qb + k, HW);
+                for (int k = 0; k < RBL; ++k) rowbuf[k] = fetch_clamped_t(fb, raw.qb + k0 + k, HW);
 #pragma unroll
-            for (int k = 0; k < WS; ++k) x[k].y = rowbuf[k];
+                for (int k = 0; k < RBL; ++k) x[k0 + k].y = rowbuf[k];
+            });
             wave_sync();
         }
         sa = 0.f;
@@ -683,9 +689,11 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         } else {          // generic per-pixel gather with the flat-index clamp (rare: rolled loops
                           // that park the row in LDS)
             wave_sync();
+            static_for<0, RBH>([&](auto hc) TPIV_LAMBDA_INLINE {
+            constexpr int k0 = decltype(hc)::value * RBL;
 #pragma unroll UNR_CWS
-            for (int k = 0; k < WS; ++k) {
-                const float nxa = (gx0f + (float)k) - vx;
+            for (int k = 0; k < RBL; ++k) {
+                const float nxa = (gx0f + (float)(k0 + k)) - vx;
                 const float uxa_f = ceilf(nxa), dxa_f = floorf(nxa);
                 const int uxa = f2i_sat_t(uxa_f), dxa = f2i_sat_t(dxa_f);
                 rowbuf[k] = bilerp_ref(fetch_clamped_t(fa, (long long)c.dya * p.W + dxa, HW),
@@ -695,10 +703,10 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                                        nxa - dxa_f, c.wya_up, c.wya_dn, c.ydeg_a || (uxa == dxa));
             }
 #pragma unroll
-            for (int k = 0; k < WS; ++k) x[k].x = rowbuf[k];
+            for (int k = 0; k < RBL; ++k) x[k0 + k].x = rowbuf[k];
 #pragma unroll UNR_CWS
-            for (int k = 0; k < WS; ++k) {
-                const float nxb = (gx0f + (float)k) + vx;
+            for (int k = 0; k < RBL; ++k) {
+                const float nxb = (gx0f + (float)(k0 + k)) + vx;
                 const float uxb_f = ceilf(nxb), dxb_f = floorf(nxb);
                 const int uxb = f2i_sat_t(uxb_f), dxb = f2i_sat_t(dxb_f);
                 rowbuf[k] = bilerp_ref(fetch_clamped_t(fb, (long long)c.dyb * p.W + dxb, HW),
@@ -708,7 +716,8 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                                        nxb - dxb_f, c.wyb_up, c.wyb_dn, c.ydeg_b || (uxb == dxb));
             }
 #pragma unroll
-            for (int k = 0; k < WS; ++k) x[k].y = rowbuf[k];
+            for (int k = 0; k < RBL; ++k) x[k0 + k].y = rowbuf[k];
+            });
             wave_sync();
         }
         sa = 0.f;
@@ -845,7 +854,8 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
     constexpr bool PLANAR = OCC > 2;
     using G = TileGeo<WS, PLANAR>;
     static_assert(WS == 8 || WS == 16 || WS == 32 || WS == 64, "tile sizes of this kernel");
-    static_assert(MODE == MODE_PASS1 || 64 * (WS + 1) <= G::LDS_FLOATS,
+    constexpr int RBH = 64 * (WS + 1) <= G::LDS_FLOATS ? 1 : 2;      // slow-path row buffer pieces
+    static_assert(MODE == MODE_PASS1 || 64 * (WS / RBH + 1) <= G::LDS_FLOATS,
                   "slow-path row buffer (shifted passes) must fit the tile LDS");
     __shared__ float tile[G::LDS_FLOATS];
 
@@ -965,7 +975,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         cf x[WS];
         float sa, sb;                      // window sums (for the mean)
         TPIV_STAMP(0);      // loop head: geometry, next shifts, combine loads
-        convert_rows<WS, MODE>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile);
+        convert_rows<WS, MODE, RBH>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile);
         TPIV_STAMP(1);      // wait for the rows + conversion / bilinear sampling
         // 64x64 (register-bound): the dequeue issued at the loop head has landed by now; move it to a
         // scalar register (kept in a VGPR to the loop end it would be spilled, and the reload would
@@ -1193,9 +1203,10 @@ static hipError_t launch_tile(const PassParams& p_in, int n_cu, hipStream_t stre
         const char* e = getenv("TPIV_OCC");
         return e ? atoi(e) : 0;
     }();
-    const int occ = occ_env ? occ_env : (WS == 16 ? 4 : ((WS == 32 || (WS == 64 && MODE == MODE_PASS1)) ? 3 : 2));
-    if constexpr (WS == 64 && MODE == MODE_PASS1) {
-        // 64x64 pass 1 (no shifted-window slow paths, so the small planar LDS layout is enough)
+    const int occ = occ_env ? occ_env : (WS == 16 ? 4 : ((WS == 32 || (WS == 64 && MODE != MODE_CWS)) ? 3 : 2));
+    if constexpr (WS == 64 && MODE != MODE_CWS) {
+        // 64x64 pass 1 and DWS at three wavefronts per SIMD (planar tiles, 11-row map, slow-path row
+        // buffer in two pieces); the CWS variant needs 230 VGPRs and stays at two
         if (occ == 3) {
             hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 3>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
             return hipGetLastError();
