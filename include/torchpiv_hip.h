@@ -11,11 +11,11 @@
  *   - every pointer named *_dev is device memory on the CURRENT HIP device, owned by
  *     the caller (PyTorch-ROCm tensors: tensor.data_ptr()); the run functions only enqueue
  *     work on `stream` (a hipStream_t passed as void*; NULL = the null stream) and return at
- *     once.  tpiv_plan_run allocates nothing; the function-level entry points (tpiv_pass1 /
- *     tpiv_iter) keep one grow-only scratch buffer per device inside the library (32 bytes per
- *     window; re-allocated, with a device synchronise, only when a call needs more than any
- *     earlier one).  That buffer is shared by all function-level calls on a device: do not
- *     overlap them on different streams (plans own their workspace and may run concurrently);
+ *     once.  No entry point allocates device memory or synchronises: a plan owns its workspace
+ *     (allocated once by tpiv_plan_create), and the function-level entry points (tpiv_pass1 /
+ *     tpiv_iter) take a caller-provided work buffer of tpiv_work_bytes() bytes (hand-off records
+ *     between the tile kernel and the finalize kernel).  The library keeps no state between
+ *     calls, so calls on different streams (with different work buffers) may overlap;
  *   - fields are row-major [batch, n_rows, n_cols]; frames are uint8 [batch, H, W];
  *   - return value: TPIV_OK or an error code; tpiv_last_error() gives the message
  *     of the calling thread's last failure.  Nothing is thrown across the ABI.
@@ -23,13 +23,14 @@
 #ifndef TORCHPIV_HIP_H
 #define TORCHPIV_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define TPIV_VERSION 1
+#define TPIV_VERSION 2
 
 enum tpiv_status {
     TPIV_OK = 0,
@@ -43,6 +44,13 @@ enum tpiv_status {
 enum tpiv_mode {
     TPIV_MODE_DWS = 1, /* discrete window shift,  piv_iteration_DWS  B:744-812 */
     TPIV_MODE_CWS = 2  /* continuous window shift, piv_iteration_CWS B:677-740 */
+};
+
+enum tpiv_precision {
+    TPIV_PREC_FAST = 0,      /* pass 1 in float32 (mean-removed windows; observed deviation ~1e-6 px) */
+    TPIV_PREC_REFERENCE = 1  /* pass 1 in float64 like the reference (B:513-514 promotes the windows to
+                                float64 before the FFT); passes >= 2 are float32 + float64 epilogue in
+                                the reference itself (B:249-257, B:382), so they are the same in both */
 };
 
 typedef struct tpiv_plan tpiv_plan;
@@ -74,8 +82,13 @@ int tpiv_spline_matrix(int nc, const double* xc, int nf, const double* xf, doubl
  * correlation_to_displacement B:360-422, peak2peak_secondpeak B:346-358).
  * Outputs: u, v float64 and invalid uint8 (1 = peak ratio < val_ratio). */
 int tpiv_pass1(const uint8_t* a_dev, const uint8_t* b_dev, int batch, int H, int W,
-               int ws, int ov, double val_ratio, int val_win,
-               double* u_dev, double* v_dev, uint8_t* invalid_dev, void* stream);
+               int ws, int ov, double val_ratio, int val_win, int precision,
+               double* u_dev, double* v_dev, uint8_t* invalid_dev,
+               void* work_dev, size_t work_bytes, void* stream);
+
+/* Bytes of device work buffer tpiv_pass1 / tpiv_iter / tpiv_debug_pass need for `batch` pairs of
+ * H x W frames at (ws, ov) (either precision); 0 if the geometry is invalid. */
+size_t tpiv_work_bytes(int H, int W, int ws, int ov, int batch);
 
 /* Predictor of one multipass iteration (host-side scipy calls in the reference,
  * B:700-717 CWS / B:769-790 DWS): spline-upsample u, v and the invalid mask from
@@ -101,18 +114,23 @@ int tpiv_iter(int mode, const uint8_t* a_dev, const uint8_t* b_dev, int batch, i
               const double* u0_dev, const double* v0_dev, const double* u2_dev, const double* v2_dev,
               double val_ratio, int val_win,
               double* u_dev, double* v_dev, uint8_t* invalid_dev,
-              double* du_dev, double* dv_dev, void* stream);
+              double* du_dev, double* dv_dev, void* work_dev, size_t work_bytes, void* stream);
 
 /* ---- plan: the whole multipass pipeline of OfflinePIV.__call__ for a batch ---- */
 
 /* Mirrors OfflinePIV.__init__ (B:825-858): pass p > 0 uses ws_p = int(ws_{p-1} // pass_scale),
  * ov_p = int(ov_{p-1} // pass_scale).  Allocates (on the current device) the spline
- * operators and the per-pass field workspace for up to max_batch pairs. */
+ * operators and the per-pass field workspace for up to max_batch pairs.
+ * precision: enum tpiv_precision (arithmetic of pass 1). */
 int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, int mode,
-                     double pass_scale, double val_ratio, int val_win, int max_batch);
+                     double pass_scale, double val_ratio, int val_win, int max_batch, int precision);
 void tpiv_plan_destroy(tpiv_plan* plan);
 int tpiv_plan_n_pass(const tpiv_plan* plan);
 int tpiv_plan_pass_geometry(const tpiv_plan* plan, int pass, int* ws, int* ov, int* n_rows, int* n_cols);
+
+/* Name of the cross-correlation kernel pass `pass` launches (for bench / profile labels), e.g.
+ * "xcorr_tile_kernel<32, 2, 3>" (the demangled form profilers print; second argument: 0 pass 1, 1 DWS, 2 CWS).  Returns buf. */
+const char* tpiv_plan_kernel_name(const tpiv_plan* plan, int pass, char* buf, int len);
 
 /* Pass 1 and every further pass (B:873-882) for `batch` <= max_batch pairs; the last
  * pass writes straight into u_dev / v_dev / invalid_dev ([batch, n_rows_last, n_cols_last]). */
@@ -138,21 +156,25 @@ int tpiv_plan_get_timing(tpiv_plan* plan, double* avg_ms, int n_slots, int* n_ru
 
 /* ---- test hook ------------------------------------------------------------------ */
 
-/* Runs one pass like tpiv_pass1 (mode 0) / tpiv_iter (mode DWS/CWS, with u0 = v0 = 0)
- * and additionally writes the staged windows win_dev [batch, N, 2, ws, ws] float32
- * (frame a, frame b, after the shift) and the correlation maps corr_dev
- * [batch, N, ws, ws] float32 (corr - min + 1e-7, fftshift layout). Either may be NULL. */
+/* Runs one pass like tpiv_pass1 (mode 0, float32 precision) / tpiv_iter (mode DWS/CWS; zero_dev =
+ * [batch, n_rows, n_cols] float64 zeros, used as u0 = v0) and additionally writes the staged
+ * windows win_dev [batch, N, 2, ws, ws] float32 (frame a, frame b, after the shift) and the
+ * correlation maps corr_dev [batch, N, ws, ws] float32 (corr - min + 1e-7, fftshift layout).
+ * Either may be NULL. */
 int tpiv_debug_pass(int mode, const uint8_t* a_dev, const uint8_t* b_dev, int batch, int H, int W,
-                    int ws, int ov, const double* u2_dev, const double* v2_dev,
+                    int ws, int ov, const double* u2_dev, const double* v2_dev, const double* zero_dev,
                     double* u_dev, double* v_dev, uint8_t* invalid_dev,
-                    float* win_dev, float* corr_dev, void* stream);
+                    float* win_dev, float* corr_dev, void* work_dev, size_t work_bytes, void* stream);
 
 /* Peak analysis alone -- correlation_to_displacement (B:360-422) + peak2peak_secondpeak
  * (B:346-358) -- on caller-supplied correlation maps [n_maps, ws, ws] float32 in fftshift layout
- * (ws = 8 or 16): runs the tile kernel's peak stage and finalize on them.  The kernel subtracts the
- * map minimum first (B:518), so feed maps whose minimum is 0 to compare with the reference function. */
-int tpiv_debug_peaks(const float* maps_dev, int n_maps, int ws, double val_ratio, int val_win,
-                     double* u_dev, double* v_dev, uint8_t* invalid_dev, void* stream);
+ * (ws = 8, 16, 32, 64 or 128): runs the kernels' peak stage and finalize on them.  planar != 0
+ * selects the LDS layout of the three-wavefront tile kernels (64x64: the three-row map); ignored
+ * for ws = 128.  The kernel subtracts the map minimum first (B:518), so feed maps whose minimum is
+ * 0 to compare with the reference function.  work_dev: n_maps * 32 bytes. */
+int tpiv_debug_peaks(const float* maps_dev, int n_maps, int ws, int planar, double val_ratio, int val_win,
+                     double* u_dev, double* v_dev, uint8_t* invalid_dev,
+                     void* work_dev, size_t work_bytes, void* stream);
 
 /* Runs the plan's own (banded) predictor of pass `pass` (1 <= pass < n_pass) on caller-supplied
  * coarse fields, exactly as tpiv_plan_run does between passes; same outputs as tpiv_predict.

@@ -337,14 +337,60 @@ def g7_generic():
     save("g7_generic", **out)
 
 
+# ------------------------------------------------- G8 round-2 additions
+def g8_round2():
+    """(a) shifted 128x128 passes (256/128 -> 128/64, both modes): the only route to a shifted
+    128-pixel window; (b) the generator at configs[0]'s geometry (64/32, one pass) on the BMP folder
+    (512x640 frames, 15 x 19 vectors; pairs without an invalid vector are dropped)."""
+    from PIL import Image
+    out = {}
+    name, H, W, ws, ov, n_pass = "big256x2", 640, 768, 256, 128, 2
+    a, b = make_frames(H, W, "shear", 2.0, False, 40)
+    out[name + "_a"], out[name + "_b"] = a.numpy(), b.numpy()
+    out[name + "_cfg"] = np.array([ws, ov, n_pass])
+    for mode in ("DWS", "CWS"):
+        u, v, x, y, val = ref.extended_search_area_piv(a, b, window_size=ws, overlap=ov, validate=True)
+        out[f"{name}_{mode}_p0_u"], out[f"{name}_{mode}_p0_v"], out[f"{name}_{mode}_p0_val"] = u, v, val
+        it = ref.IterModMap.functions[mode](a.shape, ws // 2, ov // 2, torch.device("cpu"))
+        u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
+        out[f"{name}_{mode}_p1_u"], out[f"{name}_{mode}_p1_v"], out[f"{name}_{mode}_p1_val"] = u.copy(), v.copy(), val.copy()
+        print(f"\n  {name} {mode} pass 1: grid {u.shape} invalid {int(val.sum())}")
+    H, W = 512, 640
+    specs = [("uniform", 0.0, False), ("wavy", 2.0, True), ("vortex", 4.0, True), ("zero", 0.0, False),
+             ("shear", 6.0, True)]
+    with tempfile.TemporaryDirectory() as d:
+        fr = []
+        for i, (kind, noise, special) in enumerate(specs):
+            fa, fb = make_frames(H, W, kind, noise, special, 50 + i)
+            fr.append((fa.numpy(), fb.numpy()))
+            Image.fromarray(fa.numpy(), "L").save(os.path.join(d, f"image{8 + i}_a.bmp"))
+            Image.fromarray(fb.numpy(), "L").save(os.path.join(d, f"image{8 + i}_b.bmp"))
+        out["r5_frames_a"] = np.stack([f[0] for f in fr])
+        out["r5_frames_b"] = np.stack([f[1] for f in fr])
+        kw = dict(wind_size=64, overlap=32, multipass=1, multipass_mode="DWS", dt=1, scale=1.0)
+        gen = ref.OfflinePIV(folder=d, device="cpu", file_fmt="bmp", multipass_scale=2.0, folder_mode="pairs", **kw)
+        res = list(gen())
+        out["r5_count"] = np.array([len(gen), len(res)])
+        out["r5_kw"] = np.array([64, 32, 1, 0, 1])
+        out["r5_scale"] = np.array([1.0])
+        for j, (x, y, u, v) in enumerate(res):
+            out[f"r5_{j}_x"], out[f"r5_{j}_y"], out[f"r5_{j}_u"], out[f"r5_{j}_v"] = x, y, u, v
+        print(f"\n  generator r5 (64/32, 1 pass): {len(res)} of {len(gen)} pairs yielded")
+    save("g8_round2", **out)
+
+
 if __name__ == "__main__":
     import sys as _sys
-    if len(_sys.argv) > 1 and _sys.argv[1] == "g7":
+    only = _sys.argv[1] if len(_sys.argv) > 1 else None
+    if only == "g7":
         g7_generic()
-        raise SystemExit(0)
-    g1_geometry()
-    g3_pass1()
-    g4_multipass()
-    g5_generator()
-    g6_kats()
-    g7_generic()
+    elif only == "g8":
+        g8_round2()
+    else:
+        g1_geometry()
+        g3_pass1()
+        g4_multipass()
+        g5_generator()
+        g6_kats()
+        g7_generic()
+        g8_round2()

@@ -35,6 +35,19 @@ def _worker(rank, world, port, q):
         q.put((ids.tolist(), allf[:, 0, 0, 0].tolist()))
     else:
         assert ids is None and allf is None
+    # fewer pairs than ranks: rank 1's shard is empty and it has no plan to take the grid from --
+    # its placeholder is [0, 2, 0, 0]; the tail shape travels with the counts
+    mine1 = pdist.shard_indices(1, rank, world, "block")
+    assert len(mine1) == (1 if rank == 0 else 0)
+    f1 = torch.full((1, 2, 3, 4), 7.0, dtype=torch.float64) if mine1 else torch.zeros(0, 2, 0, 0, dtype=torch.float64)
+    ids1, all1 = pdist.gather_fields(torch.tensor(mine1, dtype=torch.int64), f1)
+    if rank == 0:
+        assert ids1.tolist() == [0] and tuple(all1.shape) == (1, 2, 3, 4) and float(all1.sum()) == 7.0 * 24
+    # ... and the other way round (the destination rank is the empty one)
+    f2 = torch.full((2, 2, 3, 4), 5.0, dtype=torch.float64) if rank == 1 else torch.zeros(0, 2, 0, 0, dtype=torch.float64)
+    ids2, all2 = pdist.gather_fields(torch.tensor([4, 3] if rank == 1 else [], dtype=torch.int64), f2)
+    if rank == 0:
+        assert ids2.tolist() == [3, 4] and tuple(all2.shape) == (2, 2, 3, 4)
     # cyclic policy partitions too
     cyc = pdist.shard_indices(n_pairs, rank, world, "cyclic")
     t = torch.zeros(n_pairs)
@@ -70,7 +83,7 @@ def test_gather_two_ranks():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    # 11 pairs: rank 0 owns 0..5, rank 1 owns 6..10 and dropped pair 7
+    # 11 pairs, balanced blocks: rank 0 owns 0..5, rank 1 owns 6..10 and dropped pair 7
     assert ids == [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]
     assert vals == [float(i) for i in ids]
 
@@ -83,3 +96,7 @@ def test_shard_indices_cover_everything():
                 got = sorted(sum((pdist.shard_indices(n, r, world, pol) for r in range(world)), []))
                 assert got == list(range(n))
     assert len(pdist.shard_indices(4000, 3, 8)) == 500
+    # balanced: 9 pairs on 8 ranks leave no rank empty, sizes differ by at most one
+    sizes = [len(pdist.shard_indices(9, r, 8)) for r in range(8)]
+    assert sizes == [2, 1, 1, 1, 1, 1, 1, 1]
+    assert [len(pdist.shard_indices(3, r, 8)) for r in range(8)] == [1, 1, 1, 0, 0, 0, 0, 0]

@@ -48,6 +48,11 @@ def near_tie_windows(a, b, ws, ov, rel=1e-5):
     return tie.reshape(nr, nc)
 
 
+def pass1_constant(a, b, ws, ov):
+    nr, nc = O.field_shape(a.shape, ws, ov)
+    return constant_windows(O.windows(a, ws, ov), O.windows(b, ws, ov), nr, nc)
+
+
 def fp32_noise_excuse(aa, bb, n_rows, n_cols, val_ratio=1.2, ulps=16.0):
     """Windows whose discrete decisions lie inside the float32 rounding band of the reference's
     own transform.  The reference correlates the raw (not mean-removed) windows in float32, so
@@ -73,13 +78,34 @@ def fp32_noise_excuse(aa, bb, n_rows, n_cols, val_ratio=1.2, ulps=16.0):
     return (tie | near).reshape(n_rows, n_cols)
 
 
-def check_fields(u, v, inv, ru, rv, rinv, what, max_flip_frac=0.01, excused=None, max_bad_frac=0.0):
+EXCUSE_CAP = 0.01      # at most 1 % of the windows of a fixture may be excusable (constant-input windows aside)
+
+
+def constant_windows(aa, bb, n_rows, n_cols):
+    """Windows whose staged input is constant in either frame (black / saturated blocks): their
+    correlation map is flat up to rounding, so every discrete decision on it is a coin toss."""
+    ca = aa.reshape(aa.shape[0], -1)
+    cb = bb.reshape(bb.shape[0], -1)
+    return ((ca.max(axis=1) == ca.min(axis=1)) | (cb.max(axis=1) == cb.min(axis=1))).reshape(n_rows, n_cols)
+
+
+def check_fields(u, v, inv, ru, rv, rinv, what, max_flip_frac=0.01, excused=None, max_bad_frac=0.0,
+                 constant=None, cap=EXCUSE_CAP):
+    """excused: windows whose discrete decisions are not reproducible by any other arithmetic (see
+    near_tie_windows / fp32_noise_excuse).  The set is CAPPED: windows in it that are not
+    constant-input windows (`constant`) may be at most `cap` of the fixture, so that it cannot grow
+    silently; the counts are printed."""
     u, v, inv = u.cpu().numpy(), v.cpu().numpy(), inv.cpu().numpy().astype(bool)
     assert u.shape == ru.shape, what
     flips = inv != rinv
     err = np.maximum(np.abs(u - ru), np.abs(v - rv))
     bad = (err > TOL_PX) & ~flips
     if excused is not None:
+        free = excused if constant is None else (excused & ~constant)
+        used = excused & (flips | (err > TOL_PX))
+        print(f"  [{what}] excusable windows {int(excused.sum())} of {excused.size} "
+              f"({int(free.sum())} not constant-input), actually differing {int(used.sum())}")
+        assert free.mean() <= cap, (what, "excuse set too large", int(free.sum()), excused.size)
         flips_x = flips & ~excused
         bad = bad & ~excused
     else:
@@ -99,7 +125,7 @@ def test_pass1_golden(eng, golden):
         u, v, inv = eng.pass1(dev(g[name + "_a"]), dev(g[name + "_b"]), ws, ov)
         tie = near_tie_windows(g[name + "_a"], g[name + "_b"], ws, ov)
         e, f = check_fields(u[0], v[0], inv[0], g[name + "_u"], g[name + "_v"], g[name + "_mask"], name,
-                            excused=tie)
+                            excused=tie, constant=pass1_constant(g[name + "_a"], g[name + "_b"], ws, ov))
         print(f"pass1 {name}: max err {e:.2e} px, mask flips {f}")
 
 
@@ -130,7 +156,7 @@ def test_shift_kats_bit_exact(eng, golden):
     assert np.array_equal(win[0, :, 0].cpu().numpy(), g["shift_dws"].astype(np.float32))
 
 
-@pytest.mark.parametrize("ws", [16, 32, 64])
+@pytest.mark.parametrize("ws", [16, 32, 64, 128])
 def test_border_rows_bit_exact(eng, ws):
     """Large shifts push whole window rows out of the frame (flat-index clamp: such a row reads the
     first / last pixel everywhere, partially-outside rows wrap into the neighbouring image row):
@@ -183,7 +209,8 @@ def test_corr_map_vs_oracle(eng, ws, ov, H, W):
     scale = ref.max(axis=(-2, -1), keepdims=True)
     assert np.abs(got - ref).max() / scale.max() < 2e-5, float((np.abs(got - ref) / scale).max())
     ou, ov_, _, _, om = O.pass1(a.numpy(), b.numpy(), ws, ov, validate=True)
-    check_fields(u[0], v[0], inv[0], ou, ov_, om, f"ws{ws}", excused=near_tie_windows(a.numpy(), b.numpy(), ws, ov))
+    check_fields(u[0], v[0], inv[0], ou, ov_, om, f"ws{ws}", excused=near_tie_windows(a.numpy(), b.numpy(), ws, ov),
+                 constant=pass1_constant(a.numpy(), b.numpy(), ws, ov))
 
 
 @pytest.mark.parametrize("mode", ["DWS", "CWS"])
@@ -222,35 +249,93 @@ def test_iteration_golden_per_pass(eng, golden, mode):
             exc = fp32_noise_excuse(aa, bb, nr, nc)
             e, f = check_fields(u[0], v[0], inv[0], g[f"{name}_{mode}_p{p}_u"], g[f"{name}_{mode}_p{p}_v"],
                                 g[f"{name}_{mode}_p{p}_val"], f"{name} {mode} pass {p}",
-                                max_flip_frac=0.0, max_bad_frac=0.0, excused=exc)
+                                max_flip_frac=0.0, max_bad_frac=0.0, excused=exc,
+                                constant=constant_windows(aa, bb, nr, nc))
             print(f"{name} {mode} pass {p} (ws {w}): max err {e:.2e} px, mask flips {f} of {inv[0].numel()} "
                   f"(all inside the reference's float32 noise band; {int(exc.sum())} windows are in it)")
 
 
+def staged_windows(a, b, H, W, w, o, mode, u2, v2):
+    """The windows a pass correlates, from a given half-shift field (tensors [1, nr, nc])."""
+    idx = O.window_index((H, W), w, o)
+    sh = (lambda t: t[0].cpu().numpy().reshape(-1)[:, None, None])
+    if mode == "CWS":
+        return (O.shift_cws(a, idx, -sh(u2).astype(np.float32), -sh(v2).astype(np.float32)),
+                O.shift_cws(b, idx, sh(u2).astype(np.float32), sh(v2).astype(np.float32)))
+    return (O.shift_dws(a, idx, -sh(u2).astype(np.int64), -sh(v2).astype(np.int64)),
+            O.shift_dws(b, idx, sh(u2).astype(np.int64), sh(v2).astype(np.int64)))
+
+
+def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, noise_ulps=16.0):
+    """The whole plan (all passes on the device, batch of 2) against the reference's fields of EVERY
+    pass, without a fraction threshold: a cell may differ from the reference (value beyond 1e-3 px or
+    other validity) only if
+      (a) its own discrete decisions lie in the reference's float32 noise band (fp32_noise_excuse on
+          the windows the reference staged; pass 1: near-tie windows), or
+      (b) it is downstream of a differing cell of the previous pass: the spline predictor weight
+          |Ay| M |Ax|^T that connects them is >= 1e-4 (a changed coarse vector moves the fine
+          predictor by weight x a few px).
+    Returns the per-pass counts."""
+    a, b = g[name + "_a"], g[name + "_b"]
+    H, W = a.shape
+    n_pass = len(geo)
+    plan = eng.Plan(H, W, geo[0][0], geo[0][1], n_pass=n_pass, mode=mode, pass_scale=scale, max_batch=2,
+                    precision=precision)
+    assert [list(t[:2]) for t in plan.geometry] == [list(t) for t in geo]
+    u, v, inv = plan.run(dev(np.stack([a, a])), dev(np.stack([b, b])))
+    assert torch.equal(u[0], u[1]) and torch.equal(inv[0], inv[1])       # batch items independent
+    prev_M = None
+    counts = []
+    for p in range(n_pass):
+        w, o = geo[p]
+        pu, pv, pi = plan.pass_fields(p, 2) if p < n_pass - 1 else (u, v, inv)
+        ru, rv, rval = (g[f"{name}_{mode}_p{p}_{k}"] for k in ("u", "v", "val"))
+        err = np.maximum(np.abs(pu[0].cpu().numpy() - ru), np.abs(pv[0].cpu().numpy() - rv))
+        M = (err > TOL_PX) | (pi[0].cpu().numpy().astype(bool) != rval)
+        nr, nc = O.field_shape((H, W), w, o)
+        if p == 0:
+            E = near_tie_windows(a, b, w, o) | pass1_constant(a, b, w, o)
+            D = np.zeros_like(M)
+        else:
+            wc, oc = geo[p - 1]
+            xc, yc = eng.coordinates_1d(H, W, wc, oc)
+            xf, yf = eng.coordinates_1d(H, W, w, o)
+            Ay_, Ax_ = eng.spline_matrix(yc, yf), eng.spline_matrix(xc, xf)
+            pre = [dev(g[f"{name}_{mode}_p{p-1}_{k}"])[None] for k in ("u", "v")]
+            _, _, u2, v2 = eng.predict(mode, dev(Ay_), dev(Ax_), pre[0], pre[1],
+                                       dev(g[f"{name}_{mode}_p{p-1}_val"].astype(np.uint8))[None])
+            aa, bb = staged_windows(a, b, H, W, w, o, mode, u2, v2)
+            E = fp32_noise_excuse(aa, bb, nr, nc, ulps=noise_ulps) | constant_windows(aa, bb, nr, nc)
+            D = (np.abs(Ay_) @ prev_M.astype(np.float64) @ np.abs(Ax_).T) >= 1e-4
+        unexplained = M & ~E & ~D
+        counts.append((int(M.sum()), int((M & E).sum()), int((M & ~E & D).sum()), int(unexplained.sum()), M.size))
+        print(f"  {name} {mode} {precision} pass {p} (ws {w}): differing {int(M.sum())} of {M.size}: "
+              f"{int((M & E).sum())} in the noise band, {int((M & ~E & D).sum())} downstream of pass {p - 1}, "
+              f"{int(unexplained.sum())} unexplained; downstream region covers {float(D.mean()):.2f} of the grid")
+        assert not unexplained.any(), (name, mode, precision, p, np.argwhere(unexplained)[:6].tolist(),
+                                       err[unexplained][:6].tolist())
+        prev_M = M
+    plan.close()
+    return counts
+
+
+@pytest.mark.parametrize("precision", ["reference", "fast"])
 @pytest.mark.parametrize("mode", ["DWS", "CWS"])
-def test_multipass_plan_end_to_end(eng, golden, mode):
-    """The whole plan (all passes on the device, batch of 2) against the reference's final fields.
-    A flipped validity decision in pass p moves the predictor of the ~25-50 finer windows around it,
-    so the cascade is judged statistically; the per-pass test above is the strict one."""
+def test_multipass_plan_end_to_end(eng, golden, mode, precision):
+    """Whole-plan cascade on every multipass golden; see cascade_check for the (threshold-free) rule.
+    precision="reference" runs pass 1 in float64 like the reference, so that no pass-1 rounding leaks
+    into the later passes; "fast" is the float32 pass 1, whose ~1e-6 px deviations may tip decisions
+    that sit within 1e-4 (relative) of a threshold in later passes (wider noise band)."""
     g = golden("g4_multipass")
     for name in g["names"]:
         ws, ov, n_pass = (int(t) for t in g[name + "_cfg"])
-        a, b = g[name + "_a"], g[name + "_b"]
-        H, W = a.shape
-        plan = eng.Plan(H, W, ws, ov, n_pass=n_pass, mode=mode, max_batch=2)
-        A = dev(np.stack([a, a]))
-        B = dev(np.stack([b, b]))
-        u, v, inv = plan.run(A, B)
-        assert torch.equal(u[0], u[1]) and torch.equal(inv[0], inv[1])       # batch items independent
-        for p in range(n_pass):
-            pu, pv, pi = plan.pass_fields(p, 2) if p < n_pass - 1 else (u, v, inv)
-            ru, rv, rval = (g[f"{name}_{mode}_p{p}_{k}"] for k in ("u", "v", "val"))
-            err = np.maximum(np.abs(pu[0].cpu().numpy() - ru), np.abs(pv[0].cpu().numpy() - rv))
-            same = pi[0].cpu().numpy().astype(bool) == rval
-            frac = float(((err <= TOL_PX) & same).mean())
-            print(f"{name} {mode} pass {p}: {frac:.4f} of vectors within {TOL_PX} px and same validity")
-            assert frac >= (0.999 if p == 0 else 0.93), (name, mode, p, frac)
-        plan.close()
+        geo = [(ws >> p, ov >> p) for p in range(n_pass)]
+        counts = cascade_check(eng, g, name, mode, precision, geo,
+                               noise_ulps=16.0 if precision == "reference" else 4096.0)
+        # sanity on top of the rule: differing cells stay a small minority unless the fixture has
+        # constant-input blocks ("special")
+        if "special" not in name:
+            assert all(c[0] <= 0.08 * c[4] for c in counts), counts
 
 
 @pytest.mark.parametrize("mode", ["DWS", "CWS"])
@@ -324,7 +409,7 @@ def test_generic_sizes_pass1(eng, golden):
         u, v, inv = eng.pass1(dev(a), dev(b), ws, ov)
         tie = near_tie_windows(a, b, ws, ov)
         e, f = check_fields(u[0], v[0], inv[0], g[name + "_u"], g[name + "_v"], g[name + "_mask"], name,
-                            excused=tie)
+                            excused=tie, constant=pass1_constant(a, b, ws, ov))
         print(f"generic pass1 {name} (ws {ws}): max err {e:.2e} px, mask flips {f}")
 
 
@@ -360,53 +445,66 @@ def test_generic_sizes_multipass(eng, golden, mode):
             nr, nc = O.field_shape((H, W), w, o)
             e, f = check_fields(u[0], v[0], inv[0], g[f"{name}_{mode}_p{p}_u"], g[f"{name}_{mode}_p{p}_v"],
                                 g[f"{name}_{mode}_p{p}_val"], f"{name} {mode} pass {p}",
-                                max_flip_frac=0.0, max_bad_frac=0.0, excused=fp32_noise_excuse(aa, bb, nr, nc))
+                                max_flip_frac=0.0, max_bad_frac=0.0, excused=fp32_noise_excuse(aa, bb, nr, nc),
+                                constant=constant_windows(aa, bb, nr, nc))
             print(f"generic {name} {mode} pass {p} (ws {w}/{o}): max err {e:.2e} px, mask flips {f}")
-        plan = eng.Plan(H, W, int(geo[0][0]), int(geo[0][1]), n_pass=len(geo), mode=mode, pass_scale=scale,
-                        max_batch=1)
-        assert [list(t[:2]) for t in plan.geometry] == geo.tolist()
-        u, v, inv = plan.run(da, db)
-        last = len(geo) - 1
-        err = np.maximum(np.abs(u[0].cpu().numpy() - g[f"{name}_{mode}_p{last}_u"]),
-                         np.abs(v[0].cpu().numpy() - g[f"{name}_{mode}_p{last}_v"]))
-        same = inv[0].cpu().numpy().astype(bool) == g[f"{name}_{mode}_p{last}_val"]
-        assert ((err <= TOL_PX) & same).mean() >= 0.93
-        plan.close()
+        for precision in ("reference", "fast"):
+            cascade_check(eng, g, name, mode, precision, [(int(t[0]), int(t[1])) for t in geo], scale=scale,
+                          noise_ulps=16.0 if precision == "reference" else 4096.0)
 
 
-@pytest.mark.parametrize("ws", [8, 16])
-def test_peak_logic_on_handmade_maps(eng, golden, ws):
+@pytest.mark.parametrize("ws,planar", [(8, False), (8, True), (16, False), (16, True), (32, False), (32, True),
+                                       (64, False), (64, True), (128, False)])
+def test_peak_logic_on_handmade_maps(eng, golden, ws, planar):
     """correlation_to_displacement + peak2peak_secondpeak on crafted maps: every one-sided fix-up
     (m = 0, 1, k, k*d-2, k*(d-1)-1, last column -> first pixel of the next row), the wrap and the clamps
     of the second-peak exclusion zone, ties, constant maps -- compared with the oracle, which the CPU
-    suite pins to the reference on the same tables (tests/golden/g6_kats.npz)."""
+    suite pins to the reference on the same tables (tests/golden/g6_kats.npz).  Every peak stage is
+    covered: the tile kernel's whole-map form, its planar form (64x64: the three-row map of the
+    three-wavefront kernels) and the 128x128 stage of xcorr_big.hpp."""
     g = golden("g6_kats")
     rng = np.random.default_rng(100 + ws)
     maps = []
     if ws == 16:
         maps += [m for m in g["c2d16_maps"] if np.isfinite(m).all()]
-    else:
+    elif ws == 8:
         maps += list(g["c2d8_maps"])
     n = ws * ws
-    specials = [0, 1, ws - 1, ws, ws + 1, n - ws - 1, n - ws, n - 2, n - 1, n // 2 + ws // 2, 5 * ws - 1, 6 * ws]
+    specials = [0, 1, 2, ws - 2, ws - 1, ws, ws + 1, 2 * ws - 1, 2 * ws, n - 2 * ws, n - ws - 1, n - ws, n - ws + 1,
+                n - 3, n - 2, n - 1, n // 2 + ws // 2, n // 2 + ws // 2 - 1, 5 * ws - 1, 6 * ws, 3 * ws + 3,
+                n - 3 * ws - 4, (ws // 2) * ws, (ws // 2) * ws + ws - 1]
+    rivals = (None, 4, -4, 3, -3, 3 * ws + 3, -(3 * ws + 3), 3 * ws + 4, 4 * ws, -4 * ws, ws - 3, ws - 4, -(ws - 3),
+              "first", "last")
     for m in specials:                      # a peak at every special flat index, rivals near the wraps
-        for rival in (None, (m + 4) % n, (m - 4) % n, (m + 3 * ws + 3) % n, (m + 4 * ws) % n, 0, n - 1):
+        for rv in rivals:
             a = rng.random((ws, ws)) * 5 + 1
             a.flat[m] = 100.0
             if m + 1 < n:
                 a.flat[m + 1] = 60.0
             if m - 1 >= 0:
                 a.flat[m - 1] = 40.0
-            if rival is not None and rival != m:
-                a.flat[rival] = max(a.flat[rival], 90.0 if (rival + m) % 2 else 80.0)
+            if m + ws < n:
+                a.flat[m + ws] = 55.0
+            if m - ws >= 0:
+                a.flat[m - ws] = 35.0
+            if rv is not None:
+                rival = 0 if rv == "first" else (n - 1 if rv == "last" else (m + rv) % n)
+                if rival != m:
+                    a.flat[rival] = max(a.flat[rival], 90.0 if (rival + m) % 2 else 80.0)
             maps.append(a)
     maps += [rng.random((ws, ws)) * 10 for _ in range(64)]
+    tie = np.ones((ws, ws))
+    tie[ws // 4, ws // 4] = tie[ws // 2 + 1, ws // 2 + 2] = 50.0     # exact tie: first flat index wins, invalid
+    maps += [tie, np.full((ws, ws), 5.0)]                             # constant map: u = v = 0... (m = 0), invalid
     maps = np.stack(maps).astype(np.float32)
     maps = maps - maps.min(axis=(-2, -1), keepdims=True)          # the kernel applies B:518 itself
-    u, v, inv = eng.debug_peaks(torch.from_numpy(maps).cuda())
+    u, v, inv = eng.debug_peaks(torch.from_numpy(maps).cuda(), planar=planar)
     ou, ov, om = O.corr_to_disp(maps.copy(), maps.shape[0], 1, validate=True)
-    assert np.array_equal(inv.cpu().numpy().astype(bool), om[:, 0])
-    assert np.abs(u.cpu().numpy() - ou[:, 0]).max() < 1e-9 and np.abs(v.cpu().numpy() - ov[:, 0]).max() < 1e-9
+    bad = np.flatnonzero(inv.cpu().numpy().astype(bool) != om[:, 0])
+    assert bad.size == 0, (ws, planar, bad[:8].tolist())
+    du, dv = np.abs(u.cpu().numpy() - ou[:, 0]), np.abs(v.cpu().numpy() - ov[:, 0])
+    assert du.max() < 1e-9 and dv.max() < 1e-9, (ws, planar, int(du.argmax()), float(du.max()), int(dv.argmax()),
+                                                 float(dv.max()))
 
 
 def test_errors(eng):

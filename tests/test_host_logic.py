@@ -22,7 +22,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(_lib.lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.lib.tpiv_version() == 1
+    assert _lib.lib.tpiv_version() == _lib.ABI_VERSION == 2
 
 
 def test_geometry_matches_reference(golden):

@@ -128,3 +128,27 @@ def test_generic_sizes(golden):
                 u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
                 assert np.abs(u - g[f"{name}_{mode}_p{p}_u"]).max() <= 1e-9, (name, mode, p)
                 assert np.array_equal(val, g[f"{name}_{mode}_p{p}_val"]), (name, mode, p)
+
+
+def test_round2_goldens(golden):
+    """g8: 256/128 -> 128/64 multipass (the only route to shifted 128-pixel windows) and the
+    generator at configs[0]'s geometry (64/32, one pass)."""
+    g = golden("g8_round2")
+    name = "big256x2"
+    ws, ov, n_pass = (int(t) for t in g[name + "_cfg"])
+    a, b = g[name + "_a"], g[name + "_b"]
+    for mode in ("DWS", "CWS"):
+        u, v, x, y, val = O.pass1(a, b, ws, ov, validate=True)
+        assert np.abs(u - g[f"{name}_{mode}_p0_u"]).max() <= TOL
+        it = O.ITER[mode](a.shape, ws // 2, ov // 2)
+        u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
+        assert np.abs(u - g[f"{name}_{mode}_p1_u"]).max() <= 1e-9 and np.abs(v - g[f"{name}_{mode}_p1_v"]).max() <= 1e-9
+        assert np.array_equal(val, g[f"{name}_{mode}_p1_val"])
+    ws, ov, mp, mode, dt = (int(t) for t in g["r5_kw"])
+    res = list(O.offline_piv(zip(g["r5_frames_a"], g["r5_frames_b"]), ws, ov, multipass=mp,
+                             mode=("DWS", "CWS")[mode], dt=dt, scale=float(g["r5_scale"][0])))
+    assert len(res) == int(g["r5_count"][1]) and len(res) > 0
+    for j, (x, y, u, v) in enumerate(res):
+        assert np.array_equal(x, g[f"r5_{j}_x"]) and np.array_equal(y, g[f"r5_{j}_y"])
+        assert np.allclose(u, g[f"r5_{j}_u"], rtol=0, atol=1e-9, equal_nan=True)
+        assert np.allclose(v, g[f"r5_{j}_v"], rtol=0, atol=1e-9, equal_nan=True)

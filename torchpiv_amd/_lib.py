@@ -15,6 +15,9 @@ LIB_PATH = os.environ.get("TPIV_LIB") or os.path.join(_HERE, "libtorchpiv_hip.so
 OK, EINVAL, EKEY, EHIP, ENOMEM, EUNSUPPORTED = 0, 1, 2, 3, 4, 5
 MODE_DWS, MODE_CWS = 1, 2
 MODES = {"DWS": MODE_DWS, "CWS": MODE_CWS}
+PREC_FAST, PREC_REFERENCE = 0, 1
+PRECISIONS = {"fast": PREC_FAST, "reference": PREC_REFERENCE}
+ABI_VERSION = 2
 
 
 class HipError(RuntimeError):
@@ -46,13 +49,16 @@ SIGNATURES = {
     "tpiv_coordinates": (C.c_int, [_int, _int, _int, _int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tpiv_spline_matrix": (C.c_int, [_int, C.POINTER(C.c_double), _int, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double)]),
-    "tpiv_pass1": (C.c_int, [_u8p, _u8p, _int, _int, _int, _int, _int, _dbl, _int, _f64p, _f64p, _u8p, _vp]),
+    "tpiv_pass1": (C.c_int, [_u8p, _u8p, _int, _int, _int, _int, _int, _dbl, _int, _int, _f64p, _f64p, _u8p,
+                             _vp, C.c_size_t, _vp]),
+    "tpiv_work_bytes": (C.c_size_t, [_int, _int, _int, _int, _int]),
     "tpiv_predict": (C.c_int, [_int, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p, _f64p, _u8p,
                                _f64p, _f64p, _f64p, _f64p, _f64p, _vp]),
     "tpiv_iter": (C.c_int, [_int, _u8p, _u8p, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p, _f64p,
-                            _dbl, _int, _f64p, _f64p, _u8p, _f64p, _f64p, _vp]),
+                            _dbl, _int, _f64p, _f64p, _u8p, _f64p, _f64p, _vp, C.c_size_t, _vp]),
     "tpiv_plan_create": (C.c_int, [C.POINTER(C.c_void_p), _int, _int, _int, _int, _int, _int, _dbl, _dbl,
-                                   _int, _int]),
+                                   _int, _int, _int]),
+    "tpiv_plan_kernel_name": (C.c_char_p, [C.c_void_p, _int, C.c_char_p, _int]),
     "tpiv_plan_destroy": (None, [C.c_void_p]),
     "tpiv_plan_n_pass": (C.c_int, [C.c_void_p]),
     "tpiv_plan_pass_geometry": (C.c_int, [C.c_void_p, _int, C.POINTER(C.c_int), C.POINTER(C.c_int),
@@ -64,15 +70,20 @@ SIGNATURES = {
     "tpiv_plan_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), _int, C.POINTER(C.c_int)]),
     "tpiv_plan_debug_predict": (C.c_int, [C.c_void_p, _int, _int, _f64p, _f64p, _u8p, _f64p, _f64p, _f64p,
                                           _f64p, _vp]),
-    "tpiv_debug_peaks": (C.c_int, [_f32p, _int, _int, _dbl, _int, _f64p, _f64p, _u8p, _vp]),
-    "tpiv_debug_pass": (C.c_int, [_int, _u8p, _u8p, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p,
-                                  _f64p, _u8p, _f32p, _f32p, _vp]),
+    "tpiv_debug_peaks": (C.c_int, [_f32p, _int, _int, _int, _dbl, _int, _f64p, _f64p, _u8p, _vp, C.c_size_t, _vp]),
+    "tpiv_debug_pass": (C.c_int, [_int, _u8p, _u8p, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p, _f64p,
+                                  _f64p, _u8p, _f32p, _f32p, _vp, C.c_size_t, _vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)        # AttributeError if the library lacks a declared symbol
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+if lib.tpiv_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} has ABI version {lib.tpiv_version()}, this package needs {ABI_VERSION}: rebuild "
+                      "(make -C torchpiv_amd/csrc)")
 
 
 def check(rc: int) -> None:

@@ -117,13 +117,14 @@ def moving_window_array(array: torch.Tensor, window_size, overlap) -> torch.Tens
 # pass 1 (B:459-520)
 # ----------------------------------------------------------------------------------------
 def extended_search_area_piv(frame_a, frame_b, window_size=32, overlap=0, validate: bool = False,
-                             validation_ratio: float = 1.2):
+                             validation_ratio: float = 1.2, precision: str = "fast"):
     """First-pass PIV of one pair.  frame_a / frame_b: uint8 tensors [H, W] on a ROCm device.
     Returns (u, v, x, y, mask) as numpy arrays like the reference (mask None if not validate).
-    Raises ValueError for overlap >= window_size or a window larger than the image."""
+    Raises ValueError for overlap >= window_size or a window larger than the image.
+    precision (extension): "fast" = float32 transforms, "reference" = float64 like B:513-514."""
     H, W = frame_a.shape[-2], frame_a.shape[-1]
     u, v, inv = engine.pass1(frame_a, frame_b, int(window_size), int(overlap),
-                             val_ratio=float(validation_ratio))
+                             val_ratio=float(validation_ratio), precision=precision)
     x, y = get_coordinates((H, W), window_size, overlap)
     mask = inv[0].cpu().numpy().astype(bool) if validate else None
     return u[0].cpu().numpy(), v[0].cpu().numpy(), x, y, mask
@@ -274,7 +275,12 @@ class OfflinePIV:
 
     def __init__(self, folder: str, device: str, file_fmt: str, wind_size: int, overlap: int,
                  multipass: int = 1, multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.,
-                 multipass_scale: float = 2., folder_mode: str = "pairs") -> None:
+                 multipass_scale: float = 2., folder_mode: str = "pairs", precision: str = "fast") -> None:
+        # precision (extension, keyword after the reference's arguments): "fast" runs pass 1 in float32,
+        # "reference" in float64 like the reference (B:513-514); later passes are float32 in both.
+        if precision not in ("fast", "reference"):
+            raise KeyError(precision)
+        self._precision = precision
         self._wind_size = wind_size
         self._overlap = overlap
         self._dt = dt
@@ -293,6 +299,14 @@ class OfflinePIV:
     def __len__(self) -> int:
         return len(self._dataset)
 
+    def frame_shape(self):
+        """(H, W) of the first decodable pair, None for an empty / undecodable folder."""
+        for i in range(len(self._dataset)):
+            a, _ = self._dataset[i]
+            if a is not None:
+                return tuple(a.shape)
+        return None
+
     def _get_plan(self, H, W, max_batch=1):
         if (self._plan is None or (self._plan.H, self._plan.W) != (H, W)
                 or self._plan.max_batch < max_batch):
@@ -301,7 +315,7 @@ class OfflinePIV:
             self._plan = engine.Plan(H, W, int(self._wind_size), int(self._overlap),
                                      n_pass=max(1, int(self._iter)), mode=self._mode,
                                      pass_scale=self._iter_scale, max_batch=max_batch,
-                                     device=self._device)
+                                     device=self._device, precision=self._precision)
         return self._plan
 
     def _finish(self, u, v, val, x, y):

@@ -33,43 +33,18 @@ int hip_fail(hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail(e_, #expr); \
     } while (0)
 
-// Workspace of the function-level seam (tpiv_pass1 / tpiv_iter / tpiv_debug_pass): the raw peak
-// records between the tile kernel and the finalize kernel.  One grow-only buffer per device, kept
-// by the library (a plan owns its own and never touches this one).
-struct Scratch {
-    int device = -1;
-    float* ptr = nullptr;
-    size_t bytes = 0;
-};
-Scratch g_scratch[16];
-
-int scratch_for(size_t bytes, float** out) {
-    *out = nullptr;
-    if (bytes == 0) return TPIV_OK;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return fail(TPIV_EUNSUPPORTED, "device index above 15");
-    Scratch& s = g_scratch[dev];
-    if (s.bytes < bytes) {
-        if (s.ptr) {
-            HIP_TRY(hipDeviceSynchronize());
-            (void)hipFree(s.ptr);
-            s.ptr = nullptr;
-            s.bytes = 0;
-        }
-        void* q = nullptr;
-        hipError_t e = hipMalloc(&q, bytes);
-        if (e != hipSuccess) return fail(TPIV_ENOMEM, std::string("hipMalloc(scratch): ") + hipGetErrorString(e));
-        s.ptr = static_cast<float*>(q);
-        s.bytes = bytes;
-        s.device = dev;
-    }
-    *out = s.ptr;
+// The function-level seam (tpiv_pass1 / tpiv_iter / tpiv_debug_*) works in a caller-provided buffer:
+// the library keeps no device state between calls.
+int check_work(const void* work, size_t have, size_t need) {
+    if (need == 0) return TPIV_OK;
+    if (!work || have < need)
+        return fail(TPIV_EINVAL, "work buffer too small: need " + std::to_string(need) + " bytes (tpiv_work_bytes), got " +
+                                     std::to_string(have));
     return TPIV_OK;
 }
 
-// 8/16/32/64: second-generation tile kernel; 128: first-generation; anything else in 2..256:
-// generic-size DFT kernel (xcorr_generic.hip)
+// 8/16/32/64: tile kernel (xcorr_tile.hpp); 128 pass 1: xcorr_big.hpp; anything else in 2..256 (and
+// shifted 128x128 passes): generic-size DFT kernel (xcorr_generic.hip)
 bool supported_ws(int ws) { return ws >= 2 && ws <= 256; }
 
 // B:503-507 argument checks, then what the kernels cover
@@ -227,7 +202,7 @@ struct PassGeo {
 }  // namespace
 
 struct tpiv_plan {
-    int H = 0, W = 0, n_pass = 0, mode = 0, max_batch = 0, val_win = 3, device = 0;
+    int H = 0, W = 0, n_pass = 0, mode = 0, max_batch = 0, val_win = 3, device = 0, precision = 0;
     double val_ratio = 1.2;
     std::vector<PassGeo> geo;
     // device workspace
@@ -240,6 +215,7 @@ struct tpiv_plan {
     std::vector<int> ku, bwx, bwg, seg_len;
     double *u0 = nullptr, *v0 = nullptr, *u2 = nullptr, *v2 = nullptr, *T = nullptr;
     float* peak_raw = nullptr;           // [max_batch, max N_p, 8] hand-off tile kernel -> finalize
+    size_t peak_raw_bytes = 0;
     std::vector<void*> allocs;
     // optional per-kernel timing: events[run][2*slot + {0,1}]
     bool timing = false;
@@ -417,10 +393,12 @@ int tpiv_spline_matrix(int nc, const double* xc, int nf, const double* xf, doubl
 }
 
 static int pass1_impl(const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws, int ov,
-                      double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, float* peak_raw,
-                      float* dbg_win, float* dbg_corr, void* stream) {
+                      double val_ratio, int val_win, int precision, double* u, double* v, uint8_t* invalid,
+                      void* work, size_t work_bytes, float* dbg_win, float* dbg_corr, void* stream) {
     int rc = check_window(H, W, ws, ov, val_win);
     if (rc) return rc;
+    if (precision != TPIV_PREC_FAST && precision != TPIV_PREC_REFERENCE)
+        return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST or TPIV_PREC_REFERENCE");
     if (batch <= 0) return TPIV_OK;
     tpiv::PassParams p{};
     p.dbg_win = dbg_win;
@@ -439,11 +417,10 @@ static int pass1_impl(const uint8_t* a, const uint8_t* b, int batch, int H, int 
     p.val_ratio = val_ratio;
     p.val_win = val_win;
     p.stamps = g_stamps;
-    p.peak_raw = peak_raw;
-    if (!peak_raw) {       // function-level call: library-owned scratch
-        rc = scratch_for(tpiv::peak_raw_bytes(ws, batch, p.n_rows * p.n_cols), &p.peak_raw);
-        if (rc) return rc;
-    }
+    p.precision = precision;
+    rc = check_work(work, work_bytes, tpiv::peak_raw_bytes(ws, batch, p.n_rows * p.n_cols, precision));
+    if (rc) return rc;
+    p.peak_raw = static_cast<float*>(work);
     int n_cu;
     rc = n_cu_of_current_device(&n_cu);
     if (rc) return rc;
@@ -452,9 +429,17 @@ static int pass1_impl(const uint8_t* a, const uint8_t* b, int batch, int H, int 
 }
 
 int tpiv_pass1(const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws, int ov,
-               double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, void* stream) {
-    return pass1_impl(a, b, batch, H, W, ws, ov, val_ratio, val_win, u, v, invalid, nullptr, nullptr, nullptr,
-                      stream);
+               double val_ratio, int val_win, int precision, double* u, double* v, uint8_t* invalid,
+               void* work, size_t work_bytes, void* stream) {
+    return pass1_impl(a, b, batch, H, W, ws, ov, val_ratio, val_win, precision, u, v, invalid, work, work_bytes,
+                      nullptr, nullptr, stream);
+}
+
+size_t tpiv_work_bytes(int H, int W, int ws, int ov, int batch) {
+    if (ov >= ws || ws > H || ws > W || ws <= 0 || ov < 0 || batch <= 0 || !supported_ws(ws)) return 0;
+    int nr, nc;
+    field_shape(H, W, ws, ov, &nr, &nc);
+    return tpiv::peak_raw_bytes(ws, batch, nr * nc, TPIV_PREC_REFERENCE);      // the larger of the two
 }
 
 int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf, const double* Ay,
@@ -486,7 +471,7 @@ int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf, const 
 static int run_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
                     int ov, const double* u0, const double* v0, const double* u2, const double* v2,
                     double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, double* du,
-                    double* dv, float* dbg_win, float* dbg_corr, float* peak_raw, void* stream) {
+                    double* dv, float* dbg_win, float* dbg_corr, void* work, size_t work_bytes, void* stream) {
     if (mode != TPIV_MODE_DWS && mode != TPIV_MODE_CWS) return fail(TPIV_EKEY, "unknown multipass mode");
     int rc = check_window(H, W, ws, ov, val_win);
     if (rc) return rc;
@@ -514,11 +499,9 @@ static int run_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int
     p.dbg_win = dbg_win;
     p.dbg_corr = dbg_corr;
     p.stamps = g_stamps;
-    p.peak_raw = peak_raw;
-    if (!peak_raw) {
-        rc = scratch_for(tpiv::peak_raw_bytes(ws, batch, p.n_rows * p.n_cols), &p.peak_raw);
-        if (rc) return rc;
-    }
+    rc = check_work(work, work_bytes, tpiv::peak_raw_bytes(ws, batch, p.n_rows * p.n_cols, TPIV_PREC_FAST));
+    if (rc) return rc;
+    p.peak_raw = static_cast<float*>(work);
     int n_cu;
     rc = n_cu_of_current_device(&n_cu);
     if (rc) return rc;
@@ -529,36 +512,26 @@ static int run_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int
 int tpiv_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws, int ov,
               const double* u0, const double* v0, const double* u2, const double* v2,
               double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, double* du,
-              double* dv, void* stream) {
+              double* dv, void* work, size_t work_bytes, void* stream) {
     return run_iter(mode, a, b, batch, H, W, ws, ov, u0, v0, u2, v2, val_ratio, val_win, u, v, invalid,
-                    du, dv, nullptr, nullptr, nullptr, stream);
+                    du, dv, nullptr, nullptr, work, work_bytes, stream);
 }
 
 int tpiv_debug_pass(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
-                    int ov, const double* u2, const double* v2, double* u, double* v,
-                    uint8_t* invalid, float* win, float* corr, void* stream) {
+                    int ov, const double* u2, const double* v2, const double* zero, double* u, double* v,
+                    uint8_t* invalid, float* win, float* corr, void* work, size_t work_bytes, void* stream) {
     if (mode == 0)
-        return pass1_impl(a, b, batch, H, W, ws, ov, 1.2, 3, u, v, invalid, nullptr, win, corr, stream);
-    int nr, nc;
-    int rc = tpiv_field_shape(H, W, ws, ov, &nr, &nc);
-    if (rc) return rc;
-    const size_t n = (size_t)batch * nr * nc;
-    double* zero = nullptr;
-    HIP_TRY(hipMalloc((void**)&zero, n * sizeof(double)));
-    hipError_t e = hipMemsetAsync(zero, 0, n * sizeof(double), (hipStream_t)stream);
-    if (e == hipSuccess) {
-        rc = run_iter(mode, a, b, batch, H, W, ws, ov, zero, zero, u2, v2, 1.2, 3, u, v, invalid, nullptr,
-                      nullptr, win, corr, nullptr, stream);
-        e = hipStreamSynchronize((hipStream_t)stream);
-    }
-    (void)hipFree(zero);
-    if (e != hipSuccess) return hip_fail(e, "tpiv_debug_pass");
-    return rc;
+        return pass1_impl(a, b, batch, H, W, ws, ov, 1.2, 3, TPIV_PREC_FAST, u, v, invalid, work, work_bytes, win,
+                          corr, stream);
+    if (!zero || !u2 || !v2) return fail(TPIV_EINVAL, "tpiv_debug_pass: shifted passes need u2, v2 and a zero field");
+    return run_iter(mode, a, b, batch, H, W, ws, ov, zero, zero, u2, v2, 1.2, 3, u, v, invalid, nullptr, nullptr,
+                    win, corr, work, work_bytes, stream);
 }
 
-int tpiv_debug_peaks(const float* maps, int n_maps, int ws, double val_ratio, int val_win, double* u,
-                     double* v, uint8_t* invalid, void* stream) {
-    if (ws != 8 && ws != 16) return fail(TPIV_EUNSUPPORTED, "tpiv_debug_peaks handles 8x8 and 16x16 maps");
+int tpiv_debug_peaks(const float* maps, int n_maps, int ws, int planar, double val_ratio, int val_win, double* u,
+                     double* v, uint8_t* invalid, void* work, size_t work_bytes, void* stream) {
+    if (ws != 8 && ws != 16 && ws != 32 && ws != 64 && ws != 128)
+        return fail(TPIV_EUNSUPPORTED, "tpiv_debug_peaks handles 8, 16, 32, 64 and 128 pixel maps");
     if (n_maps <= 0) return TPIV_OK;
     tpiv::PassParams p{};
     p.batch = 1;
@@ -570,14 +543,15 @@ int tpiv_debug_peaks(const float* maps, int n_maps, int ws, double val_ratio, in
     p.val = invalid;
     p.val_ratio = val_ratio;
     p.val_win = val_win;
-    int rc = scratch_for((size_t)n_maps * 8 * sizeof(float), &p.peak_raw);
+    int rc = check_work(work, work_bytes, (size_t)n_maps * 8 * sizeof(float));
     if (rc) return rc;
-    HIP_TRY(tpiv::launch_peaks_from_maps(p, maps, n_maps, (hipStream_t)stream));
+    p.peak_raw = static_cast<float*>(work);
+    HIP_TRY(tpiv::launch_peaks_from_maps(p, maps, n_maps, planar, (hipStream_t)stream));
     return TPIV_OK;
 }
 
 int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, int mode,
-                     double pass_scale, double val_ratio, int val_win, int max_batch) {
+                     double pass_scale, double val_ratio, int val_win, int max_batch, int precision) {
     if (!out) return fail(TPIV_EINVAL, "null plan pointer");
     *out = nullptr;
     if (n_pass < 1) n_pass = 1;     // range(multipass - 1) is empty for multipass <= 1 (B:855)
@@ -585,7 +559,10 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
         return fail(TPIV_EKEY, "unknown multipass mode");
     if (max_batch < 1) return fail(TPIV_EINVAL, "max_batch must be >= 1");
     if (!(pass_scale > 0)) return fail(TPIV_EINVAL, "multipass_scale must be positive");
+    if (precision != TPIV_PREC_FAST && precision != TPIV_PREC_REFERENCE)
+        return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST or TPIV_PREC_REFERENCE");
     tpiv_plan* pl = new tpiv_plan();
+    pl->precision = precision;
     pl->H = H;
     pl->W = W;
     pl->n_pass = n_pass;
@@ -663,10 +640,13 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
     }
     if (rc == TPIV_OK) {
         size_t raw = 0;
-        for (const PassGeo& g : pl->geo) {
-            const size_t b = tpiv::peak_raw_bytes(g.ws, max_batch, g.n_rows * g.n_cols);
+        for (size_t i = 0; i < pl->geo.size(); ++i) {
+            const PassGeo& g = pl->geo[i];
+            const size_t b = tpiv::peak_raw_bytes(g.ws, max_batch, g.n_rows * g.n_cols,
+                                                  i == 0 ? precision : (int)TPIV_PREC_FAST);
             if (b > raw) raw = b;
         }
+        pl->peak_raw_bytes = raw;
         if (raw) rc = pl->alloc(&pl->peak_raw, raw / sizeof(float) + 64);
     }
     if (rc == TPIV_OK && n_pass > 1) {
@@ -698,6 +678,14 @@ int tpiv_plan_pass_geometry(const tpiv_plan* plan, int pass, int* ws, int* ov, i
     if (n_rows) *n_rows = g.n_rows;
     if (n_cols) *n_cols = g.n_cols;
     return TPIV_OK;
+}
+
+const char* tpiv_plan_kernel_name(const tpiv_plan* plan, int pass, char* buf, int len) {
+    if (!buf || len <= 0) return buf;
+    buf[0] = 0;
+    if (!plan || pass < 0 || pass >= plan->n_pass) return buf;
+    const int mode = pass == 0 ? (int)tpiv::MODE_PASS1 : plan->mode;
+    return tpiv::xcorr_kernel_name(plan->geo[pass].ws, mode, pass == 0 ? plan->precision : 0, buf, len);
 }
 
 int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u, double** v, uint8_t** invalid) {
@@ -773,8 +761,9 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
         int rc;
         if (p == 0) {
             mark(0, 0);
-            rc = pass1_impl(a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->val_ratio, plan->val_win, pu, pv,
-                            pval, plan->peak_raw, nullptr, nullptr, stream);
+            rc = pass1_impl(a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->val_ratio, plan->val_win,
+                            plan->precision, pu, pv, pval, plan->peak_raw, plan->peak_raw_bytes, nullptr, nullptr,
+                            stream);
             mark(0, 1);
         } else {
             const PassGeo& c = plan->geo[p - 1];
@@ -786,7 +775,7 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
             if (!rc)
                 rc = run_iter(plan->mode, a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->u0, plan->v0,
                               plan->u2, plan->v2, plan->val_ratio, plan->val_win, pu, pv, pval, nullptr,
-                              nullptr, nullptr, nullptr, plan->peak_raw, stream);
+                              nullptr, nullptr, nullptr, plan->peak_raw, plan->peak_raw_bytes, stream);
             mark(2 * p, 1);
         }
         if (rc) return rc;

@@ -26,12 +26,14 @@ struct PassParams {
     double* dv;
     double val_ratio;
     int val_win;
+    int precision;         // pass 1 only: 0 = float32 kernels, 1 = float64 (TPIV_PREC_REFERENCE)
     // test hooks (nullptr in production)
     float* dbg_win;        // [batch, N, 2, ws, ws] staged windows (after the shift)
     float* dbg_corr;       // [batch, N, ws, ws] corr - min + eps, fftshift layout
     unsigned long long* stamps;   // diagnostic build (-DTPIV_STAMPS) only: per-phase cycle sums
-    // workspace [batch, N, 8] float32 between the tile kernel and finalize_kernel (WS <= 64):
+    // workspace [batch, N, 8] float32 between the tile kernel and finalize_kernel:
     // {c[m], c[left], c[right], c[top], c[bot], c[m2], bits(m), bits(dead)} per window
+    // (float64 pass 1: 8 doubles per window, m and dead stored as values)
     float* peak_raw;
     unsigned* work_ctr;      // 8 x 16 dwords: per-XCD item counters of the tile kernel (set by launch_xcorr)
     // n / d for n < 2^31 as (n * magic) >> shift (set by the tile launcher; keeps the per-item index
@@ -85,9 +87,19 @@ struct BandedPredictParams {
 };
 
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream);
-// bytes of PassParams::peak_raw a pass needs (0 for the 128x128 kernel, which fuses its epilogue)
-size_t peak_raw_bytes(int ws, int batch, int n_windows);
-hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_maps, hipStream_t stream);
+// wavefronts per SIMD the tile kernel of (ws, mode) is built for (the OCC template argument of
+// xcorr_tile_kernel); 0 for sizes that run another kernel
+constexpr int tile_occ_c(int ws, int mode) {
+    return (ws != 8 && ws != 16 && ws != 32 && ws != 64) ? 0
+           : (ws == 16 ? 4 : ((ws == 32 || (ws == 64 && mode != MODE_CWS)) ? 3 : 2));
+}
+inline int tile_occ(int ws, int mode) { return tile_occ_c(ws, mode); }
+// symbol-like name of the kernel launch_xcorr picks for (ws, mode) -- for bench / profile labels
+const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len);
+// bytes of PassParams::peak_raw a pass needs (records, work-queue counters, generic-size DFT scratch)
+size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision);
+// test hook: peak stage + finalize on caller-made maps; planar selects the LDS layout variant of the tile kernel
+hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream);
 hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t stream);
 hipError_t launch_predict(const PredictParams& q, hipStream_t stream);
 

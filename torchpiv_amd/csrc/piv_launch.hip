@@ -1,6 +1,8 @@
-// Predictor kernels and the tile-size dispatch (see xcorr_kernel.hpp for the tile kernel).
+// Predictor kernels, finalize kernel and the tile-size dispatch (tile kernels: xcorr_tile.hpp, xcorr_big.hpp,
+// xcorr_generic.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "piv_kernels.h"
 
@@ -10,13 +12,15 @@ hipError_t launch_xcorr_ws8(const PassParams& p, int mode, int n_cu, hipStream_t
 hipError_t launch_xcorr_ws16(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws32(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws64(const PassParams& p, int mode, int n_cu, hipStream_t stream);
-hipError_t launch_xcorr_ws128(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_big128_pass1(const PassParams& p, int n_cu, hipStream_t stream);
-hipError_t launch_peak_debug_ws8(const PassParams& p, const float* maps, int n_maps, hipStream_t stream);
-hipError_t launch_peak_debug_ws16(const PassParams& p, const float* maps, int n_maps, hipStream_t stream);
-struct cf;
-hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, cf* scratch, hipStream_t stream);
-int generic_blocks(int ws, long long items, int n_cu);
+hipError_t launch_peak_debug_ws8(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream);
+hipError_t launch_peak_debug_ws16(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream);
+hipError_t launch_peak_debug_ws32(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream);
+hipError_t launch_peak_debug_ws64(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream);
+hipError_t launch_peak_debug_ws128(const PassParams& p, const float* maps, int n_maps, hipStream_t stream);
+hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, void* scratch, hipStream_t stream);
+int generic_blocks(int ws, long long items, int n_cu, int elem_bytes);
+hipError_t launch_xcorr_f64(const PassParams& p, int n_cu, hipStream_t stream);      // xcorr_f64.hip: 8..64, pass 1
 
 // ---- finalize: sub-pixel fit, validation and multipass combine, one thread per window -----------
 // PIVbackend.py:385-422 (correlation_to_displacement) and B:728-738 / B:800-810 (combine).  Input:
@@ -28,16 +32,28 @@ __device__ __forceinline__ double nan_to_num_f(double x) {      // torch.nan_to_
     return x;
 }
 
+// F64: the records are 8 doubles (float64 first pass), else 8 floats
+template <bool F64>
 __global__ __launch_bounds__(256) void finalize_kernel(PassParams p, int mode) {
     const size_t total = (size_t)p.batch * p.n_rows * p.n_cols;
     const int ws = p.ws;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const float4* __restrict__ rw = reinterpret_cast<const float4*>(p.peak_raw + i * 8);
-        const float4 r0 = rw[0], r1 = rw[1];
-        const double cm = (double)r0.x, cl = (double)r0.y, cr = (double)r0.z, ct = (double)r0.w;
-        const double cb = (double)r1.x, c2 = (double)r1.y;
-        const int m = __float_as_int(r1.z);
-        const bool dead = __float_as_int(r1.w) != 0;
+        double cm, cl, cr, ct, cb, c2;
+        int m;
+        bool dead;
+        if constexpr (F64) {
+            const double* __restrict__ rw = reinterpret_cast<const double*>(p.peak_raw) + i * 8;
+            cm = rw[0], cl = rw[1], cr = rw[2], ct = rw[3], cb = rw[4], c2 = rw[5];
+            m = (int)rw[6];
+            dead = rw[7] != 0.0;
+        } else {
+            const float4* __restrict__ rw = reinterpret_cast<const float4*>(p.peak_raw + i * 8);
+            const float4 r0 = rw[0], r1 = rw[1];
+            cm = (double)r0.x, cl = (double)r0.y, cr = (double)r0.z, ct = (double)r0.w;
+            cb = (double)r1.x, c2 = (double)r1.y;
+            m = __float_as_int(r1.z);
+            dead = __float_as_int(r1.w) != 0;
+        }
         const double lm = log(cm), ll = log(cl), lr = log(cr), lt = log(ct), lb = log(cb);
         const double nom1 = lr - ll;                           // B:399-402
         const double den1 = 2 * (ll + lr) - 4 * lm;
@@ -77,64 +93,91 @@ __global__ __launch_bounds__(256) void finalize_kernel(PassParams p, int mode) {
 }
 
 static bool tile_size(int ws) { return ws == 8 || ws == 16 || ws == 32 || ws == 64; }
-static size_t peak_bytes(int batch, int n_windows) {
-    return (((size_t)batch * n_windows * 8 * sizeof(float)) + 255) / 256 * 256;
+static size_t peak_bytes(int batch, int n_windows, int precision = 0) {
+    return (((size_t)batch * n_windows * 8 * (precision ? sizeof(double) : sizeof(float))) + 255) / 256 * 256;
 }
 
 // peak records, followed (generic sizes only) by the DFT scratch tiles of the resident workgroups
 // test hook: peak analysis + finalize (pass-1 semantics) on caller-supplied correlation maps
-hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_maps, hipStream_t stream) {
+hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream) {
     hipError_t e;
-    if (p.ws == 8) e = launch_peak_debug_ws8(p, maps, n_maps, stream);
-    else if (p.ws == 16) e = launch_peak_debug_ws16(p, maps, n_maps, stream);
-    else return hipErrorInvalidValue;
+    switch (p.ws) {
+        case 8: e = launch_peak_debug_ws8(p, maps, n_maps, planar, stream); break;
+        case 16: e = launch_peak_debug_ws16(p, maps, n_maps, planar, stream); break;
+        case 32: e = launch_peak_debug_ws32(p, maps, n_maps, planar, stream); break;
+        case 64: e = launch_peak_debug_ws64(p, maps, n_maps, planar, stream); break;
+        case 128: e = launch_peak_debug_ws128(p, maps, n_maps, stream); break;
+        default: return hipErrorInvalidValue;
+    }
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(finalize_kernel, dim3((n_maps + 255) / 256), dim3(256), 0, stream, p, (int)MODE_PASS1);
+    hipLaunchKernelGGL(finalize_kernel<false>, dim3((n_maps + 255) / 256), dim3(256), 0, stream, p, (int)MODE_PASS1);
     return hipGetLastError();
 }
 
 static constexpr size_t WORK_CTR_BYTES = 8 * 16 * sizeof(unsigned);
 static size_t work_ctr_offset(int batch, int n_windows) { return (peak_bytes(batch, n_windows) + 127) / 128 * 128; }
 
-size_t peak_raw_bytes(int ws, int batch, int n_windows) {
-    if (ws == 128) return peak_bytes(batch, n_windows);      // pass 1 (xcorr_big.hpp); shifted passes fuse the epilogue
-    if (tile_size(ws)) return work_ctr_offset(batch, n_windows) + WORK_CTR_BYTES;   // records + item counters
-    size_t b = peak_bytes(batch, n_windows);
-    if (!tile_size(ws))
-        b += (size_t)generic_blocks(ws, (long long)batch * n_windows, 256) * 2 * ws * ws * 8;
-    return b;
+size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision) {
+    if (tile_size(ws)) {
+        if (precision) return peak_bytes(batch, n_windows, 1);                      // float64 records only
+        return work_ctr_offset(batch, n_windows) + WORK_CTR_BYTES;                  // records + item counters
+    }
+    // generic sizes (and shifted 128x128 passes): records + the DFT scratch tiles of the resident workgroups
+    const int eb = precision ? 8 : 4;
+    return peak_bytes(batch, n_windows, precision) +
+           (size_t)generic_blocks(ws, (long long)batch * n_windows, 256, eb) * 2 * ws * ws * 2 * eb;
+}
+
+// (in the demangled form rocprofv3 prints, so that profile rows can be matched by substring; the MODE
+//  template argument is the tpiv::MODE_* value: 0 pass 1, 1 DWS, 2 CWS)
+const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len) {
+    if (precision && mode == MODE_PASS1) {
+        if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_kernel<%d>", ws);
+        else snprintf(buf, len, "xcorr_generic_kernel<0, double>");
+    } else if (tile_size(ws)) {
+        snprintf(buf, len, "xcorr_tile_kernel<%d, %d, %d>", ws, mode, tile_occ(ws, mode));
+    } else if (ws == 128 && mode == MODE_PASS1) {
+        snprintf(buf, len, "xcorr_big128_kernel");
+    } else {
+        snprintf(buf, len, "xcorr_generic_kernel<%d, float>", mode);
+    }
+    return buf;
 }
 
 hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t stream) {
     hipError_t e;
     PassParams p = p_in;
-    if (tile_size(p.ws)) {       // per-XCD work queue of the tile kernel: counters behind the peak records
+    const bool f64 = p.precision != 0;
+    if (f64 && mode != MODE_PASS1) return hipErrorInvalidValue;     // the reference's later passes are float32
+    auto generic = [&]() {
+        if (p.ws < 2 || p.ws > 256) return hipErrorInvalidValue;
+        void* scratch = reinterpret_cast<char*>(p.peak_raw) + peak_bytes(p.batch, p.n_rows * p.n_cols, p.precision);
+        return launch_xcorr_generic(p, mode, 256, scratch, stream);
+    };
+    if (f64) {
+        e = tile_size(p.ws) ? launch_xcorr_f64(p, n_cu, stream) : generic();
+    } else if (tile_size(p.ws)) {       // per-XCD work queue of the tile kernel: counters behind the peak records
         p.work_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.peak_raw) +
                                                  work_ctr_offset(p.batch, p.n_rows * p.n_cols));
         e = hipMemsetAsync(p.work_ctr, 0, WORK_CTR_BYTES, stream);
         if (e != hipSuccess) return e;
-    }
-    switch (p.ws) {
-        case 8: e = launch_xcorr_ws8(p, mode, n_cu, stream); break;
-        case 16: e = launch_xcorr_ws16(p, mode, n_cu, stream); break;
-        case 32: e = launch_xcorr_ws32(p, mode, n_cu, stream); break;
-        case 64: e = launch_xcorr_ws64(p, mode, n_cu, stream); break;
-        case 128:
-            if (mode != MODE_PASS1) return launch_xcorr_ws128(p, mode, n_cu, stream);      // fused epilogue
-            e = launch_xcorr_big128_pass1(p, n_cu, stream);
-            break;
-        default: {
-            if (p.ws < 2 || p.ws > 256) return hipErrorInvalidValue;
-            cf* scratch = reinterpret_cast<cf*>(reinterpret_cast<char*>(p.peak_raw) +
-                                                peak_bytes(p.batch, p.n_rows * p.n_cols));
-            e = launch_xcorr_generic(p, mode, 256, scratch, stream);
+        switch (p.ws) {
+            case 8: e = launch_xcorr_ws8(p, mode, n_cu, stream); break;
+            case 16: e = launch_xcorr_ws16(p, mode, n_cu, stream); break;
+            case 32: e = launch_xcorr_ws32(p, mode, n_cu, stream); break;
+            default: e = launch_xcorr_ws64(p, mode, n_cu, stream); break;
         }
+    } else if (p.ws == 128 && mode == MODE_PASS1) {
+        e = launch_xcorr_big128_pass1(p, n_cu, stream);
+    } else {
+        e = generic();          // generic sizes, and shifted 128x128 passes
     }
     if (e != hipSuccess) return e;
     const size_t total = (size_t)p.batch * p.n_rows * p.n_cols;
     size_t blocks = (total + 255) / 256;
     if (blocks > (size_t)n_cu * 32) blocks = (size_t)n_cu * 32;
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, mode);
+    if (f64) hipLaunchKernelGGL(finalize_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, stream, p, mode);
+    else hipLaunchKernelGGL(finalize_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, stream, p, mode);
     return hipGetLastError();
 }
 

@@ -54,6 +54,105 @@ __device__ __forceinline__ T block_reduce(T v, OP op, T* red, int wave, int lane
     return op(op(red[0], red[1]), op(red[2], red[3]));
 }
 
+// ---- stage 7 of the 128x128 kernel: peak analysis of one window's map (B:346-358, B:381-392, B:518).
+// in: thread (line = t & 127, par = t >> 7) holds c[j] = corr(row line, column 2j + par) in UN-shifted
+// coordinates; the map is parked in sm.plane in fftshift coordinates.  `prefetch` runs once after the
+// thread-local minimum (the kernel issues the next window's row loads there).
+template <typename PREFETCH>
+__device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[BH], BigShared& sm, int t, size_t fidx,
+                                               bool dead, PREFETCH&& prefetch) {
+    float* const plane = sm.plane;
+    const int lane = t & 63, wave = t >> 6, par = t >> 7;
+    {
+        int tq = t;
+        asm volatile("" : "+v"(tq));
+        const int ys = ((tq & 127) + 64) & 127;
+        const int KD = BW * BW;
+        float cmin = 3.4e38f;
+#pragma unroll
+        for (int j = 0; j < BH; ++j) cmin = fminf(cmin, c[j]);
+        prefetch();
+        auto fmin_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fminf(a, b); };
+        auto fmax_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); };
+        auto imin_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
+        auto imax_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a > b ? a : b; };
+        cmin = block_reduce(cmin, fmin_, sm.redf, wave, lane);       // (also: plane reads of stage 6 done)
+        float rmax = 0.f;
+        static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
+            constexpr int j = decltype(jc)::value;
+            constexpr int xe = (2 * j + 64) & 127;
+            const float v = __fadd_rn(__fsub_rn(c[j], cmin), 1e-7f);       // B:518, B:381
+            c[j] = v;
+            plane[ys * BP + xe + par] = v;
+            rmax = fmaxf(rmax, v);
+        });
+        const float gmax = block_reduce(rmax, fmax_, sm.redf + 4, wave, lane);
+        const int ywin = block_reduce(rmax == gmax ? ys : BW - 1, imin_, sm.redi, wave, lane);   // map complete
+        const int xwin = block_reduce((t < BW && plane[ywin * BP + (t & 127)] == gmax) ? t : BW - 1, imin_,
+                                      sm.redi + 4, wave, lane);
+        const int m = ywin * BW + xwin;
+        if (p.dbg_corr != nullptr) {
+            float* d = p.dbg_corr + fidx * KD + ys * BW + par;
+            static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
+                constexpr int j = decltype(jc)::value;
+                constexpr int xe = (2 * j + 64) & 127;
+                d[xe] = c[j];
+            });
+        }
+        // second peak: maximum outside the flat-index neighbourhood of m (B:346-358), see peak_analysis
+        const int wv = p.val_win;
+        int smax = 0;
+        {
+            const int dj = ys - ywin;
+            unsigned long long exl = 0ull, exh = 0ull;     // excluded columns 0..63 / 64..127 of this row
+            auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
+                lo_ = lo_ < 0 ? 0 : lo_;
+                hi_ = hi_ > BW - 1 ? BW - 1 : hi_;
+                for (int q = lo_; q <= hi_; ++q) {         // at most 2 wv + 1 columns
+                    if (q < 64) exl |= 1ull << q;
+                    else exh |= 1ull << (q - 64);
+                }
+            };
+            if (dj >= -wv && dj <= wv) span(xwin - wv, xwin + wv);
+            if (dj + 1 >= -wv && dj + 1 <= wv) span(xwin - wv + BW, xwin + wv + BW);
+            if (dj - 1 >= -wv && dj - 1 <= wv) span(xwin - wv - BW, xwin + wv - BW);
+            if (ys == 0 && (m - wv - wv * BW) <= 0) exl |= 1ull;
+            if (ys == BW - 1 && (m + wv + wv * BW) >= KD - 1) exh |= 1ull << 63;
+            // this thread's columns have parity `par`: shift it away, bit positions become even constants
+            const unsigned e0 = (unsigned)(exl >> par), e1 = (unsigned)(exl >> (32 + par));
+            const unsigned e2 = (unsigned)(exh >> par), e3 = (unsigned)(exh >> (32 + par));
+            static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
+                constexpr int j = decltype(jc)::value;
+                constexpr int xe = (2 * j + 64) & 127;
+                constexpr int wsel = xe >> 5, bit = xe & 31;
+                const unsigned word = wsel == 0 ? e0 : (wsel == 1 ? e1 : (wsel == 2 ? e2 : e3));
+                const int kill = __builtin_amdgcn_sbfe((int)word, bit, 1);
+                const int cand = __float_as_int(c[j]) | kill;
+                smax = cand > smax ? cand : smax;
+            });
+        }
+        smax = block_reduce(smax, imax_, sm.redi, wave, lane);
+        const float second_v = smax > 0 ? __int_as_float(smax) : gmax;
+        if (t < 8) {
+            int left = m + 1, right = m - 1, top = m + BW, bot = m - BW;     // B:385-392 (flat index)
+            if (left >= KD - 1) left = m;
+            if (right <= 0) right = m;
+            if (top >= KD - 1) top = m;
+            if (bot <= 0) bot = m;
+            int q = m;
+            q = (t == 1) ? left : q;
+            q = (t == 2) ? right : q;
+            q = (t == 3) ? top : q;
+            q = (t == 4) ? bot : q;
+            float outv = plane[(q / BW) * BP + (q % BW)];
+            outv = (t == 5) ? second_v : outv;
+            outv = (t == 6) ? __int_as_float(m) : outv;
+            outv = (t == 7) ? __int_as_float(dead ? 1 : 0) : outv;
+            p.peak_raw[fidx * 8 + t] = outv;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
     __shared__ BigShared sm;
     float* const plane = sm.plane;
@@ -350,97 +449,36 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
 
         // ---------------- stage 7: peak analysis on the map in LDS (fftshift coordinates)
         {
-            const int ys = ((TPIV_OPQ_T() & 127) + 64) & 127;
-            const int KD = BW * BW;
-            float c[BH];                                       // c[j]: column xs(j) = ((2j + 64) & 127) + par
-            float cmin = 3.4e38f;
+            float c[BH];                                       // c[j]: column 2j + par of row `line`
             static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
                 constexpr int j = decltype(jc)::value;
                 c[j] = (j & 1) ? zc[FFT_POS<j / 2, BH / 2>].y : zc[FFT_POS<j / 2, BH / 2>].x;
-                cmin = fminf(cmin, c[j]);
             });
-            // prefetch (the last iteration re-loads its own window: no branch around the loads)
-            issue_loads(item + per_xcd < hi ? item + per_xcd : item);
-            auto fmin_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fminf(a, b); };
-            auto fmax_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); };
-            auto imin_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
-            auto imax_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a > b ? a : b; };
-            cmin = block_reduce(cmin, fmin_, sm.redf, wave, lane);       // (also: plane reads of stage 6 done)
-            float rmax = 0.f;
-            static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
-                constexpr int j = decltype(jc)::value;
-                constexpr int xe = (2 * j + 64) & 127;
-                const float v = __fadd_rn(__fsub_rn(c[j], cmin), 1e-7f);       // B:518, B:381
-                c[j] = v;
-                plane[ys * BP + xe + par] = v;
-                rmax = fmaxf(rmax, v);
+            // prefetch: the last iteration re-loads its own window (no branch around the loads)
+            big_peak_stage(p, c, sm, t, fidx, dead, [&]() TPIV_LAMBDA_INLINE {
+                issue_loads(item + per_xcd < hi ? item + per_xcd : item);
             });
-            const float gmax = block_reduce(rmax, fmax_, sm.redf + 4, wave, lane);
-            const int ywin = block_reduce(rmax == gmax ? ys : BW - 1, imin_, sm.redi, wave, lane);   // map complete
-            const int xwin = block_reduce((t < BW && plane[ywin * BP + (t & 127)] == gmax) ? t : BW - 1, imin_,
-                                          sm.redi + 4, wave, lane);
-            const int m = ywin * BW + xwin;
-            if (p.dbg_corr != nullptr) {
-                float* d = p.dbg_corr + fidx * KD + ys * BW + par;
-                static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
-                    constexpr int j = decltype(jc)::value;
-                    constexpr int xe = (2 * j + 64) & 127;
-                    d[xe] = c[j];
-                });
-            }
-            // second peak: maximum outside the flat-index neighbourhood of m (B:346-358), see peak_analysis
-            const int wv = p.val_win;
-            int smax = 0;
-            {
-                const int dj = ys - ywin;
-                unsigned long long exl = 0ull, exh = 0ull;     // excluded columns 0..63 / 64..127 of this row
-                auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
-                    lo_ = lo_ < 0 ? 0 : lo_;
-                    hi_ = hi_ > BW - 1 ? BW - 1 : hi_;
-                    for (int q = lo_; q <= hi_; ++q) {         // at most 2 wv + 1 columns
-                        if (q < 64) exl |= 1ull << q;
-                        else exh |= 1ull << (q - 64);
-                    }
-                };
-                if (dj >= -wv && dj <= wv) span(xwin - wv, xwin + wv);
-                if (dj + 1 >= -wv && dj + 1 <= wv) span(xwin - wv + BW, xwin + wv + BW);
-                if (dj - 1 >= -wv && dj - 1 <= wv) span(xwin - wv - BW, xwin + wv - BW);
-                if (ys == 0 && (m - wv - wv * BW) <= 0) exl |= 1ull;
-                if (ys == BW - 1 && (m + wv + wv * BW) >= KD - 1) exh |= 1ull << 63;
-                // this thread's columns have parity `par`: shift it away, bit positions become even constants
-                const unsigned e0 = (unsigned)(exl >> par), e1 = (unsigned)(exl >> (32 + par));
-                const unsigned e2 = (unsigned)(exh >> par), e3 = (unsigned)(exh >> (32 + par));
-                static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
-                    constexpr int j = decltype(jc)::value;
-                    constexpr int xe = (2 * j + 64) & 127;
-                    constexpr int wsel = xe >> 5, bit = xe & 31;
-                    const unsigned word = wsel == 0 ? e0 : (wsel == 1 ? e1 : (wsel == 2 ? e2 : e3));
-                    const int kill = __builtin_amdgcn_sbfe((int)word, bit, 1);
-                    const int cand = __float_as_int(c[j]) | kill;
-                    smax = cand > smax ? cand : smax;
-                });
-            }
-            smax = block_reduce(smax, imax_, sm.redi, wave, lane);
-            const float second_v = smax > 0 ? __int_as_float(smax) : gmax;
-            if (t < 8) {
-                int left = m + 1, right = m - 1, top = m + BW, bot = m - BW;     // B:385-392 (flat index)
-                if (left >= KD - 1) left = m;
-                if (right <= 0) right = m;
-                if (top >= KD - 1) top = m;
-                if (bot <= 0) bot = m;
-                int q = m;
-                q = (t == 1) ? left : q;
-                q = (t == 2) ? right : q;
-                q = (t == 3) ? top : q;
-                q = (t == 4) ? bot : q;
-                float outv = plane[(q / BW) * BP + (q % BW)];
-                outv = (t == 5) ? second_v : outv;
-                outv = (t == 6) ? __int_as_float(m) : outv;
-                outv = (t == 7) ? __int_as_float(dead ? 1 : 0) : outv;
-                p.peak_raw[fidx * 8 + t] = outv;
-            }
         }
     }
+}
+
+// test hook: hand-made maps [n_maps, 128, 128] float32 in fftshift layout through stage 7
+__global__ __launch_bounds__(256, 2) void peak_debug_big_kernel(PassParams p, const float* maps, int n_maps) {
+    __shared__ BigShared sm;
+    const int t = threadIdx.x;
+    const int line = t & 127, par = t >> 7;
+    const int win = blockIdx.x;
+    if (win >= n_maps) return;
+    float c[BH];
+    const int ys = (line + 64) & 127;
+#pragma unroll
+    for (int j = 0; j < BH; ++j) c[j] = maps[((size_t)win * BW + ys) * BW + ((2 * j + par + 64) & 127)];
+    big_peak_stage(p, c, sm, t, (size_t)win, false, []() TPIV_LAMBDA_INLINE {});
+}
+
+inline hipError_t launch_peak_debug_big(const PassParams& p, const float* maps, int n_maps, hipStream_t stream) {
+    hipLaunchKernelGGL(peak_debug_big_kernel, dim3(n_maps), dim3(256), 0, stream, p, maps, n_maps);
+    return hipGetLastError();
 }
 
 inline hipError_t launch_xcorr_big128(const PassParams& p, int n_cu, hipStream_t stream) {

@@ -4,6 +4,9 @@
 // window, the complex tile lives in a global (L2-resident) scratch, the transforms are plain DFTs
 // with a twiddle table in LDS.  Staging, peak search and hand-off to finalize_kernel follow the
 // same reference semantics as xcorr_tile.hpp (PIVbackend.py:147-216, 249-257, 346-422, 459-520).
+// Templated on the arithmetic type: float (all modes) and double (first pass at reference precision,
+// TPIV_PREC_REFERENCE: the reference promotes pass 1 to float64, B:513-514 -- windows divided by their
+// mean, no mean removal, float64 transforms, map and peak analysis).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -46,16 +49,30 @@ __device__ __forceinline__ float cws_sample_g(const uint8_t* __restrict__ f, int
     return degenerate ? f11 : r;
 }
 
+template <typename R>
+struct cplx {
+    R x, y;
+};
+template <typename R>
 struct AM {
-    float v;
+    R v;
     int idx;
 };
-__device__ __forceinline__ AM better_g(AM a, AM b) {
+template <typename R>
+__device__ __forceinline__ AM<R> better_g(AM<R> a, AM<R> b) {
     return ((b.v > a.v) || (b.v == a.v && b.idx < a.idx)) ? b : a;
 }
+template <typename R>
+__device__ __forceinline__ R rmin(R a, R b) { return a < b ? a : (b < a ? b : (a == a ? a : b)); }     // fmin semantics
+__device__ __forceinline__ float add_eps(float c, float cmin) { return __fadd_rn(__fsub_rn(c, cmin), 1e-7f); }
+__device__ __forceinline__ double add_eps(double c, double cmin) { return __dadd_rn(__dsub_rn(c, cmin), 1e-7); }
+// record slots 6 (peak index) and 7 (dead flag): bit patterns in float records, plain values in double records
+__device__ __forceinline__ float rec_int(float, int v) { return __int_as_float(v); }
+__device__ __forceinline__ double rec_int(double, int v) { return (double)v; }
 
 // block reductions through LDS (all threads get the result)
-__device__ float block_sum(float v, float* red) {
+template <typename R>
+__device__ R block_sum(R v, R* red) {
     __syncthreads();
     red[threadIdx.x] = v;
     __syncthreads();
@@ -65,37 +82,41 @@ __device__ float block_sum(float v, float* red) {
     }
     return red[0];
 }
-__device__ float block_min(float v, float* red) {
+template <typename R>
+__device__ R block_min(R v, R* red) {
     __syncthreads();
     red[threadIdx.x] = v;
     __syncthreads();
     for (int s = GT / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + s]);
+        if ((int)threadIdx.x < s) red[threadIdx.x] = rmin(red[threadIdx.x], red[threadIdx.x + s]);
         __syncthreads();
     }
     return red[0];
 }
-__device__ AM block_argmax(AM a, float* red, int* redi) {
+template <typename R>
+__device__ AM<R> block_argmax(AM<R> a, R* red, int* redi) {
     __syncthreads();
     red[threadIdx.x] = a.v;
     redi[threadIdx.x] = a.idx;
     __syncthreads();
     for (int s = GT / 2; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) {
-            AM x{red[threadIdx.x], redi[threadIdx.x]}, y{red[threadIdx.x + s], redi[threadIdx.x + s]};
+            AM<R> x{red[threadIdx.x], redi[threadIdx.x]}, y{red[threadIdx.x + s], redi[threadIdx.x + s]};
             x = better_g(x, y);
             red[threadIdx.x] = x.v;
             redi[threadIdx.x] = x.idx;
         }
         __syncthreads();
     }
-    return AM{red[0], redi[0]};
+    return AM<R>{red[0], redi[0]};
 }
 
-template <int MODE>
-__global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scratch) {
+template <int MODE, typename R>
+__global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>* scratch) {
+    using cf = cplx<R>;
+    constexpr bool F64 = sizeof(R) == 8;
     __shared__ cf tw[256];            // exp(-2 pi i k / n)
-    __shared__ float red[GT];
+    __shared__ R red[GT];
     __shared__ int redi[GT];
     const int n = p.ws, nn = n * n;
     const int tid = threadIdx.x;
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
     for (int k = tid; k < n; k += GT) {
         double s, c;
         sincospi(2.0 * (double)k / (double)n, &s, &c);
-        tw[k] = cf{(float)c, (float)(-s)};
+        tw[k] = cf{(R)c, (R)(-s)};
     }
     __syncthreads();
 
@@ -118,7 +139,7 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
         const uint8_t* __restrict__ fa = p.A + (size_t)pair * HW;
         const uint8_t* __restrict__ fb = p.B + (size_t)pair * HW;
         const size_t fidx = (size_t)item;
-        float vx = 0.f, vy = 0.f;
+        float vx = 0.f, vy = 0.f;     // (shifted passes exist in float only)
         long long sh = 0;
         if constexpr (MODE == MODE_DWS) sh = (long long)p.v2[fidx] * p.W + (long long)p.u2[fidx];
         if constexpr (MODE == MODE_CWS) {
@@ -126,14 +147,14 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
             vy = (float)p.v2[fidx];
         }
         // ---- staging
-        float sa = 0.f, sb = 0.f;
+        R sa = 0, sb = 0;
         for (int i = tid; i < nn; i += GT) {
             const int y = i / n, x = i % n;
-            float a, b;
+            R a, b;
             if constexpr (MODE == MODE_PASS1) {
                 const size_t q = (size_t)(y0 + y) * p.W + x0 + x;
-                a = (float)fa[q];
-                b = (float)fb[q];
+                a = (R)fa[q];
+                b = (R)fb[q];
             } else if constexpr (MODE == MODE_DWS) {
                 const long long q = (long long)(y0 + y) * p.W + x0 + x;
                 a = fetch_clamped_g(fa, q - sh, HW);
@@ -146,29 +167,41 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
             sa += a;
             sb += b;
             if (p.dbg_win != nullptr) {
-                p.dbg_win[fidx * 2 * nn + i] = a;
-                p.dbg_win[fidx * 2 * nn + nn + i] = b;
+                p.dbg_win[fidx * 2 * nn + i] = (float)a;
+                p.dbg_win[fidx * 2 * nn + nn + i] = (float)b;
             }
         }
         sa = block_sum(sa, red);
         sb = block_sum(sb, red);
-        const float ma = sa / (float)nn, mb = sb / (float)nn;
+        R ma = sa / (R)nn, mb = sb / (R)nn;        // (sums of integers: exact in either type)
         bool dead = false;
-        float ka = 1.f, kb = 1.f;
+        R ka = 1, kb = 1;
         if constexpr (MODE == MODE_PASS1) {
-            dead = (sa == 0.f) || (sb == 0.f);
-            ka = dead ? 0.f : 1.0f / ma;
-            kb = dead ? 0.f : 1.0f / mb;
+            dead = (sa == 0) || (sb == 0);
+            ka = dead ? (R)0 : (R)1 / ma;
+            kb = dead ? (R)0 : (R)1 / mb;
         }
         __syncthreads();
+        if constexpr (F64) {
+            // reference arithmetic (B:513-514): a / mean(a) by division, the DC pedestal stays in
+            for (int i = tid; i < nn; i += GT) {
+                const cf z = T0[i];
+                T0[i] = dead ? cf{0, 0} : cf{z.x / ma, z.y / mb};
+            }
+            ma = 0;
+            mb = 0;
+            ka = 1;
+            kb = 1;
+            __syncthreads();
+        }
         // ---- forward DFT over x (rows), with the mean removal folded in: T1[y][kx]
         for (int i = tid; i < nn; i += GT) {
             const int y = i / n, kx = i % n;
-            float re = 0.f, im = 0.f;
+            R re = 0, im = 0;
             int idx = 0;
             for (int x = 0; x < n; ++x) {
                 const cf z = T0[y * n + x];
-                const float zr = (z.x - ma) * ka, zi = (z.y - mb) * kb;
+                const R zr = (z.x - ma) * ka, zi = (z.y - mb) * kb;
                 const cf w = tw[idx];
                 re += zr * w.x - zi * w.y;
                 im += zr * w.y + zi * w.x;
@@ -181,7 +214,7 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
         // ---- forward DFT over y (columns): T0[ky][kx]
         for (int i = tid; i < nn; i += GT) {
             const int ky = i / n, kx = i % n;
-            float re = 0.f, im = 0.f;
+            R re = 0, im = 0;
             int idx = 0;
             for (int y = 0; y < n; ++y) {
                 const cf z = T1[y * n + kx];
@@ -195,13 +228,13 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
         }
         __syncthreads();
         // ---- cross-spectrum: T1[k] = conj(A) * B / n^2 with A, B split out of Z = FFT2(a + i b)
-        const float scale = 0.25f / ((float)nn);
+        const R scale = (R)0.25 / ((R)nn);
         for (int i = tid; i < nn; i += GT) {
             const int ky = i / n, kx = i % n;
             const cf zk = T0[i];
             const cf zm = T0[((n - ky) % n) * n + (n - kx) % n];
             cf pr;
-            pr.x = (zk.x * zm.y + zk.y * zm.x) * (2.0f * scale);
+            pr.x = (zk.x * zm.y + zk.y * zm.x) * ((R)2 * scale);
             pr.y = ((zm.x * zm.x - zk.x * zk.x) + (zm.y * zm.y - zk.y * zk.y)) * scale;
             T1[i] = pr;
         }
@@ -209,7 +242,7 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
         // ---- inverse DFT over ky: T0[y][kx]
         for (int i = tid; i < nn; i += GT) {
             const int y = i / n, kx = i % n;
-            float re = 0.f, im = 0.f;
+            R re = 0, im = 0;
             int idx = 0;
             for (int ky = 0; ky < n; ++ky) {
                 const cf z = T1[ky * n + kx];
@@ -223,12 +256,12 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
         }
         __syncthreads();
         // ---- inverse DFT over kx, real part only, stored in fftshift coordinates into the map
-        float* map = reinterpret_cast<float*>(T1);
+        R* map = reinterpret_cast<R*>(T1);
         const int hshift = n / 2;
-        float cmin = 3.4e38f;
+        R cmin = (R)3.4e38;
         for (int i = tid; i < nn; i += GT) {
             const int y = i / n, x = i % n;
-            float re = 0.f;
+            R re = 0;
             int idx = 0;
             for (int kx = 0; kx < n; ++kx) {
                 const cf z = T0[y * n + kx];
@@ -239,15 +272,15 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
             }
             const int ys = (y + hshift) % n, xs = (x + hshift) % n;
             map[ys * n + xs] = re;
-            cmin = fminf(cmin, re);
+            cmin = rmin(cmin, re);
         }
         cmin = block_min(cmin, red);
         // ---- corr - min + eps (B:518, B:381), first peak
-        AM best{-1.f, 0};
+        AM<R> best{(R)-1, 0};
         for (int i = tid; i < nn; i += GT) {
-            const float v = __fadd_rn(__fsub_rn(map[i], cmin), 1e-7f);
+            const R v = add_eps(map[i], cmin);
             map[i] = v;
-            if (p.dbg_corr != nullptr) p.dbg_corr[fidx * nn + i] = v;
+            if (p.dbg_corr != nullptr) p.dbg_corr[fidx * nn + i] = (float)v;
             if (v > best.v) {
                 best.v = v;
                 best.idx = i;
@@ -257,7 +290,7 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
         const int m = best.idx;
         // ---- second peak outside the flat-index neighbourhood (B:346-358), brute-force membership
         const int wv = p.val_win;
-        AM second{-1.f, nn};
+        AM<R> second{(R)-1, nn};
         for (int i = tid; i < nn; i += GT) {
             bool excl = false;
             for (int j = -wv; j <= wv; ++j) {
@@ -266,7 +299,7 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
             }
             if (i == 0 && (m - wv - wv * n) <= 0) excl = true;              // clamp to 0
             if (i == nn - 1 && (m + wv + wv * n) >= nn - 1) excl = true;    // clamp to n*n-1
-            const float v = map[i];
+            const R v = map[i];
             if (!excl && v > second.v) {
                 second.v = v;
                 second.idx = i;
@@ -286,15 +319,15 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
             q = (tid == 3) ? top : q;
             q = (tid == 4) ? bot : q;
             q = (tid == 5) ? (second.idx < nn ? second.idx : 0) : q;
-            float outv = map[q];
+            R outv = map[q];
             // Every cell inside the exclusion zone (maps smaller than 7x7): the reference's second
             // arg-max then runs over an all-zero map and returns index 0 (B:357).  In pass 1 the
             // float64 `cor` aliases the zeroed map (B:382), so c[m2] = 0 and the ratio is +inf;
             // in passes >= 2 `cor` is a float64 copy made before the zeroing, so c[m2] = c[0].
-            if (tid == 5 && second.idx >= nn && MODE == MODE_PASS1) outv = 0.0f;
-            outv = (tid == 6) ? __int_as_float(m) : outv;
-            outv = (tid == 7) ? __int_as_float(dead ? 1 : 0) : outv;
-            p.peak_raw[fidx * 8 + tid] = outv;
+            if (tid == 5 && second.idx >= nn && MODE == MODE_PASS1) outv = 0;
+            outv = (tid == 6) ? rec_int(R(), m) : outv;
+            outv = (tid == 7) ? rec_int(R(), dead ? 1 : 0) : outv;
+            reinterpret_cast<R*>(p.peak_raw)[fidx * 8 + tid] = outv;
         }
         __syncthreads();
     }
@@ -302,9 +335,9 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cf* scr
 
 }  // namespace
 
-int generic_blocks(int ws, long long items, int n_cu) {
+int generic_blocks(int ws, long long items, int n_cu, int elem_bytes) {
     // scratch = 2 * ws^2 complex per workgroup; keep it below 256 MiB
-    const long long per = 16LL * ws * ws;
+    const long long per = 4LL * elem_bytes * ws * ws;
     long long b = (256LL << 20) / per;
     if (b > (long long)n_cu * 4) b = (long long)n_cu * 4;
     if (b > items) b = items;
@@ -312,18 +345,26 @@ int generic_blocks(int ws, long long items, int n_cu) {
     return (int)b;
 }
 
-hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, cf* scratch, hipStream_t stream) {
+hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, void* scratch, hipStream_t stream) {
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
-    const int blocks = generic_blocks(p.ws, items, n_cu);
+    if (p.precision != 0) {      // float64: first pass only
+        if (mode != MODE_PASS1) return hipErrorInvalidValue;
+        const int blocks = generic_blocks(p.ws, items, n_cu, 8);
+        hipLaunchKernelGGL((xcorr_generic_kernel<MODE_PASS1, double>), dim3(blocks), dim3(GT), 0, stream, p,
+                           static_cast<cplx<double>*>(scratch));
+        return hipGetLastError();
+    }
+    const int blocks = generic_blocks(p.ws, items, n_cu, 4);
+    cplx<float>* sc = static_cast<cplx<float>*>(scratch);
     switch (mode) {
         case MODE_PASS1:
-            hipLaunchKernelGGL((xcorr_generic_kernel<MODE_PASS1>), dim3(blocks), dim3(GT), 0, stream, p, scratch);
+            hipLaunchKernelGGL((xcorr_generic_kernel<MODE_PASS1, float>), dim3(blocks), dim3(GT), 0, stream, p, sc);
             break;
         case MODE_DWS:
-            hipLaunchKernelGGL((xcorr_generic_kernel<MODE_DWS>), dim3(blocks), dim3(GT), 0, stream, p, scratch);
+            hipLaunchKernelGGL((xcorr_generic_kernel<MODE_DWS, float>), dim3(blocks), dim3(GT), 0, stream, p, sc);
             break;
         case MODE_CWS:
-            hipLaunchKernelGGL((xcorr_generic_kernel<MODE_CWS>), dim3(blocks), dim3(GT), 0, stream, p, scratch);
+            hipLaunchKernelGGL((xcorr_generic_kernel<MODE_CWS, float>), dim3(blocks), dim3(GT), 0, stream, p, sc);
             break;
         default: return hipErrorInvalidValue;
     }

@@ -1143,9 +1143,9 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
 // ---- test hook: feed hand-made correlation maps straight into peak_analysis ------------------------
 // maps: [n_windows, WS, WS] float32 in fftshift layout (what correlation_to_displacement receives,
 // before its `+= eps`); one wavefront handles 64/WS maps.  Output: peak_raw records.
-template <int WS>
+template <int WS, bool PLANAR>
 __global__ __launch_bounds__(64, 2) void peak_debug_kernel(PassParams p, const float* maps, int n_maps) {
-    using G = TileGeo<WS, false>;
+    using G = TileGeo<WS, PLANAR>;
     __shared__ float tile[G::LDS_FLOATS];
     const int lane = threadIdx.x;
     const int w = lane / WS, r = lane % WS;
@@ -1156,14 +1156,18 @@ __global__ __launch_bounds__(64, 2) void peak_debug_kernel(PassParams p, const f
     const int ys = (r + WS / 2) % WS;
 #pragma unroll
     for (int xo = 0; xo < WS; ++xo) crow[xo] = maps[((size_t)win * WS + ys) * WS + (xo + WS / 2) % WS];
-    peak_analysis<WS, false>(p, crow, tile, w, r, active, false, (size_t)win);
+    peak_analysis<WS, PLANAR>(p, crow, tile, w, r, active, false, (size_t)win);
 }
 
+// planar != 0: the LDS layout of the three-wavefront kernels (for 64x64: the three-row SMALLMAP form)
 template <int WS>
-hipError_t launch_peak_debug(const PassParams& p, const float* maps, int n_maps, hipStream_t stream) {
+hipError_t launch_peak_debug(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream) {
     using G = TileGeo<WS, false>;
     const int blocks = (n_maps + G::WPW - 1) / G::WPW;
-    hipLaunchKernelGGL((peak_debug_kernel<WS>), dim3(blocks), dim3(64), 0, stream, p, maps, n_maps);
+    if (planar)
+        hipLaunchKernelGGL((peak_debug_kernel<WS, true>), dim3(blocks), dim3(64), 0, stream, p, maps, n_maps);
+    else
+        hipLaunchKernelGGL((peak_debug_kernel<WS, false>), dim3(blocks), dim3(64), 0, stream, p, maps, n_maps);
     return hipGetLastError();
 }
 
@@ -1198,28 +1202,34 @@ static hipError_t launch_tile(const PassParams& p_in, int n_cu, hipStream_t stre
     // the peak search stopped using compare/select chains) gains nothing more: the VALU is saturated.
     // 16x16 is built for four (its CWS variant needs 129 VGPRs unconstrained, one more than four
     // wavefronts allow: 165 -> 155 us/pair at 4096^2); 8x8 is built for two but small enough (107
-    // VGPRs) to run four.  TPIV_OCC=2|3|4 overrides for experiments.
+    // VGPRs) to run four.  64x64 pass 1 and DWS run three (planar tiles, three-row map, slow-path row
+    // buffer in two pieces); the 64x64 CWS variant needs 230 VGPRs and stays at two.
+    // Only the chosen variant is instantiated (tile_occ_c, piv_kernels.h); -DTPIV_EXPERIMENT builds all
+    // of them and lets TPIV_OCC=2|3|4 pick one at run time.
+    constexpr int OCC = tile_occ_c(WS, MODE);
+#ifdef TPIV_EXPERIMENT
     static const int occ_env = [] {
         const char* e = getenv("TPIV_OCC");
         return e ? atoi(e) : 0;
     }();
-    const int occ = occ_env ? occ_env : (WS == 16 ? 4 : ((WS == 32 || (WS == 64 && MODE != MODE_CWS)) ? 3 : 2));
-    if constexpr (WS == 64 && MODE != MODE_CWS) {
-        // 64x64 pass 1 and DWS at three wavefronts per SIMD (planar tiles, 11-row map, slow-path row
-        // buffer in two pieces); the CWS variant needs 230 VGPRs and stays at two
-        if (occ == 3) {
+    if (occ_env == 2 && OCC != 2) {
+        hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+        return hipGetLastError();
+    }
+    if constexpr (WS <= 32 || MODE != MODE_CWS) {
+        if (occ_env == 3 && OCC != 3) {
             hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 3>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
             return hipGetLastError();
         }
     }
-    if (WS <= 32 && occ == 3)
-        hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, (WS <= 32 ? 3 : 2)>), dim3((unsigned)blocks), dim3(64), 0,
-                           stream, p);
-    else if (WS <= 32 && occ == 4)
-        hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, (WS <= 32 ? 4 : 2)>), dim3((unsigned)blocks), dim3(64), 0,
-                           stream, p);
-    else
-        hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    if constexpr (WS <= 32) {
+        if (occ_env == 4 && OCC != 4) {
+            hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 4>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+            return hipGetLastError();
+        }
+    }
+#endif
+    hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, OCC>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

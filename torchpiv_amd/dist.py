@@ -37,12 +37,16 @@ def init_from_env(backend: str | None = None):
 
 
 def shard_indices(n_pairs: int, rank: int, world: int, policy: str = "block"):
-    """Pair indices owned by `rank`.  'block': contiguous ceil(n/world) runs (keeps file reads
-    sequential per rank); 'cyclic': i % world == rank (balances a stream of unknown length)."""
+    """Pair indices owned by `rank`.  'block': contiguous balanced runs of n // world pairs, the first
+    n % world ranks taking one more (keeps file reads sequential per rank; a shard is empty only when
+    n < world); 'cyclic': i % world == rank (balances a stream of unknown length)."""
     if policy == "cyclic":
         return list(range(rank, n_pairs, world))
-    per = (n_pairs + world - 1) // world
-    return list(range(min(rank * per, n_pairs), min((rank + 1) * per, n_pairs)))
+    if policy != "block":
+        raise KeyError(policy)
+    q, r = divmod(n_pairs, world)
+    lo = rank * q + min(rank, r)
+    return list(range(lo, lo + q + (1 if rank < r else 0)))
 
 
 def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=None):
@@ -51,7 +55,9 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
     ids    int64 [n_local]            dataset index of every field this rank produced
     fields       [n_local, C, R, S]   e.g. C = 2 for (u, v); same dtype/shape tail on all ranks
     Returns (ids_all, fields_all) sorted by dataset index on `dst`, (None, None) elsewhere.
-    One count all-gather (8 bytes per rank) + one padded payload gather onto `dst`: on xGMI's full
+    Ranks with nothing to send pass fields of shape [0, ...]; their tail shape is taken from the ranks
+    that have data (exchanged with the counts), so an empty shard needs no plan.
+    One count all-gather (8 + 8*6 bytes per rank) + one padded payload gather onto `dst`: on xGMI's full
     mesh the seven shards arrive over seven different links at once, and no other rank has to hold
     the whole result (an all-gather would move and store world x more).
     """
@@ -65,11 +71,31 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
         fields = fields.cpu()
         ids = ids.cpu()
     dev = fields.device
-    n_local = torch.tensor([ids.numel()], dtype=torch.int64, device=dev)
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, n_local, group=group)
+    # counts and tail shapes in one small exchange: [n, ndim_tail, d0, d1, d2, d3, d4]
+    tail_local = tuple(fields.shape[1:])
+    if len(tail_local) > 5:
+        raise ValueError("gather_fields: at most 5 trailing dimensions")
+    meta = torch.zeros(7, dtype=torch.int64, device=dev)
+    meta[0] = ids.numel()
+    meta[1] = len(tail_local)
+    for k, d in enumerate(tail_local):
+        meta[2 + k] = d
+    metas = torch.zeros(world * 7, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    metas = metas.view(world, 7).cpu()
+    counts = metas[:, 0]
     n_max = int(counts.max().item())
-    tail = tuple(fields.shape[1:])
+    tail = tail_local
+    have = (counts > 0).nonzero().flatten()
+    if have.numel():
+        first = metas[int(have[0])]
+        tail = tuple(int(t) for t in first[2:2 + int(first[1])])
+        for r_ in have.tolist():
+            t_r = tuple(int(t) for t in metas[r_][2:2 + int(metas[r_][1])])
+            if t_r != tail:
+                raise ValueError(f"gather_fields: rank {r_} holds fields of shape {t_r}, rank {int(have[0])} {tail}")
+    if ids.numel() == 0:
+        fields = fields.new_zeros((0,) + tail)
     pad_f = torch.zeros((n_max,) + tail, dtype=fields.dtype, device=dev)
     pad_i = torch.full((n_max,), -1, dtype=torch.int64, device=dev)
     pad_f[: ids.numel()] = fields
@@ -82,18 +108,10 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
     else:
         lst_f = lst_i = None
     dst_global = dist.get_global_rank(group, dst) if group is not None else dst
-    try:
-        dist.gather(pad_f, gather_list=lst_f, dst=dst_global, group=group)
-        dist.gather(pad_i, gather_list=lst_i, dst=dst_global, group=group)
-    except (NotImplementedError, RuntimeError) as exc:
-        # a backend without gather rejects the call on every rank before any communication:
-        # fall back to the all-gather every backend has (world x the traffic, same result on dst)
-        if "gather" not in str(exc).lower() and "support" not in str(exc).lower():
-            raise
-        all_f = torch.empty((world * n_max,) + tail, dtype=fields.dtype, device=dev)
-        all_i = torch.empty(world * n_max, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(all_f, pad_f, group=group)
-        dist.all_gather_into_tensor(all_i, pad_i, group=group)
+    # (gather is implemented by both backends this package runs on -- RCCL and gloo; any error here is a
+    #  real one and propagates: a fallback decided per rank could leave the ranks in different collectives)
+    dist.gather(pad_f, gather_list=lst_f, dst=dst_global, group=group)
+    dist.gather(pad_i, gather_list=lst_i, dst=dst_global, group=group)
     if rank != dst:
         return None, None
     keep = all_i >= 0
@@ -118,10 +136,18 @@ def run_sharded(piv, batch_size: int = 32, policy: str = "block", group=None):
     dev = piv._device
     if uv:
         f = torch.from_numpy(np.stack(uv)).to(dev)
-    else:
-        plan_shape = piv._plan.out_shape if piv._plan is not None else (0, 0)
-        f = torch.zeros((0, 2) + tuple(plan_shape), dtype=torch.float64, device=dev)
+    else:       # empty shard (or every pair of it dropped): gather_fields takes the grid from the other ranks
+        f = torch.zeros((0, 2, 0, 0), dtype=torch.float64, device=dev)
     i_all, f_all = gather_fields(torch.tensor(ids, dtype=torch.int64, device=dev), f, group=group)
     if rank != 0:
         return None
+    if xy is None and len(piv):        # rank 0 itself yielded nothing: the grid depends on the geometry only
+        from . import backend
+        w, o = int(piv._wind_size), int(piv._overlap)
+        for _ in range(max(1, int(piv._iter)) - 1):
+            w, o = int(w // piv._iter_scale), int(o // piv._iter_scale)
+        shape = piv.frame_shape()
+        if shape is not None:
+            x, y = backend.get_coordinates(shape, w, o)
+            xy = (x * piv._scale, y * piv._scale)
     return i_all.cpu().numpy(), xy, f_all.cpu().numpy()

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import MODES, check, lib
+from ._lib import MODES, PRECISIONS, check, lib
 
 
 def _stream() -> int:
@@ -37,6 +37,21 @@ def _frames(a: torch.Tensor, b: torch.Tensor):
     if a.dim() != 3:
         raise ValueError("frames must be [H, W] or [batch, H, W]")
     return a.contiguous(), b.contiguous()
+
+
+def _work(H, W, ws, ov, batch, device):
+    """Caller-provided work buffer of the function-level entry points (torch's caching allocator is
+    stream-aware, so concurrent calls on different streams get different buffers)."""
+    n = int(lib.tpiv_work_bytes(H, W, ws, ov, batch))
+    buf = torch.empty(max(n, 16), dtype=torch.uint8, device=device)
+    return buf, n
+
+
+def _precision(precision):
+    try:
+        return PRECISIONS[precision]
+    except KeyError:
+        raise KeyError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}") from None
 
 
 def field_shape(H, W, ws, ov):
@@ -67,18 +82,21 @@ def spline_matrix(xc: np.ndarray, xf: np.ndarray) -> np.ndarray:
     return A
 
 
-def pass1(a, b, ws, ov, val_ratio=1.2, val_win=3):
+def pass1(a, b, ws, ov, val_ratio=1.2, val_win=3, precision="fast"):
     """Device part of extended_search_area_piv(validate=True). Returns u, v (float64) and
-    invalid (uint8), each [batch, n_rows, n_cols], on the frames' device."""
+    invalid (uint8), each [batch, n_rows, n_cols], on the frames' device.
+    precision: "fast" (float32 transforms) or "reference" (float64 like PIVbackend.py:513-514)."""
     a, b = _frames(a, b)
     B, H, W = a.shape
+    prec = _precision(precision)
     nr, nc = field_shape(H, W, ws, ov)
     u = torch.empty(B, nr, nc, dtype=torch.float64, device=a.device)
     v = torch.empty_like(u)
     inv = torch.empty(B, nr, nc, dtype=torch.uint8, device=a.device)
     with torch.cuda.device(a.device):
-        check(lib.tpiv_pass1(a.data_ptr(), b.data_ptr(), B, H, W, ws, ov, val_ratio, val_win,
-                             u.data_ptr(), v.data_ptr(), inv.data_ptr(), _stream()))
+        work, nbytes = _work(H, W, ws, ov, B, a.device)
+        check(lib.tpiv_pass1(a.data_ptr(), b.data_ptr(), B, H, W, ws, ov, val_ratio, val_win, prec,
+                             u.data_ptr(), v.data_ptr(), inv.data_ptr(), work.data_ptr(), nbytes, _stream()))
     return u, v, inv
 
 
@@ -111,12 +129,13 @@ def iterate(mode, a, b, ws, ov, u0, v0, u2, v2, val_ratio=1.2, val_win=3, want_r
     du = torch.empty_like(u) if want_raw else None
     dv = torch.empty_like(u) if want_raw else None
     with torch.cuda.device(dev):
+        work, nbytes = _work(H, W, ws, ov, B, dev)
         check(lib.tpiv_iter(MODES[mode], a.data_ptr(), b.data_ptr(), B, H, W, ws, ov,
                             u0.contiguous().data_ptr(), v0.contiguous().data_ptr(),
                             u2.contiguous().data_ptr(), v2.contiguous().data_ptr(),
                             val_ratio, val_win, u.data_ptr(), v.data_ptr(), inv.data_ptr(),
                             du.data_ptr() if want_raw else None, dv.data_ptr() if want_raw else None,
-                            _stream()))
+                            work.data_ptr(), nbytes, _stream()))
     if want_raw:
         return u, v, inv, du, dv
     return u, v, inv
@@ -135,26 +154,31 @@ def debug_pass(mode, a, b, ws, ov, u2=None, v2=None):
     win = torch.empty(B, N, 2, ws, ws, dtype=torch.float32, device=dev)
     corr = torch.empty(B, N, ws, ws, dtype=torch.float32, device=dev)
     m = 0 if mode in (0, None, "PASS1") else MODES[mode]
+    zero = torch.zeros(B, nr, nc, dtype=torch.float64, device=dev) if m else None
     with torch.cuda.device(dev):
+        work, nbytes = _work(H, W, ws, ov, B, dev)
         check(lib.tpiv_debug_pass(m, a.data_ptr(), b.data_ptr(), B, H, W, ws, ov,
                                   u2.contiguous().data_ptr() if u2 is not None else None,
                                   v2.contiguous().data_ptr() if v2 is not None else None,
+                                  zero.data_ptr() if zero is not None else None,
                                   u.data_ptr(), v.data_ptr(), inv.data_ptr(), win.data_ptr(),
-                                  corr.data_ptr(), _stream()))
+                                  corr.data_ptr(), work.data_ptr(), nbytes, _stream()))
     return u, v, inv, win, corr
 
 
-def debug_peaks(maps: torch.Tensor, val_ratio=1.2, val_win=3):
-    """Test hook: the kernels' peak analysis on hand-made correlation maps [n, ws, ws] (ws 8 or 16)."""
+def debug_peaks(maps: torch.Tensor, val_ratio=1.2, val_win=3, planar=False):
+    """Test hook: the kernels' peak analysis on hand-made correlation maps [n, ws, ws], ws in
+    8/16/32/64/128.  planar selects the LDS layout of the three-wavefront tile kernels."""
     _need_cuda(maps)
     maps = maps.contiguous().float()
     n, ws = maps.shape[0], maps.shape[-1]
     u = torch.empty(n, dtype=torch.float64, device=maps.device)
     v = torch.empty_like(u)
     inv = torch.empty(n, dtype=torch.uint8, device=maps.device)
+    work = torch.empty(max(n * 32, 16), dtype=torch.uint8, device=maps.device)
     with torch.cuda.device(maps.device):
-        check(lib.tpiv_debug_peaks(maps.data_ptr(), n, ws, float(val_ratio), int(val_win), u.data_ptr(),
-                                   v.data_ptr(), inv.data_ptr(), _stream()))
+        check(lib.tpiv_debug_peaks(maps.data_ptr(), n, ws, 1 if planar else 0, float(val_ratio), int(val_win),
+                                   u.data_ptr(), v.data_ptr(), inv.data_ptr(), work.data_ptr(), n * 32, _stream()))
     return u, v, inv
 
 
@@ -163,7 +187,7 @@ class Plan:
     pairs resident on one GPU.  Owns the device workspace; `run` only enqueues kernels."""
 
     def __init__(self, H, W, ws, ov, n_pass=1, mode="CWS", pass_scale=2.0, val_ratio=1.2,
-                 val_win=3, max_batch=1, device=None):
+                 val_win=3, max_batch=1, device=None, precision="fast"):
         if not torch.cuda.is_available():
             raise RuntimeError("torchpiv_amd.Plan needs a ROCm device (there is no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
@@ -172,10 +196,14 @@ class Plan:
             raise KeyError(mode)
         self._h = C.c_void_p()
         self.H, self.W, self.max_batch = H, W, max_batch
+        self.precision = precision
+        prec = _precision(precision)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         with torch.cuda.device(self.device):
             check(lib.tpiv_plan_create(C.byref(self._h), H, W, ws, ov, n_pass, MODES.get(mode, 0),
                                        float(pass_scale), float(val_ratio), int(val_win),
-                                       int(max_batch)))
+                                       int(max_batch), prec))
         self.n_pass = lib.tpiv_plan_n_pass(self._h)
         self.geometry = []
         for p in range(self.n_pass):
@@ -203,6 +231,10 @@ class Plan:
         B = a.shape[0]
         if a.shape[1] != self.H or a.shape[2] != self.W:
             raise ValueError("frame shape differs from the plan's")
+        if a.device != self.device or b.device != self.device:
+            raise ValueError(f"frames live on {a.device}, the plan on {self.device}")
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds the plan's max_batch {self.max_batch}")
         nr, nc = self.out_shape
         if out is None:
             u = torch.empty(B, nr, nc, dtype=torch.float64, device=a.device)
@@ -210,10 +242,23 @@ class Plan:
             inv = torch.empty(B, nr, nc, dtype=torch.uint8, device=a.device)
         else:
             u, v, inv = out
+            for t, dt, name in ((u, torch.float64, "u"), (v, torch.float64, "v"), (inv, torch.uint8, "invalid")):
+                if not isinstance(t, torch.Tensor) or t.dtype != dt:
+                    raise TypeError(f"out[{name}] must be a {dt} tensor")
+                if t.device != self.device:
+                    raise ValueError(f"out[{name}] lives on {t.device}, the plan on {self.device}")
+                if not t.is_contiguous() or t.dim() != 3 or t.shape[0] < B or tuple(t.shape[1:]) != (nr, nc):
+                    raise ValueError(f"out[{name}] must be contiguous [>= {B}, {nr}, {nc}], got {tuple(t.shape)}")
         with torch.cuda.device(self.device):
             check(lib.tpiv_plan_run(self._h, a.data_ptr(), b.data_ptr(), B, u.data_ptr(),
                                     v.data_ptr(), inv.data_ptr(), _stream()))
         return u, v, inv
+
+    def kernel_name(self, p):
+        """Name of the cross-correlation kernel pass p launches (bench / profile labels)."""
+        buf = C.create_string_buffer(128)
+        lib.tpiv_plan_kernel_name(self._h, p, buf, 128)
+        return buf.value.decode()
 
     def debug_predict(self, p, u_c, v_c, inv_c):
         """Test hook: the plan's banded predictor of pass p on given coarse fields."""

@@ -13,6 +13,7 @@ sums reduce across ranks with ONE all-reduce for multi-GPU runs.
 """
 from __future__ import annotations
 
+import itertools
 import os
 
 import numpy as np
@@ -22,34 +23,48 @@ from .backend import OfflinePIV
 KEYS_PAIR = ("x[mm]", "y[mm]", "Vx[m/s]", "Vy[m/s]")
 
 
+def _numbered(path: str):
+    """path, then 'stem (1).ext', 'stem (2).ext', ... -- the naming scheme of PlotterFunctions.py:16-24."""
+    stem, ext = os.path.splitext(path)
+    yield path
+    for n in itertools.count(1):
+        yield f"{stem} ({n}){ext}"
+
+
 def uniquify(path: str) -> str:
-    """PlotterFunctions.py:16-24."""
-    filename, extension = os.path.splitext(path)
-    counter = 1
-    while os.path.exists(path):
-        path = filename + " (" + str(counter) + ")" + extension
-        counter += 1
-    return path
+    """First name of the numbered series that does not exist yet (PlotterFunctions.py:16-24)."""
+    return next(p for p in _numbered(path) if not os.path.exists(p))
+
+
+def _reserve(path: str) -> str:
+    """Like uniquify, but the name is CLAIMED atomically (O_EXCL), so that two processes exporting into
+    one directory can never pick the same file (the reference is single-process and only tests)."""
+    for cand in _numbered(path):
+        try:
+            os.close(os.open(cand, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o644))
+            return cand
+        except FileExistsError:
+            continue
 
 
 def save_binary(name, path, data: dict, sep: str = ", "):
-    """PlotterFunctions.py:48-53: np.save of the stacked values (dict order)."""
-    if not os.path.exists(path):
-        os.mkdir(path)
-    path = uniquify(os.path.join(path, name))
-    np.save(path, np.stack(list(data.values()), axis=0))
-    return path
+    """PlotterFunctions.py:48-53: one .npy holding the dict's arrays stacked along a new first axis, in
+    dict order.  Returns the path written."""
+    os.makedirs(path, exist_ok=True)
+    target = _reserve(os.path.join(path, name))
+    with open(target, "wb") as f:
+        np.save(f, np.stack([np.asarray(v) for v in data.values()], axis=0))
+    return target
 
 
 def save_table(name, path, data: dict, sep: str = ", "):
-    """PlotterFunctions.py:55-65: one flattened column per key, header = keys, '%.6f'."""
-    cols = [np.asarray(v).reshape(-1) for v in data.values()]
-    if not os.path.exists(path):
-        os.mkdir(path)
-    path = uniquify(os.path.join(path, name))
-    np.savetxt(path, np.stack(cols, axis=1), delimiter=sep, header=sep.join(data.keys()), comments="",
-               fmt="%.6f")
-    return path
+    """PlotterFunctions.py:55-65: a text table, one column per key (arrays flattened row-major), the
+    keys joined by `sep` as header line, numbers as '%.6f'.  Returns the path written."""
+    os.makedirs(path, exist_ok=True)
+    table = np.column_stack([np.ravel(np.asarray(v)) for v in data.values()])
+    target = _reserve(os.path.join(path, name))
+    np.savetxt(target, table, fmt="%.6f", delimiter=sep, header=sep.join(data), comments="")
+    return target
 
 
 class EnsembleStats:
@@ -158,10 +173,13 @@ def run_folder(folder: str, device: str, file_fmt: str, wind_size: int, overlap:
         stats.add(u, v)
         done += 1
         output = dict(zip(KEYS_PAIR, (x, y, u, v)))
+        # single process: the reference's names (numbered in processing order); several ranks: the
+        # dataset index goes into the name, so that files map to pairs whatever the interleaving
+        tag = f"_pair_{i:06d}" if world > 1 else "_pair"
         if save_opt == "Save all binary":
-            save_binary(f"{name}_pair.npy", save_dir, output.copy())
+            save_binary(f"{name}{tag}.npy", save_dir, output.copy())
         elif save_opt == "Save all text":
-            save_table(f"{name}_pair.txt", save_dir, output.copy())
+            save_table(f"{name}{tag}.txt", save_dir, output.copy())
         if on_pair is not None:
             on_pair(i, output)
     if distributed and world > 1:
