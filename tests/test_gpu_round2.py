@@ -10,7 +10,7 @@ import torch
 
 from oracle import piv_oracle as O
 from test_gpu_parity import (TOL_PX, cascade_check, check_fields, constant_windows, dev, fp32_noise_excuse,
-                             staged_windows)
+                             pass1_constant, staged_windows)
 
 pytestmark = pytest.mark.gpu
 
@@ -47,12 +47,14 @@ def exact_tie_windows(a, b, ws, ov):
 def check_reference_precision(eng, a, b, ws, ov, ru, rv, rmask, what):
     u, v, inv = eng.pass1(dev(a), dev(b), ws, ov, precision="reference")
     u, v, inv = u[0].cpu().numpy(), v[0].cpu().numpy(), inv[0].cpu().numpy().astype(bool)
-    tie = exact_tie_windows(a, b, ws, ov)
+    const = pass1_constant(a, b, ws, ov)           # flat maps (saturated / black blocks): every cell ties
+    tie = exact_tie_windows(a, b, ws, ov) | const
     err = np.maximum(np.abs(u - ru), np.abs(v - rv))
     flips = inv != rmask
-    n_tie = int(tie.sum())
+    n_tie = int((tie & ~const).sum())
     print(f"  reference precision {what} (ws {ws}): max |d| {err[~tie].max() if (~tie).any() else 0:.2e} px over "
-          f"{err.size - n_tie} windows, mask flips {int((flips & ~tie).sum())}, exact float64 ties {n_tie}")
+          f"{err.size - int(tie.sum())} windows, mask flips {int((flips & ~tie).sum())}, exact float64 ties {n_tie}, "
+          f"constant-input windows {int(const.sum())} (of which differing: {int((const & (flips | (err > TOL_REF))).sum())})")
     assert n_tie <= 0.002 * tie.size + 1, (what, n_tie)          # genuine ties are rare
     assert not (flips & ~tie).any(), (what, np.argwhere(flips & ~tie)[:5].tolist())
     assert err[~tie].max() <= TOL_REF, (what, float(err[~tie].max()), np.argwhere((err > TOL_REF) & ~tie)[:5].tolist())
