@@ -55,7 +55,7 @@ def check_reference_precision(eng, a, b, ws, ov, ru, rv, rmask, what):
     print(f"  reference precision {what} (ws {ws}): max |d| {err[~tie].max() if (~tie).any() else 0:.2e} px over "
           f"{err.size - int(tie.sum())} windows, mask flips {int((flips & ~tie).sum())}, exact float64 ties {n_tie}, "
           f"constant-input windows {int(const.sum())} (of which differing: {int((const & (flips | (err > TOL_REF))).sum())})")
-    assert n_tie <= 0.002 * tie.size + 1, (what, n_tie)          # genuine ties are rare
+    assert n_tie <= 0.01 * tie.size, (what, n_tie)          # genuine ties are rare (the same 1 % cap as elsewhere)
     assert not (flips & ~tie).any(), (what, np.argwhere(flips & ~tie)[:5].tolist())
     assert err[~tie].max() <= TOL_REF, (what, float(err[~tie].max()), np.argwhere((err > TOL_REF) & ~tie)[:5].tolist())
 
