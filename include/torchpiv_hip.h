@@ -142,6 +142,25 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a_dev, const uint8_t* b_dev, i
 int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u_dev, double** v_dev,
                           uint8_t** invalid_dev);
 
+/* ---- post-validation (B:884-892) ------------------------------------------------- */
+
+/* Device part of the reference's per-pair host post-processing, for a whole batch:
+ *   u[val] = v[val] = NaN (B:885-886; `invalid_dev` plays the NaN mask, u/v are not overwritten with NaN),
+ *   interpolate_boarders (B:328-344) on u and v in place,
+ *   the ring / hole census of getPixelsForInterp (B:266-282) -> counts_dev [batch, 4] int32 =
+ *   {holes, ring cells, ambiguous holes, general holes}.  Both drop decisions of fillMissingValues
+ *   (B:284-308) follow from the counts: ring == 0 (nothing to interpolate from: the interpolator raises ->
+ *   pair dropped, including the "no invalid vector" quirk) and 4 * ring >= n_rows * n_cols ("to many false
+ *   vectors").
+ *   Holes whose Delaunay-linear value does not depend on the triangulation (both N and S, or both E and W,
+ *   neighbours valid, but not all four) are filled in place: (N + S) / 2 resp. (E + W) / 2.  Holes with all
+ *   four neighbours valid (co-circular diamond: Qhull's tie-break decides between the two) and holes inside
+ *   wider gaps are only classified; a pair with ambiguous + general > 0 needs the host triangulation.
+ * cls_dev [batch, n_rows, n_cols] uint8: 0 valid, 2 hole filled here, 3 ambiguous hole, 4 general hole,
+ * 5 ring cell.  Needs n_rows, n_cols >= 2. */
+int tpiv_postval(double* u_dev, double* v_dev, const uint8_t* invalid_dev, int batch, int n_rows, int n_cols,
+                 uint8_t* cls_dev, int32_t* counts_dev, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------ */
 
 /* Per-kernel timing with hipEvents recorded on the run's own stream (torch.cuda.Event only

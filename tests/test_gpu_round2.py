@@ -165,3 +165,152 @@ def test_plan_out_validation(eng):
     with pytest.raises(ValueError):
         plan.run(torch.zeros(3, 128, 128, dtype=torch.uint8).cuda(), torch.zeros(3, 128, 128, dtype=torch.uint8).cuda())
     plan.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# post-validation on the device (tpiv_postval) against the host SciPy path (= the reference's, pinned by
+# tests/test_host_logic.py::test_post_validation_matches_reference on golden g6 pv_*)
+# ---------------------------------------------------------------------------------------------
+def _host_postval(u, v, val):
+    from torchpiv_amd import backend as Bk
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return Bk.post_validate(u.copy(), v.copy(), val)
+
+
+def _random_masks(rng, nr, nc):
+    """Hole patterns: isolated cells (co-circular diamonds), straight runs, blobs, border cells, whole
+    border edges, and the two drop cases (no hole; too many)."""
+    cases = []
+    m = np.zeros((nr, nc), bool)
+    cases.append(("none", m.copy()))
+    m = rng.random((nr, nc)) < 0.02
+    cases.append(("isolated", m))
+    m = np.zeros((nr, nc), bool)
+    m[3, 2:7] = True
+    m[6:11, 9] = True
+    m[12, 4:6] = True
+    cases.append(("runs only", m))                                    # device-complete
+    m = np.zeros((nr, nc), bool)
+    m[4:7, 5:9] = True
+    m[10, 10] = m[10, 12] = True
+    cases.append(("blob", m))
+    m = np.zeros((nr, nc), bool)
+    m[0, :] = True
+    m[5, 0] = m[nr - 1, 3:6] = m[2:4, nc - 1] = True
+    m[0, 0] = m[nr - 1, nc - 1] = True
+    cases.append(("edges", m))
+    m = rng.random((nr, nc)) < 0.3
+    cases.append(("too many", m))
+    m = np.zeros((nr, nc), bool)
+    m[1:nr - 1, 1] = True
+    m[1, 3:8] = True
+    cases.append(("runs next to the border", m))
+    m = np.ones((nr, nc), bool)
+    cases.append(("all invalid", m))
+    m = np.zeros((nr, nc), bool)
+    m[:, 0] = m[:, nc - 1] = True
+    m[0, :] = m[nr - 1, :] = True
+    cases.append(("whole frame border", m))
+    return cases
+
+
+def test_postval_device_vs_host(eng, golden):
+    """tpiv_postval on crafted masks: border interpolation bit-compatible with np.interp, the census
+    reproduces both drop decisions, device fills equal the Delaunay fill, classes are right."""
+    rng = np.random.default_rng(3)
+    nr, nc = 17, 23
+    names, us, vs, ms = [], [], [], []
+    for name, m in _random_masks(rng, nr, nc):
+        names.append(name)
+        us.append(rng.standard_normal((nr, nc)) * 4 + 2)
+        vs.append(rng.standard_normal((nr, nc)) * 3 - 1)
+        ms.append(m)
+    g = golden("g6_kats")          # the reference's own KAT: NaN pattern of pv_in
+    pv = g["pv_in"]
+    U = torch.from_numpy(np.stack(us)).cuda()
+    V = torch.from_numpy(np.stack(vs)).cuda()
+    M = torch.from_numpy(np.stack(ms).astype(np.uint8)).cuda()
+    cls, counts = eng.postval(U, V, M)
+    cls, counts, Ud, Vd = cls.cpu().numpy(), counts.cpu().numpy(), U.cpu().numpy(), V.cpu().numpy()
+    from torchpiv_amd import backend as Bk
+    for k, name in enumerate(names):
+        u0, v0, m = us[k].copy(), vs[k].copy(), ms[k]
+        u0[m] = np.nan
+        v0[m] = np.nan
+        ub, vb = Bk.interpolate_boarders(u0.copy()), Bk.interpolate_boarders(v0.copy())
+        hole = np.isnan(ub)
+        assert np.array_equal(hole, (cls[k] >= 1) & (cls[k] <= 4)), name
+        ring, _ = Bk.getPixelsForInterp(ub)
+        assert np.array_equal(ring, cls[k] == 5), name
+        assert counts[k, 0] == hole.sum() and counts[k, 1] == ring.sum(), name
+        # border interpolation: np.interp arithmetic, bit for bit, on every cell the device did not fill
+        untouched = ~hole
+        assert np.array_equal(Ud[k][untouched], ub[untouched]) and np.array_equal(Vd[k][untouched], vb[untouched]), name
+        hu, hv = _host_postval(us[k], vs[k], m)
+        dropped = ring.sum() == 0 or 4 * ring.sum() >= nr * nc
+        if hu is None:
+            # the census reproduces the drop, or Qhull refused the ring (a host-fallback pair by class)
+            assert dropped or (counts[k, 2] + counts[k, 3]) > 0, name
+            continue
+        assert not dropped, name
+        filled = cls[k] == 2
+        assert np.allclose(Ud[k][filled], hu[filled], rtol=0, atol=1e-12), name
+        assert np.allclose(Vd[k][filled], hv[filled], rtol=0, atol=1e-12), name
+        if counts[k, 2] + counts[k, 3] == 0:
+            assert np.allclose(Ud[k], hu, rtol=0, atol=1e-12, equal_nan=True), name
+        print(f"  postval '{name}': holes {counts[k, 0]}, ring {counts[k, 1]}, ambiguous {counts[k, 2]}, "
+              f"general {counts[k, 3]}, filled on the device {int(filled.sum())}")
+    # the reference's KAT (golden g6 pv_*): same NaN pattern through the device path
+    m = np.isnan(pv)
+    u = np.where(m, 0.0, pv)
+    U = torch.from_numpy(u[None].copy()).cuda()
+    V = torch.from_numpy(u[None].copy()).cuda()
+    cls, counts = eng.postval(U, V, torch.from_numpy(m[None].astype(np.uint8)).cuda())
+    got = U[0].cpu().numpy()
+    keep = cls[0].cpu().numpy() != 3
+    keep &= cls[0].cpu().numpy() != 4
+    assert np.allclose(got[keep], g["pv_filled"][keep], rtol=0, atol=1e-12)
+    hole = (cls[0].cpu().numpy() >= 1) & (cls[0].cpu().numpy() <= 4)
+    assert np.array_equal(got[~hole], g["pv_borders"][~hole])
+
+
+def test_resident_generator_equals_host_post_validation(eng):
+    """ResidentPIV (device post-validation + counted host fallbacks) against the same kernels' raw fields
+    pushed through the host-only reference path: identical drops, values to 1e-12."""
+    import torchpiv_amd as T
+    from torchpiv_amd import synth
+    H, W = 512, 640
+    A, B = [], []
+    for i in range(6):
+        a, b = synth.make_pair(H, W, 300 + i, kind=("wavy", "vortex", "shear")[i % 3], noise=(0.0, 3.0, 8.0)[i % 3])
+        if i in (1, 4):
+            a[100:140, 200:330] = 0            # a dead patch: a blob of invalid vectors in pass 2
+            b[100:140, 200:330] = 0
+        if i == 5:
+            a[:, :] = 7                        # constant frame: everything invalid -> "too many" / no ring
+        A.append(a)
+        B.append(b)
+    A, B = torch.stack(A).cuda(), torch.stack(B).cuda()
+    piv = T.ResidentPIV(A, B, 32, 16, multipass=2, multipass_mode="CWS", dt=2, scale=0.5)
+    res = {i: (x, y, u, v) for i, x, y, u, v in piv.batched(4)}
+    plan = eng.Plan(H, W, 32, 16, n_pass=2, mode="CWS", max_batch=6)
+    u, v, inv = plan.run(A, B)
+    u, v, inv = u.cpu().numpy(), v.cpu().numpy(), inv.cpu().numpy().astype(bool)
+    n_kept = 0
+    for i in range(6):
+        hu, hv = _host_postval(u[i], v[i], inv[i])
+        if hu is None:
+            assert i not in res, i
+            continue
+        n_kept += 1
+        assert i in res, i
+        x, y, gu, gv = res[i]
+        wu = np.flip(hu, axis=0) * 0.5 / 2 * 1000
+        wv = -np.flip(hv, axis=0) * 0.5 / 2 * 1000
+        assert np.allclose(gu, wu, rtol=0, atol=1e-9, equal_nan=True) and np.allclose(gv, wv, rtol=0, atol=1e-9, equal_nan=True), i
+    st = piv.stats
+    print("  post-validation stats:", st)
+    assert st["pairs"] == 6 and st["device_complete"] + st["host_fallback"] - st["dropped_by_qhull"] == n_kept
+    assert list(piv()) and len(list(piv())) == n_kept
+    plan.close()

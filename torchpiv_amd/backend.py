@@ -6,8 +6,13 @@ What runs where
   * device (libtorchpiv_hip.so): every pass of a pair -- windows, shift, FFT correlation,
     peak, validation, predictor, combine -- with the fields staying on the GPU between passes
     (the reference does three D2H copies and one H2D per pass);
-  * host (this file): dataset/decoding, the post-validation hole fill of B:884-892
-    (numpy + scipy, as in the reference), flip and unit scaling, the generator protocol.
+  * device, batched (tpiv_postval): the post-validation of B:884-892 as far as it does not depend on
+    Qhull's tie-breaking -- NaN-out, border interpolation, the ring / hole census (both drop decisions
+    follow from it, so dropped pairs never leave the GPU) and every hole whose Delaunay-linear value is
+    fixed by its N/S or E/W neighbours;
+  * host (this file): dataset/decoding, the Delaunay hole fill (scipy/Qhull, as in the reference) for
+    the pairs that still hold an ambiguous or wide hole -- counted in OfflinePIV.stats --, flip and
+    unit scaling, the generator protocol.
 
 There is no CPU compute path: device="cpu" raises.
 """
@@ -255,6 +260,29 @@ def post_validate(u, v, val):
     return u, v
 
 
+def fill_holes_host(u: np.ndarray, v: np.ndarray, hole: np.ndarray):
+    """fillMissingValues (B:284-308) for u AND v with ONE triangulation: both fields carry the same
+    holes, so the reference's two interpolators triangulate the same ring points in the same order
+    and apply the same barycentric weights; evaluating a two-column interpolator is bit-identical.
+    u, v are filled in place; returns False when the reference would drop the pair (Qhull refuses
+    the ring, e.g. collinear points; the size test is done by the caller from the ring count)."""
+    from scipy.interpolate import LinearNDInterpolator
+    ring = np.zeros_like(hole)
+    ring[1:, :] |= hole[:-1, :]
+    ring[:-1, :] |= hole[1:, :]
+    ring[:, 1:] |= hole[:, :-1]
+    ring[:, :-1] |= hole[:, 1:]
+    ring &= ~hole
+    try:
+        interp = LinearNDInterpolator(np.argwhere(ring), np.stack([u[ring], v[ring]], axis=1))
+        vals = interp(np.argwhere(hole))
+    except Exception:
+        return False
+    u[hole] = vals[:, 0]
+    v[hole] = vals[:, 1]
+    return True
+
+
 def free_cuda_memory():
     torch.cuda.empty_cache()
 
@@ -292,6 +320,7 @@ class OfflinePIV:
         self._iter_function = IterModMap.functions[multipass_mode]      # KeyError like B:850
         self._mode = multipass_mode
         self._plan = None
+        self.reset_stats()
         if not self:
             return
         _require_gpu(self._device)
@@ -318,10 +347,60 @@ class OfflinePIV:
                                      device=self._device, precision=self._precision)
         return self._plan
 
-    def _finish(self, u, v, val, x, y):
-        u, v = post_validate(u, v, val)
-        if u is None:
+    def reset_stats(self):
+        """Counters of the post-validation: pairs seen, dropped for 'no invalid vector' / 'too many
+        false vectors' (decided on the device), finished on the device alone, sent to the host
+        triangulation (and dropped there because Qhull refused the ring)."""
+        self.stats = {"pairs": 0, "dropped_no_invalid": 0, "dropped_too_many": 0, "device_complete": 0,
+                      "host_fallback": 0, "dropped_by_qhull": 0}
+
+    def _post_validate_batch(self, u, v, inv):
+        """B:884-892 for a batch of final fields on the device.  u, v float64 [n, nr, nc] (modified in
+        place), inv uint8.  Returns a list with one entry per pair: None (dropped) or (u, v) numpy
+        arrays before the flip / scaling.  One small D2H (the census) decides the drops; only the
+        surviving pairs are copied back."""
+        n, nr, nc = u.shape
+        cls, counts = engine.postval(u, v, inv)
+        cnt = counts.cpu().numpy().astype(np.int64)                  # [n, 4] holes, ring, ambiguous, general
+        ring = cnt[:, 1]
+        no_ring = ring == 0                  # nothing to interpolate from (B:300-304; the clean-pair quirk)
+        too_many = ~no_ring & (4 * ring >= nr * nc)                  # points.size >= mask.size / 2 (B:299, 305)
+        keep = ~no_ring & ~too_many
+        need_host = keep & ((cnt[:, 2] + cnt[:, 3]) > 0)
+        st = self.stats
+        st["pairs"] += n
+        st["dropped_no_invalid"] += int(no_ring.sum())
+        st["dropped_too_many"] += int(too_many.sum())
+        for _ in range(2 * int(too_many.sum())):                  # once for u, once for v (B:306, B:889-890)
+            print("Warning! to many false vectors")
+        out = [None] * n
+        idx = np.flatnonzero(keep)
+        if idx.size == 0:
+            return out
+        sel = torch.from_numpy(idx).to(u.device)
+        uk = u.index_select(0, sel).cpu().numpy()
+        vk = v.index_select(0, sel).cpu().numpy()
+        hidx = np.flatnonzero(need_host[idx])
+        ck = cls.index_select(0, sel[torch.from_numpy(hidx).to(u.device)]).cpu().numpy() if hidx.size else None
+        pos = {int(h): j for j, h in enumerate(hidx)}
+        for k, i in enumerate(idx):
+            if k in pos:
+                st["host_fallback"] += 1
+                c = ck[pos[k]]
+                hole = (c >= 1) & (c <= 4)
+                if not fill_holes_host(uk[k], vk[k], hole):
+                    st["dropped_by_qhull"] += 1
+                    continue
+            else:
+                st["device_complete"] += 1
+            out[int(i)] = (uk[k], vk[k])
+        return out
+
+    def _finish(self, uv, x, y):
+        """Flip and unit scaling of B:894-898 (numpy, the reference's own expressions)."""
+        if uv is None:
             return None
+        u, v = uv
         u = np.flip(u, axis=0)
         v = -np.flip(v, axis=0)
         u = u * self._scale / self._dt * 1000
@@ -343,8 +422,7 @@ class OfflinePIV:
             u, v, inv = plan.run(a, b)
             w, o, _, _ = plan.geometry[-1]
             x, y = get_coordinates(a.shape, w, o)
-            out = self._finish(u[0].cpu().numpy(), v[0].cpu().numpy(),
-                               inv[0].cpu().numpy().astype(bool), x, y)
+            out = self._finish(self._post_validate_batch(u, v, inv)[0], x, y)
             if out is None:
                 continue
             yield out
@@ -417,9 +495,62 @@ class OfflinePIV:
             u, v, inv = plan.run(A, B)
             up.synchronize()                  # staging buffer may be refilled now
             free[buf].set()
-            u, v, inv = u.cpu().numpy(), v.cpu().numpy(), inv.cpu().numpy().astype(bool)
-            for k, i in enumerate(chunk):
-                out = self._finish(u[k], v[k], inv[k], x, y)
+            for i, uv in zip(chunk, self._post_validate_batch(u, v, inv)):
+                out = self._finish(uv, x, y)
                 if out is not None:
                     yield (i,) + out
         th.join()
+
+
+class ResidentPIV(OfflinePIV):
+    """OfflinePIV over frame pairs that already live on the GPU (uint8 tensors [n, H, W]): the same
+    passes, post-validation, flip and scaling, without dataset / decoding / upload.  Extension used by
+    the end-to-end benchmark and by callers that acquire straight into device memory."""
+
+    def __init__(self, frames_a: torch.Tensor, frames_b: torch.Tensor, wind_size: int, overlap: int,
+                 multipass: int = 1, multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.,
+                 multipass_scale: float = 2., precision: str = "fast") -> None:
+        if frames_a.shape != frames_b.shape or frames_a.dim() != 3 or frames_a.dtype != torch.uint8 \
+                or frames_b.dtype != torch.uint8:
+            raise ValueError("ResidentPIV: two uint8 tensors [n, H, W] of one shape")
+        if precision not in ("fast", "reference"):
+            raise KeyError(precision)
+        self._precision = precision
+        self._wind_size, self._overlap, self._dt = wind_size, overlap, dt
+        self._iter, self._iter_scale, self._scale = multipass, multipass_scale, scale
+        self._device = _require_gpu(frames_a.device)
+        self._iter_function = IterModMap.functions[multipass_mode]
+        self._mode = multipass_mode
+        self._plan = None
+        self._A, self._B = frames_a.contiguous(), frames_b.contiguous()
+        self._dataset = range(frames_a.shape[0])
+        self.reset_stats()
+
+    def frame_shape(self):
+        return tuple(self._A.shape[1:]) if len(self) else None
+
+    def batched(self, batch_size: int = 32, indices=None) -> Generator:
+        idx = list(range(len(self))) if indices is None else list(indices)
+        if not idx:
+            return
+        H, W = self._A.shape[1:]
+        plan = self._get_plan(H, W, max_batch=batch_size)
+        w, o, _, _ = plan.geometry[-1]
+        x, y = get_coordinates((H, W), w, o)
+        contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
+        for s in range(0, len(idx), batch_size):
+            chunk = idx[s:s + batch_size]
+            if contiguous:
+                A, B = self._A[chunk[0]:chunk[0] + len(chunk)], self._B[chunk[0]:chunk[0] + len(chunk)]
+            else:
+                sel = torch.tensor(chunk, device=self._device)
+                A, B = self._A.index_select(0, sel), self._B.index_select(0, sel)
+            u, v, inv = plan.run(A, B)
+            for i, uv in zip(chunk, self._post_validate_batch(u, v, inv)):
+                out = self._finish(uv, x, y)
+                if out is not None:
+                    yield (i,) + out
+
+    def __call__(self) -> Generator:
+        for _, x, y, u, v in self.batched(1):
+            yield x, y, u, v

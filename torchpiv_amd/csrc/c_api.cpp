@@ -784,6 +784,25 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
     return TPIV_OK;
 }
 
+int tpiv_postval(double* u, double* v, const uint8_t* invalid, int batch, int n_rows, int n_cols, uint8_t* cls,
+                 int32_t* counts, void* stream) {
+    if (batch < 0 || n_rows < 2 || n_cols < 2) return fail(TPIV_EINVAL, "tpiv_postval: needs a grid of at least 2 x 2");
+    if ((long long)n_rows * n_cols >= (1LL << 31)) return fail(TPIV_EUNSUPPORTED, "field too large");
+    if (batch == 0) return TPIV_OK;
+    if (!u || !v || !invalid || !cls || !counts) return fail(TPIV_EINVAL, "tpiv_postval: null pointer");
+    tpiv::PostvalParams q{};
+    q.u = u;
+    q.v = v;
+    q.invalid = invalid;
+    q.cls = cls;
+    q.counts = counts;
+    q.batch = batch;
+    q.n_rows = n_rows;
+    q.n_cols = n_cols;
+    HIP_TRY(tpiv::launch_postval(q, (hipStream_t)stream));
+    return TPIV_OK;
+}
+
 // Diagnostic builds (make stamps): device buffer of 32 uint64 that the tile kernels add their
 // per-phase s_memtime deltas to.  Not declared in the public header: the production library
 // ignores it (the stamp code is compiled out).

@@ -86,6 +86,18 @@ struct BandedPredictParams {
     double* v2;
 };
 
+// post-validation on the device (postval.hip)
+struct PostvalParams {
+    double* u;               // [batch, n_rows, n_cols], modified in place (border interpolation, determined fills)
+    double* v;
+    const uint8_t* invalid;  // [batch, n_rows, n_cols] 1 = invalid vector
+    uint8_t* cls;            // out [batch, n_rows, n_cols]: 0 valid, 2 hole filled here, 3 ambiguous hole,
+                             //     4 general hole, 5 ring (valid cell next to a hole)
+    int* counts;             // out [batch, 4]: holes, ring cells, ambiguous holes, general holes
+    int batch, n_rows, n_cols;
+};
+hipError_t launch_postval(const PostvalParams& p, hipStream_t stream);
+
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 // wavefronts per SIMD the tile kernel of (ws, mode) is built for (the OCC template argument of
 // xcorr_tile_kernel); 0 for sizes that run another kernel

@@ -1,0 +1,168 @@
+// Post-validation of the final fields on the device, batched over pairs.
+//
+// Reference (PIVbackend.py:884-892, per pair, on the host):  u[val] = v[val] = NaN;
+// interpolate_boarders (B:328-344): 1-D np.interp along the first / last row and the first / last
+// column, in that order, an all-NaN edge is left alone;  fillMissingValues (B:284-308):
+// ring = valid cells 4-adjacent to a NaN cell (getPixelsForInterp B:266-282: OpenCV 3x3
+// MORPH_ELLIPSE = the cross, zero border); if 2 * #ring >= size / 2 the pair is dropped ("to many
+// false vectors"); otherwise scipy's LinearNDInterpolator over the Delaunay triangulation (Qhull) of
+// the ring points fills the NaN cells, and ANY exception drops the pair -- in particular "no NaN
+// cell at all" (zero points), the reference's dropped-clean-pair quirk.
+//
+// What runs here, for the whole batch at once:
+//   postval_border_kernel    the four border interpolations with np.interp's arithmetic
+//                            (slope * (x - xp[j]) + fp[j], end values outside the valid range) and the
+//                            reference's edge order (later edges see the corners filled by earlier ones);
+//   postval_classify_kernel  ring / hole census per pair (-> both drop decisions need only these counts,
+//                            so dropped pairs never leave the device) and the hole fill WHERE THE
+//                            DELAUNAY-LINEAR VALUE DOES NOT DEPEND ON THE TRIANGULATION:
+//
+//     a hole cell whose N and S neighbours are ring points while E and W are not BOTH ring points lies
+//     on the segment N-S, and that segment is an edge of EVERY Delaunay triangulation of the ring
+//     (the circle through N and S centred a quarter cell towards the missing side contains no other
+//     lattice point), so the interpolant there is (N + S) / 2; likewise (E + W) / 2.  This covers every
+//     straight run of invalid vectors.
+//
+//     A hole with all four neighbours valid (an isolated invalid vector) is the centre of a
+//     CO-CIRCULAR diamond: the triangulation may take either diagonal, the value is (N+S)/2 or
+//     (E+W)/2, and Qhull decides by the order in which it happened to insert the four vertices
+//     ('Qt' fans a non-simplicial facet from its highest vertex id) -- a function of the whole point
+//     set.  Such cells (class AMBIGUOUS) and cells inside wider holes (class GENERAL) are only
+//     counted here: pairs that contain any go to the host triangulation (torchpiv_amd/backend.py),
+//     and the fallbacks are counted.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "piv_kernels.h"
+
+namespace tpiv {
+
+namespace {
+
+// cell classes in PostvalParams::cls (one byte per cell); "hole" <=> 1 <= c <= 4
+enum : uint8_t { PV_VALID = 0, PV_HOLE = 1, PV_FILLED = 2, PV_AMBIGUOUS = 3, PV_GENERAL = 4, PV_RING = 5 };
+
+__device__ __forceinline__ bool is_hole(uint8_t c) { return c >= PV_HOLE && c <= PV_GENERAL; }
+
+// one edge of one field pair: index i of the edge -> flat cell offset base + i * stride
+__device__ void border_edge(double* __restrict__ u, double* __restrict__ v, uint8_t* __restrict__ cls, int base,
+                            int stride, int L) {
+#pragma clang fp contract(off)
+    // all-NaN edge: left alone (B:332, 335, 338, 341)
+    int any_valid = 0;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) any_valid |= !is_hole(cls[base + i * stride]);
+    any_valid = __syncthreads_or(any_valid);
+    if (!any_valid) return;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        if (!is_hole(cls[base + i * stride])) continue;
+        int l = i - 1, r = i + 1;
+        while (l >= 0 && is_hole(cls[base + l * stride])) --l;
+        while (r < L && is_hole(cls[base + r * stride])) ++r;
+        double* const f[2] = {u, v};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            double val;
+            if (l < 0) val = f[q][base + r * stride];                  // np.interp: left of xp[0] -> fp[0]
+            else if (r >= L) val = f[q][base + l * stride];            //            right of xp[-1] -> fp[-1]
+            else {
+                const double fl = f[q][base + l * stride], fr = f[q][base + r * stride];
+                const double slope = (fr - fl) / ((double)r - (double)l);
+                val = slope * ((double)i - (double)l) + fl;
+                if (val != val) val = slope * ((double)i - (double)r) + fr;      // numpy: NaN one way -> try the other
+            }
+            f[q][base + i * stride] = val;
+        }
+    }
+    __syncthreads();          // every scan of this edge is done before its cells turn valid
+    for (int i = threadIdx.x; i < L; i += blockDim.x)
+        if (is_hole(cls[base + i * stride])) cls[base + i * stride] = PV_VALID;
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void postval_border_kernel(PostvalParams p) {
+    const size_t off = (size_t)blockIdx.x * p.n_rows * p.n_cols;
+    double* u = p.u + off;
+    double* v = p.v + off;
+    uint8_t* cls = p.cls + off;
+    const uint8_t* inv = p.invalid + off;
+    const int n = p.n_rows * p.n_cols;
+    int any = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint8_t h = inv[i] ? PV_HOLE : PV_VALID;
+        cls[i] = h;
+        any |= h;
+    }
+    any = __syncthreads_or(any);
+    if (!any) return;                                            // B:329-330
+    border_edge(u, v, cls, 0, 1, p.n_cols);                                   // first row
+    border_edge(u, v, cls, (p.n_rows - 1) * p.n_cols, 1, p.n_cols);           // last row
+    border_edge(u, v, cls, 0, p.n_cols, p.n_rows);                            // first column
+    border_edge(u, v, cls, p.n_cols - 1, p.n_cols, p.n_rows);                 // last column
+}
+
+// grid (blocks per pair, batch): a block never spans two pairs, so the census needs one atomic per wave
+__global__ __launch_bounds__(256) void postval_classify_kernel(PostvalParams p) {
+    const int pair = blockIdx.y;
+    const size_t off = (size_t)pair * p.n_rows * p.n_cols;
+    double* __restrict__ u = p.u + off;
+    double* __restrict__ v = p.v + off;
+    uint8_t* cls = p.cls + off;
+    const int nr = p.n_rows, nc = p.n_cols, n = nr * nc;
+    int n_hole = 0, n_ring = 0, n_amb = 0, n_gen = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = i / nc, c = i - r * nc;
+        // neighbour is a usable (valid) cell?  out of the field: no (zero border, B:278-279)
+        const bool hN = r > 0 && is_hole(cls[i - nc]), hS = r < nr - 1 && is_hole(cls[i + nc]);
+        const bool hW = c > 0 && is_hole(cls[i - 1]), hE = c < nc - 1 && is_hole(cls[i + 1]);
+        if (!is_hole(cls[i])) {
+            if (hN || hS || hW || hE) {
+                cls[i] = PV_RING;
+                ++n_ring;
+            }
+            continue;
+        }
+        ++n_hole;
+        const bool vN = r > 0 && !hN, vS = r < nr - 1 && !hS, vW = c > 0 && !hW, vE = c < nc - 1 && !hE;
+        if (vN && vS && vW && vE) {
+            cls[i] = PV_AMBIGUOUS;
+            ++n_amb;
+        } else if (vN && vS) {
+            u[i] = (u[i - nc] + u[i + nc]) * 0.5;
+            v[i] = (v[i - nc] + v[i + nc]) * 0.5;
+            cls[i] = PV_FILLED;
+        } else if (vW && vE) {
+            u[i] = (u[i - 1] + u[i + 1]) * 0.5;
+            v[i] = (v[i - 1] + v[i + 1]) * 0.5;
+            cls[i] = PV_FILLED;
+        } else {
+            cls[i] = PV_GENERAL;
+            ++n_gen;
+        }
+    }
+    int vals[4] = {n_hole, n_ring, n_amb, n_gen};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int s = vals[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&p.counts[pair * 4 + q], s);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_postval(const PostvalParams& p, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)p.batch * 4 * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(postval_border_kernel, dim3(p.batch), dim3(256), 0, stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int n = p.n_rows * p.n_cols;
+    int bpp = (n + 256 * 8 - 1) / (256 * 8);          // ~8 cells per thread
+    if (bpp < 1) bpp = 1;
+    if (bpp > 256) bpp = 256;
+    hipLaunchKernelGGL(postval_classify_kernel, dim3(bpp, p.batch), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace tpiv

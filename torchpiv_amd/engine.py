@@ -182,6 +182,26 @@ def debug_peaks(maps: torch.Tensor, val_ratio=1.2, val_win=3, planar=False):
     return u, v, inv
 
 
+def postval(u, v, inv):
+    """Device part of the post-validation (PIVbackend.py:884-892) for a batch, IN PLACE on u, v
+    (float64 [B, nr, nc]): border interpolation, ring / hole census, fills that do not depend on the
+    Delaunay triangulation.  Returns (cls uint8 [B, nr, nc], counts int32 [B, 4] = holes, ring,
+    ambiguous, general); see include/torchpiv_hip.h tpiv_postval."""
+    _need_cuda(u, v, inv)
+    if u.dtype != torch.float64 or v.dtype != torch.float64 or inv.dtype != torch.uint8:
+        raise TypeError("postval: u, v float64 and invalid uint8")
+    if not (u.is_contiguous() and v.is_contiguous() and inv.is_contiguous()) or u.dim() != 3 \
+            or u.shape != v.shape or u.shape != inv.shape:
+        raise ValueError("postval: contiguous [batch, n_rows, n_cols] tensors of one shape")
+    B, nr, nc = u.shape
+    cls = torch.empty(B, nr, nc, dtype=torch.uint8, device=u.device)
+    counts = torch.empty(B, 4, dtype=torch.int32, device=u.device)
+    with torch.cuda.device(u.device):
+        check(lib.tpiv_postval(u.data_ptr(), v.data_ptr(), inv.data_ptr(), B, nr, nc, cls.data_ptr(),
+                               counts.data_ptr(), _stream()))
+    return cls, counts
+
+
 class Plan:
     """The multipass pipeline of OfflinePIV.__call__ (PIVbackend.py:873-882) for batches of
     pairs resident on one GPU.  Owns the device workspace; `run` only enqueues kernels."""
