@@ -22,34 +22,79 @@ def folder(tmp_path_factory, golden):
 
 
 def _close(got, want, frac_ok=0.75, tol=1e-3):
-    """Final fields after all passes and the hole fill (in px: callers divide by 1000*scale/dt).
-    A flipped validity decision upstream (a window inside the float32 rounding band of the
-    reference's own transform, see test_gpu_parity.fp32_noise_excuse) moves the predictor of the
-    finer windows around it and re-triangulates the hole fill, so a handful of flips changes a
-    whole patch of interpolated cells: numerically equivalent builds of the kernels have scored
-    0.82 - 0.91 on the worst fixture pair.  The end-to-end criterion is therefore robust: the BULK
-    must be exact (median error far below the tolerance) and at least `frac_ok` of the vectors
-    within tolerance; strict per-pass parity is tests/test_gpu_parity.py."""
+    """Loose sanity criterion for the sharded-run test only (the generator test below is strict)."""
     ok = np.isclose(got, want, rtol=0, atol=tol, equal_nan=True)
     both = np.isfinite(got) & np.isfinite(want)
     med = np.median(np.abs(got[both] - want[both])) if both.any() else 0.0
     return ok.mean() >= frac_ok and med < 1e-5
 
 
+def explained_region(a, b, ws, ov, n_pass, mode):
+    """Cells of the YIELDED field (after hole fill and flip) that may legitimately differ from the
+    reference: everything downstream of a window whose discrete decisions are a coin toss.
+      * pass 1: exact arg-max ties and constant-input windows (black / saturated blocks);
+      * pass p: the float32 noise band of the reference's own transform (fp32_noise_excuse, wide form
+        for the float32 pass 1), constant-input windows, and the cells whose spline predictor weight to
+        an excusable coarse cell is >= 1e-4;
+      * post-validation: a connected patch of (invalid or excusable) cells that contains an excusable
+        cell may re-triangulate as a whole, so the patch and its ring are explained; so is a border
+        edge that holds such a cell (1-D interpolation along the edge).
+    Computed with the CPU oracle (pinned to the reference on these very frames by
+    tests/test_oracle_golden.py::test_generator)."""
+    from scipy import ndimage
+    from oracle import piv_oracle as O
+    from test_gpu_parity import constant_windows, fp32_noise_excuse, near_tie_windows, pass1_constant
+    from torchpiv_amd import engine
+    H, W = a.shape
+    u, v, x, y, val = O.pass1(a, b, ws, ov, validate=True)
+    E = near_tie_windows(a, b, ws, ov) | pass1_constant(a, b, ws, ov)
+    w, o = ws, ov
+    for p in range(1, n_pass):
+        xc, yc = x[0, :].copy(), y[:, 0].copy()
+        w, o = w // 2, o // 2
+        it = O.ITER[mode](a.shape, w, o)
+        u, v, x, y, val, _, _, _, _, u2, v2 = it(a, b, x, y, u.copy(), v.copy(), val.copy(), debug=True)
+        Ay, Ax = engine.spline_matrix(yc, y[:, 0]), engine.spline_matrix(xc, x[0, :])
+        D = (np.abs(Ay) @ E.astype(np.float64) @ np.abs(Ax).T) >= 1e-4
+        idx = O.window_index((H, W), w, o)
+        f = (lambda t, dt: t.reshape(-1)[:, None, None].astype(dt))
+        if mode == "CWS":
+            aa = O.shift_cws(a, idx, -f(u2, np.float32), -f(v2, np.float32))
+            bb = O.shift_cws(b, idx, f(u2, np.float32), f(v2, np.float32))
+        else:
+            aa = O.shift_dws(a, idx, -f(u2, np.int64), -f(v2, np.int64))
+            bb = O.shift_dws(b, idx, f(u2, np.int64), f(v2, np.int64))
+        nr, nc = u.shape
+        E = D | fp32_noise_excuse(aa, bb, nr, nc, ulps=4096.0) | constant_windows(aa, bb, nr, nc)
+    patch, n = ndimage.label(val | E)
+    hit = np.unique(patch[E])
+    region = np.isin(patch, hit[hit > 0]) | E
+    region = ndimage.binary_dilation(region, structure=ndimage.generate_binary_structure(2, 1))
+    for sl in ((0, slice(None)), (-1, slice(None)), (slice(None), 0), (slice(None), -1)):
+        if region[sl].any():
+            region[sl] = True
+    return np.flip(region, axis=0)
+
+
 # Pair 3 of the fixture is frame_b == frame_a without noise: its predictor is ~ +-1e-8 px and the
 # reference's CWS "integral coordinate => nearest sample" quirk (PIVbackend.py:170,193) makes the
-# result depend on the SIGN of that rounding noise -- not reproducible by any other arithmetic.
+# result depend on the SIGN of that rounding noise -- not reproducible by float32 arithmetic in pass 1
+# (precision="reference" reproduces the sign and is NOT exempted).
 DEGENERATE = {("r2", 3), ("r4", 3)}
 
 
+@pytest.mark.parametrize("precision", ["fast", "reference"])
 @pytest.mark.parametrize("run", ["r1", "r2", "r3", "r4"])
-def test_offline_piv_generator(folder, golden, run):
+def test_offline_piv_generator(folder, golden, run, precision):
+    """The generator against the reference's own OfflinePIV runs: same pairs dropped, same coordinates,
+    and every cell within 1e-3 px unless it is downstream of a coin-toss window (explained_region) --
+    no fraction threshold."""
     import torchpiv_amd as T
     g = golden("g5_generator")
     ws, ov, mp_, mode, dt = (int(t) for t in g[run + "_kw"])
     scale = float(g[run + "_scale"][0])
     piv = T.OfflinePIV(folder, "cuda:0", "bmp", ws, ov, multipass=mp_, multipass_mode=("DWS", "CWS")[mode],
-                       dt=dt, scale=scale)
+                       dt=dt, scale=scale, precision=precision)
     n_all, n_yield = (int(t) for t in g[run + "_count"])
     assert len(piv) == n_all
     res = list(piv())
@@ -59,19 +104,47 @@ def test_offline_piv_generator(folder, golden, run):
         assert u.dtype == np.float64 and x.dtype == np.float64
         assert np.array_equal(x, g[f"{run}_{j}_x"]) and np.array_equal(y, g[f"{run}_{j}_y"])
         assert u.shape == g[f"{run}_{j}_u"].shape
-        if (run, yielded[j]) in DEGENERATE:
+        if precision == "fast" and (run, yielded[j]) in DEGENERATE:
             continue
         unit = 1000 * scale / dt
-        fu = np.isclose(u / unit, g[f"{run}_{j}_u"] / unit, rtol=0, atol=1e-3, equal_nan=True).mean()
-        fv = np.isclose(v / unit, g[f"{run}_{j}_v"] / unit, rtol=0, atol=1e-3, equal_nan=True).mean()
-        print(f"{run} pair {yielded[j]}: within 1e-3 px: u {fu:.4f} v {fv:.4f}")
-        assert _close(u / unit, g[f"{run}_{j}_u"] / unit), (run, j, fu)
-        assert _close(v / unit, g[f"{run}_{j}_v"] / unit), (run, j, fv)
+        bad = ~np.isclose(u / unit, g[f"{run}_{j}_u"] / unit, rtol=0, atol=1e-3, equal_nan=True)
+        bad |= ~np.isclose(v / unit, g[f"{run}_{j}_v"] / unit, rtol=0, atol=1e-3, equal_nan=True)
+        i = yielded[j]
+        region = explained_region(g["frames_a"][i], g["frames_b"][i], ws, ov, mp_, ("DWS", "CWS")[mode])
+        print(f"{run} {precision} pair {i}: {int(bad.sum())} of {bad.size} cells beyond 1e-3 px, "
+              f"{int((bad & ~region).sum())} unexplained; explained region covers {region.mean():.2f} of the field")
+        assert not (bad & ~region).any(), (run, j, np.argwhere(bad & ~region)[:6].tolist())
     # the batched extension gives the same tuples, tagged with the pair index
     res_b = list(piv.batched(batch_size=3))
     assert len(res_b) == len(res)
     for (i, x, y, u, v), (x2, y2, u2, v2) in zip(res_b, res):
         assert np.array_equal(u, u2, equal_nan=True) and np.array_equal(v, v2, equal_nan=True)
+    print("  post-validation:", piv.stats)
+
+
+def test_generator_config0_geometry(tmp_path, golden):
+    """BASELINE.json configs[0]'s geometry (64/32, ONE pass, DWS) -- the bundled test_images are absent
+    from the reference checkout, so the reference's run on seeded synthetic BMPs is the golden (g8 r5)."""
+    from PIL import Image
+    import torchpiv_amd as T
+    g = golden("g8_round2")
+    for i, (a, b) in enumerate(zip(g["r5_frames_a"], g["r5_frames_b"])):
+        Image.fromarray(a, "L").save(tmp_path / f"image{8 + i}_a.bmp")
+        Image.fromarray(b, "L").save(tmp_path / f"image{8 + i}_b.bmp")
+    for precision in ("fast", "reference"):
+        piv = T.OfflinePIV(str(tmp_path), "cuda:0", "bmp", 64, 32, multipass=1, multipass_mode="DWS", precision=precision)
+        res = list(piv())
+        assert len(piv) == int(g["r5_count"][0]) and len(res) == int(g["r5_count"][1]) > 0
+        yielded = [i for i, *_ in piv.batched(batch_size=4)]
+        for j, (x, y, u, v) in enumerate(res):
+            assert np.array_equal(x, g[f"r5_{j}_x"]) and np.array_equal(y, g[f"r5_{j}_y"])
+            bad = ~np.isclose(u / 1000, g[f"r5_{j}_u"] / 1000, rtol=0, atol=1e-3, equal_nan=True)
+            bad |= ~np.isclose(v / 1000, g[f"r5_{j}_v"] / 1000, rtol=0, atol=1e-3, equal_nan=True)
+            i = yielded[j]
+            region = explained_region(g["r5_frames_a"][i], g["r5_frames_b"][i], 64, 32, 1, "DWS")
+            print(f"r5 {precision} pair {i}: {int(bad.sum())} of {bad.size} cells beyond 1e-3 px, "
+                  f"{int((bad & ~region).sum())} unexplained; explained region {region.mean():.2f}")
+            assert not (bad & ~region).any()
 
 
 def test_function_seam_signatures(golden):
