@@ -34,8 +34,9 @@ def explained_region(a, b, ws, ov, n_pass, mode):
     reference: everything downstream of a window whose discrete decisions are a coin toss.
       * pass 1: exact arg-max ties and constant-input windows (black / saturated blocks);
       * pass p: the float32 noise band of the reference's own transform (fp32_noise_excuse, wide form
-        for the float32 pass 1), constant-input windows, and the cells whose spline predictor weight to
-        an excusable coarse cell is >= 1e-4;
+        for the float32 pass 1, including ill-conditioned sub-pixel fits: a peak neighbour at the map
+        minimum), constant-input windows, and the cells whose spline predictor weight to an excusable
+        coarse cell is >= 1e-4;
       * post-validation: a connected patch of (invalid or excusable) cells that contains an excusable
         cell may re-triangulate as a whole, so the patch and its ring are explained; so is a border
         edge that holds such a cell (1-D interpolation along the edge).
@@ -65,7 +66,7 @@ def explained_region(a, b, ws, ov, n_pass, mode):
             aa = O.shift_dws(a, idx, -f(u2, np.int64), -f(v2, np.int64))
             bb = O.shift_dws(b, idx, f(u2, np.int64), f(v2, np.int64))
         nr, nc = u.shape
-        E = D | fp32_noise_excuse(aa, bb, nr, nc, ulps=4096.0) | constant_windows(aa, bb, nr, nc)
+        E = D | fp32_noise_excuse(aa, bb, nr, nc, ulps=4096.0, fit_tol=0.5e-3) | constant_windows(aa, bb, nr, nc)
     patch, n = ndimage.label(val | E)
     hit = np.unique(patch[E])
     region = np.isin(patch, hit[hit > 0]) | E
