@@ -5,11 +5,12 @@
 // correalte_fft B:249-257 runs rfft2 / irfft2 in complex128, `corr - corr.min()` B:518 and
 // correlation_to_displacement B:360-422 on the float64 map).  The float32 tile kernels
 // (xcorr_tile.hpp) hold a whole line per lane in registers; a 64-point complex float64 line would
-// need 256 VGPRs, so this kernel keeps the packed tile Z = a/mean(a) + i b/mean(b) in LDS as two
-// planes of doubles (WS = 64: 2 x 33 KB, two workgroups per CU) and transforms it IN PLACE:
+// need 256 VGPRs, so this kernel keeps the packed tile Z = a/mean(a) + i b/mean(b) in LDS (16-byte
+// complex elements, WS = 64: 66.6 KB, two workgroups per CU) and transforms it IN PLACE:
 //
-//   forward  decimation in frequency, radix 4 (radix 2 first when log2 WS is odd): natural order in,
-//            digit-reversed order out -- along x, then along y;
+//   forward  decimation in frequency, radix 8 (then 4 or 2 for what is left of the length): natural
+//            order in, digit-reversed order out -- along x, then along y; two LDS passes per
+//            dimension for WS = 64, and only the first of them carries non-trivial twiddles;
 //   spectrum the pair {k, -k} is found through the digit-reversal table and handled by ONE thread:
 //            P(k) = conj(A) B from Z(k), Z(-k) (packed real transforms), P(-k) = conj P(k);
 //   inverse  the exact inverse of the forward stages in reverse order (decimation in time, conjugate
@@ -35,27 +36,30 @@ __device__ __forceinline__ cd cmul(cd a, cd w) { return cd{a.x * w.x - a.y * w.y
 __device__ __forceinline__ cd cmulc(cd a, cd w) { return cd{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }   // a * conj(w)
 __device__ __forceinline__ cd cadd_(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
 __device__ __forceinline__ cd csub_(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+// a * (-i) for the forward transform, a * (+i) for the inverse
+template <bool FWD>
+__device__ __forceinline__ cd rot90(cd a) { return FWD ? cd{a.y, -a.x} : cd{-a.y, a.x}; }
 
-constexpr bool radix2_first_d(int n) { return n == 2 || n == 8 || n == 32 || n == 128; }
-// position of bin k after the in-place DIF transform of length n (same rule as fft_pos, fft_inreg.hpp)
+// radix of the stage that works on blocks of length L: 8 while it fits, then what is left (4 or 2)
+constexpr int radix_of(int L) { return L >= 8 ? 8 : L; }
+// position of bin k after the in-place DIF transform of length n
 constexpr int pos_of(int k, int n) {
     if (n <= 1) return 0;
-    if (radix2_first_d(n)) return (k % 2) * (n / 2) + pos_of(k / 2, n / 2);
-    return (k % 4) * (n / 4) + pos_of(k / 4, n / 4);
+    const int r = radix_of(n);
+    return (k % r) * (n / r) + pos_of(k / r, n / r);
 }
 
 template <int WS>
 struct F64Geo {
     static constexpr int NT = WS >= 32 ? 256 : 64;      // threads per workgroup (one window)
-    static constexpr int P = WS + 1;                    // plane pitch in doubles
+    static constexpr int P = WS + 1;                    // tile pitch in complex elements
     static constexpr int NW = NT / 64;                  // wavefronts
 };
 
 template <int WS>
 struct F64Shared {
-    double re[WS * (WS + 1)];
-    double im[WS * (WS + 1)];
-    double twc[WS], tws[WS];          // exp(-2 pi i k / WS) = twc - i * (-tws) ... stored as (cos, -sin)
+    cd z[WS * (WS + 1)];              // the packed tile a/mean(a) + i b/mean(b): 16-byte elements (ds_*_b128)
+    cd tw[WS];                        // exp(-2 pi i k / WS)
     int pos[WS];                      // bin -> position
     int bin[WS];                      // position -> bin
     double redd[8];
@@ -78,65 +82,95 @@ __device__ __forceinline__ T wg_reduce(T v, OP op, T* red) {
     return r;
 }
 
-// ---- one radix-R stage on sub-length L, along x (ALONG_Y = false) or y, forward (DIF) or inverse (DIT)
+// R-point DFT of x[0..R) in registers, natural order in and out; FWD: exp(-2 pi i pq/R), else the conjugate kernel
+template <int R, bool FWD>
+__device__ __forceinline__ void dft_small(cd (&x)[R]) {
+    if constexpr (R == 2) {
+        const cd a = x[0], b = x[1];
+        x[0] = cadd_(a, b);
+        x[1] = csub_(a, b);
+    } else if constexpr (R == 4) {
+        const cd t0 = cadd_(x[0], x[2]), t1 = csub_(x[0], x[2]), t2 = cadd_(x[1], x[3]);
+        const cd t3 = rot90<FWD>(csub_(x[1], x[3]));
+        x[0] = cadd_(t0, t2);
+        x[1] = cadd_(t1, t3);
+        x[2] = csub_(t0, t2);
+        x[3] = csub_(t1, t3);
+    } else {
+        static_assert(R == 8, "radix 2, 4 or 8");
+        constexpr double H = 0.70710678118654752440;
+        // first layer: a_p = x_p + x_{p+4} (even outputs), b_p = (x_p - x_{p+4}) w8^p (odd outputs)
+        cd a[4], b[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            a[p] = cadd_(x[p], x[p + 4]);
+            b[p] = csub_(x[p], x[p + 4]);
+        }
+        // w8^1 = (1 -+ i)/sqrt2, w8^2 = -+i, w8^3 = (-1 -+ i)/sqrt2   (upper sign: forward)
+        b[1] = FWD ? cd{(b[1].x + b[1].y) * H, (b[1].y - b[1].x) * H} : cd{(b[1].x - b[1].y) * H, (b[1].y + b[1].x) * H};
+        b[2] = rot90<FWD>(b[2]);
+        b[3] = FWD ? cd{(b[3].y - b[3].x) * H, -(b[3].x + b[3].y) * H} : cd{-(b[3].x + b[3].y) * H, (b[3].x - b[3].y) * H};
+        dft_small<4, FWD>(a);
+        dft_small<4, FWD>(b);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            x[2 * p] = a[p];
+            x[2 * p + 1] = b[p];
+        }
+    }
+}
+
+// ---- one radix-R stage on sub-length L of every line, along x (ALONG_Y = false) or y, forward
+//      (decimation in frequency: butterfly, then twiddle) or inverse (conjugate twiddle, then butterfly).
+// Thread mapping: a line has WS / R butterflies (index t = block * (L/R) + j).  The twiddles depend on j
+// only, so the mapping keeps t FIXED per thread and walks the lines: each thread fetches its R - 1
+// twiddles once per stage.  Along y a wavefront covers LW consecutive columns (16-byte elements: one
+// ds_read_b128 per lane, rows LW apart) of NT / LW butterfly indices.
 template <int WS, int L, int R, bool ALONG_Y, bool FWD>
 __device__ __forceinline__ void stage(F64Shared<WS>& sm) {
     using G = F64Geo<WS>;
-    constexpr int P = G::P;
-    constexpr int Q = L / R;                   // butterflies per block
+    constexpr int P = G::P, NT = G::NT;
+    constexpr int Q = L / R;                   // butterflies per block = stride between a butterfly's elements
+    constexpr int BPL = WS / R;                // butterflies per line
     constexpr int TWS = WS / L;                // twiddle stride in the length-WS table
-    constexpr int NB = WS * (WS / R);          // butterflies of the whole tile
-    for (int b = threadIdx.x; b < NB; b += G::NT) {
-        int line, t;
-        if constexpr (ALONG_Y) {
-            line = b % WS;                     // lanes walk along a row of the planes
-            t = b / WS;
-        } else {
-            line = b / (WS / R);
-            t = b % (WS / R);
-        }
+    // lines per pass over the tile and butterfly index of this thread
+    constexpr int LW = ALONG_Y ? (WS < 32 ? WS : 32) : 1;          // lanes that walk along a row (along y)
+    constexpr int TPP = ALONG_Y ? NT / LW : BPL;                   // butterfly indices handled per pass
+    static_assert(ALONG_Y || NT % BPL == 0, "t must not depend on the pass");
+    const int tid = threadIdx.x;
+    const int t0 = ALONG_Y ? tid / LW : tid % BPL;
+    const int line0 = ALONG_Y ? tid % LW : tid / BPL;
+    constexpr int LSTEP = ALONG_Y ? LW : NT / BPL;                 // lines advanced per pass
+    for (int t = t0; t < BPL; t += TPP) {                          // (one iteration unless NT / LW < WS / R)
         const int blk = t / Q, j = t % Q;
         const int e0 = blk * L + j;
-        auto addr = [&](int q) { return ALONG_Y ? (e0 + q * Q) * P + line : line * P + e0 + q * Q; };
-        auto tw = [&](int q) { const int i = (q * j * TWS) % WS; return cd{sm.twc[i], sm.tws[i]}; };
-        if constexpr (R == 2) {
-            const int a0 = addr(0), a1 = addr(1);
-            cd a{sm.re[a0], sm.im[a0]}, c{sm.re[a1], sm.im[a1]};
-            cd y0, y1;
+        cd w[R];
+        if constexpr (Q > 1) {
+#pragma unroll
+            for (int q = 1; q < R; ++q) w[q] = sm.tw[(q * j * TWS) % WS];
+        }
+        for (int line = line0; line < WS; line += LSTEP) {
+            cd x[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) x[q] = ALONG_Y ? sm.z[(e0 + q * Q) * P + line] : sm.z[line * P + e0 + q * Q];
             if constexpr (FWD) {
-                y0 = cadd_(a, c);
-                y1 = cmul(csub_(a, c), tw(1));
+                dft_small<R, true>(x);
+                if constexpr (Q > 1) {
+#pragma unroll
+                    for (int q = 1; q < R; ++q) x[q] = cmul(x[q], w[q]);
+                }
             } else {
-                const cd v1 = cmulc(c, tw(1));
-                y0 = cadd_(a, v1);
-                y1 = csub_(a, v1);
+                if constexpr (Q > 1) {
+#pragma unroll
+                    for (int q = 1; q < R; ++q) x[q] = cmulc(x[q], w[q]);
+                }
+                dft_small<R, false>(x);
             }
-            sm.re[a0] = y0.x, sm.im[a0] = y0.y;
-            sm.re[a1] = y1.x, sm.im[a1] = y1.y;
-        } else {
-            const int a0 = addr(0), a1 = addr(1), a2 = addr(2), a3 = addr(3);
-            cd x0{sm.re[a0], sm.im[a0]}, x1{sm.re[a1], sm.im[a1]}, x2{sm.re[a2], sm.im[a2]}, x3{sm.re[a3], sm.im[a3]};
-            cd y0, y1, y2, y3;
-            if constexpr (FWD) {
-                const cd t0 = cadd_(x0, x2), t1 = csub_(x0, x2), t2 = cadd_(x1, x3), bd = csub_(x1, x3);
-                const cd t3{bd.y, -bd.x};                      // -i (x1 - x3)
-                y0 = cadd_(t0, t2);
-                y1 = cmul(cadd_(t1, t3), tw(1));
-                y2 = cmul(csub_(t0, t2), tw(2));
-                y3 = cmul(csub_(t1, t3), tw(3));
-            } else {
-                const cd v1 = cmulc(x1, tw(1)), v2 = cmulc(x2, tw(2)), v3 = cmulc(x3, tw(3));
-                const cd s0 = cadd_(x0, v2), s1 = csub_(x0, v2), s2 = cadd_(v1, v3), d = csub_(v1, v3);
-                const cd s3{-d.y, d.x};                        // +i (v1 - v3)
-                y0 = cadd_(s0, s2);
-                y1 = cadd_(s1, s3);
-                y2 = csub_(s0, s2);
-                y3 = csub_(s1, s3);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                if constexpr (ALONG_Y) sm.z[(e0 + q * Q) * P + line] = x[q];
+                else sm.z[line * P + e0 + q * Q] = x[q];
             }
-            sm.re[a0] = y0.x, sm.im[a0] = y0.y;
-            sm.re[a1] = y1.x, sm.im[a1] = y1.y;
-            sm.re[a2] = y2.x, sm.im[a2] = y2.y;
-            sm.re[a3] = y3.x, sm.im[a3] = y3.y;
         }
     }
     __syncthreads();
@@ -146,7 +180,7 @@ __device__ __forceinline__ void stage(F64Shared<WS>& sm) {
 template <int WS, int L, bool ALONG_Y, bool FWD>
 __device__ __forceinline__ void transform(F64Shared<WS>& sm) {
     if constexpr (L >= 2) {
-        constexpr int R = radix2_first_d(L) ? 2 : 4;
+        constexpr int R = radix_of(L);
         if constexpr (FWD) {
             stage<WS, L, R, ALONG_Y, true>(sm);
             transform<WS, L / R, ALONG_Y, true>(sm);
@@ -169,8 +203,7 @@ __global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p)
     for (int k = tid; k < WS; k += NT) {
         double s, c;
         sincospi(2.0 * (double)k / (double)WS, &s, &c);
-        sm.twc[k] = c;
-        sm.tws[k] = -s;
+        sm.tw[k] = cd{c, -s};
         const int q = pos_of(k, WS);            // (evaluated at run time: small recursion, once per workgroup)
         sm.pos[k] = q;
         sm.bin[q] = k;
@@ -223,8 +256,7 @@ __global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const double a = (double)((da[q] >> (8 * k)) & 0xffu), b = (double)((db[q] >> (8 * k)) & 0xffu);
-                    sm.re[y * P + x4 + k] = dead ? 0.0 : a / ma;       // B:513-514
-                    sm.im[y * P + x4 + k] = dead ? 0.0 : b / mb;
+                    sm.z[y * P + x4 + k] = dead ? cd{0.0, 0.0} : cd{a / ma, b / mb};       // B:513-514
                 }
             }
         }
@@ -244,16 +276,13 @@ __global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p)
                 const int e2 = qy * WS + qx;
                 if (e2 < e) continue;                      // the partner's thread writes both cells
                 const int a1 = py * P + px, a2 = qy * P + qx;
-                const double a_ = sm.re[a1], b_ = sm.im[a1], c_ = sm.re[a2], d_ = sm.im[a2];
+                const cd zk = sm.z[a1], zm = sm.z[a2];
+                const double a_ = zk.x, b_ = zk.y, c_ = zm.x, d_ = zm.y;
                 // Z(k) = a + ib, Z(-k) = c + id:  4 P(k) = 2 (a d + b c) + i ((c^2 - a^2) + (d^2 - b^2))
                 const double pr = (a_ * d_ + b_ * c_) * (2.0 * SC);
                 const double pi = ((c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_)) * SC;
-                sm.re[a1] = pr;
-                sm.im[a1] = pi;
-                if (e2 != e) {                             // P(-k) = conj P(k)
-                    sm.re[a2] = pr;
-                    sm.im[a2] = -pi;
-                }
+                sm.z[a1] = cd{pr, pi};
+                if (e2 != e) sm.z[a2] = cd{pr, -pi};       // P(-k) = conj P(k)
             }
             __syncthreads();
         }
@@ -265,14 +294,14 @@ __global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p)
         // ---- peak analysis in fftshift coordinates (y' = (y + WS/2) % WS, x' likewise), float64
         auto dmin = [](double a, double b) { return a < b ? a : b; };
         double cmin = 1.7e308;
-        for (int e = tid; e < NN; e += NT) cmin = dmin(cmin, sm.re[(e / WS) * P + e % WS]);
+        for (int e = tid; e < NN; e += NT) cmin = dmin(cmin, sm.z[(e / WS) * P + e % WS].x);
         cmin = wg_reduce<G::NW>(cmin, dmin, sm.redd);
         double bv = -1.0;
         int bf = NN;
         for (int e = tid; e < NN; e += NT) {
             const int y = e / WS, x = e % WS;
-            const double v = __dadd_rn(__dsub_rn(sm.re[y * P + x], cmin), 1e-7);      // B:518, B:381
-            sm.re[y * P + x] = v;
+            const double v = __dadd_rn(__dsub_rn(sm.z[y * P + x].x, cmin), 1e-7);      // B:518, B:381
+            sm.z[y * P + x].x = v;
             const int f = ((y + WS / 2) % WS) * WS + (x + WS / 2) % WS;
             if (v > bv || (v == bv && f < bf)) {
                 bv = v;
@@ -295,7 +324,7 @@ __global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p)
             }
             if (f == 0 && (m - wv - wv * WS) <= 0) excl = true;
             if (f == NN - 1 && (m + wv + wv * WS) >= NN - 1) excl = true;
-            const double v = sm.re[y * P + x];
+            const double v = sm.z[y * P + x].x;
             if (!excl && v > sv) sv = v;
         }
         sv = wg_reduce<G::NW>(sv, [](double a, double b) { return a > b ? a : b; }, sm.redd);
@@ -311,7 +340,7 @@ __global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p)
             q = (tid == 3) ? top : q;
             q = (tid == 4) ? bot : q;
             const int ys = q / WS, xs = q % WS;                               // shifted -> stored coordinates
-            double outv = sm.re[((ys + WS / 2) % WS) * P + (xs + WS / 2) % WS];
+            double outv = sm.z[((ys + WS / 2) % WS) * P + (xs + WS / 2) % WS].x;
             // nothing left outside the exclusion zone: the reference's second arg-max runs over the zeroed
             // map, whose float64 storage `cor` aliases in pass 1 (B:382): c[m2] = 0, ratio = +inf
             outv = (tid == 5) ? (sv >= 0.0 ? sv : 0.0) : outv;
@@ -327,7 +356,7 @@ template <int WS>
 hipError_t launch_f64(const PassParams& p, int n_cu, hipStream_t stream) {
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
     if (items <= 0) return hipErrorInvalidValue;
-    const int per_cu = WS == 64 ? 2 : (WS == 32 ? 4 : 8);       // LDS: 66.6 KB / 17 KB / ... per workgroup
+    const int per_cu = WS == 64 ? 2 : (WS == 32 ? 4 : 8);       // LDS: 67.7 KB / 17.5 KB / ... per workgroup
     long long blocks = items < (long long)n_cu * per_cu ? items : (long long)n_cu * per_cu;
     blocks = (blocks + 7) / 8 * 8;
     hipLaunchKernelGGL((xcorr_f64_kernel<WS>), dim3((unsigned)blocks), dim3(F64Geo<WS>::NT), 0, stream, p);
