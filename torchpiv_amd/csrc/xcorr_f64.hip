@@ -51,9 +51,12 @@ constexpr int pos_of(int k, int n) {
 
 template <int WS>
 struct F64Geo {
-    static constexpr int NT = WS >= 32 ? 256 : 64;      // threads per workgroup (one window)
+    // threads per workgroup (one window).  64x64: 512, i.e. 16 wavefronts per CU with the two workgroups the
+    // LDS admits -- at 256 threads the two wavefronts per SIMD could not hide the LDS round trips
+    static constexpr int NT = WS >= 64 ? 512 : (WS >= 32 ? 256 : 64);
     static constexpr int P = WS + 1;                    // tile pitch in complex elements
     static constexpr int NW = NT / 64;                  // wavefronts
+    static constexpr int OCC = WS >= 64 ? 4 : 1;        // wavefronts per SIMD the register budget must allow
 };
 
 template <int WS>
@@ -62,9 +65,9 @@ struct F64Shared {
     cd tw[WS];                        // exp(-2 pi i k / WS)
     int pos[WS];                      // bin -> position
     int bin[WS];                      // position -> bin
-    double redd[8];
+    double redd[16];
     int redi[8];
-    unsigned redu[8];
+    unsigned redu[16];
 };
 
 // ---- workgroup reductions (every thread gets the result) ------------------------------------------
@@ -123,9 +126,12 @@ __device__ __forceinline__ void dft_small(cd (&x)[R]) {
 // ---- one radix-R stage on sub-length L of every line, along x (ALONG_Y = false) or y, forward
 //      (decimation in frequency: butterfly, then twiddle) or inverse (conjugate twiddle, then butterfly).
 // Thread mapping: a line has WS / R butterflies (index t = block * (L/R) + j).  The twiddles depend on j
-// only, so the mapping keeps t FIXED per thread and walks the lines: each thread fetches its R - 1
-// twiddles once per stage.  Along y a wavefront covers LW consecutive columns (16-byte elements: one
-// ds_read_b128 per lane, rows LW apart) of NT / LW butterfly indices.
+// only, so a thread keeps ONE t and walks the lines: it fetches its R - 1 twiddles once per stage.
+// The LW lanes that share a t are consecutive LINES.  Along y that is LW consecutive 16-byte elements of
+// a tile row; along x it is LW consecutive rows of one column, 65 elements = 260 dwords = 4 banks
+// (mod 64) apart -- both patterns are conflict-free for ds_read/write_b128.  (Mapping the lanes of a
+// wavefront to the butterflies of one row instead cost 3 bank-conflict cycles per LDS cycle:
+// SQ_LDS_BANK_CONFLICT 2.7e10 against SQ_ACTIVE_INST_LDS 8.4e9 per launch.)
 template <int WS, int L, int R, bool ALONG_Y, bool FWD>
 __device__ __forceinline__ void stage(F64Shared<WS>& sm) {
     using G = F64Geo<WS>;
@@ -133,14 +139,12 @@ __device__ __forceinline__ void stage(F64Shared<WS>& sm) {
     constexpr int Q = L / R;                   // butterflies per block = stride between a butterfly's elements
     constexpr int BPL = WS / R;                // butterflies per line
     constexpr int TWS = WS / L;                // twiddle stride in the length-WS table
-    // lines per pass over the tile and butterfly index of this thread
-    constexpr int LW = ALONG_Y ? (WS < 32 ? WS : 32) : 1;          // lanes that walk along a row (along y)
-    constexpr int TPP = ALONG_Y ? NT / LW : BPL;                   // butterfly indices handled per pass
-    static_assert(ALONG_Y || NT % BPL == 0, "t must not depend on the pass");
+    constexpr int LW = WS < NT * 8 / WS ? WS : NT * 8 / WS;        // lanes that share a butterfly index
+    constexpr int TPP = NT / LW;                                   // butterfly indices handled per pass
     const int tid = threadIdx.x;
-    const int t0 = ALONG_Y ? tid / LW : tid % BPL;
-    const int line0 = ALONG_Y ? tid % LW : tid / BPL;
-    constexpr int LSTEP = ALONG_Y ? LW : NT / BPL;                 // lines advanced per pass
+    const int t0 = tid / LW;
+    const int line0 = tid % LW;
+    constexpr int LSTEP = LW;                                      // lines advanced per pass
     for (int t = t0; t < BPL; t += TPP) {                          // (one iteration unless NT / LW < WS / R)
         const int blk = t / Q, j = t % Q;
         const int e0 = blk * L + j;
@@ -149,7 +153,12 @@ __device__ __forceinline__ void stage(F64Shared<WS>& sm) {
 #pragma unroll
             for (int q = 1; q < R; ++q) w[q] = sm.tw[(q * j * TWS) % WS];
         }
-        for (int line = line0; line < WS; line += LSTEP) {
+        constexpr int NIT = (WS + LSTEP - 1) / LSTEP;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int line = line0 + it * LSTEP;
+            if (LSTEP * NIT != WS && line >= WS) break;
+            if (WS < LSTEP && line >= WS) break;
             cd x[R];
 #pragma unroll
             for (int q = 0; q < R; ++q) x[q] = ALONG_Y ? sm.z[(e0 + q * Q) * P + line] : sm.z[line * P + e0 + q * Q];
@@ -192,7 +201,7 @@ __device__ __forceinline__ void transform(F64Shared<WS>& sm) {
 }
 
 template <int WS>
-__global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p) {
+__global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_kernel(PassParams p) {
     using G = F64Geo<WS>;
     constexpr int NT = G::NT, P = G::P, NN = WS * WS;
     constexpr int NDW = NN / 4;                 // dwords per frame window
@@ -245,9 +254,17 @@ __global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p)
         }
         auto uadd = [](unsigned a, unsigned b) { return a + b; };
         ia = wg_reduce<G::NW>(ia, uadd, sm.redu);
-        ib = wg_reduce<G::NW>(ib, uadd, sm.redu + 4);
+        ib = wg_reduce<G::NW>(ib, uadd, sm.redu + 8);
         const bool dead = ia == 0u || ib == 0u;          // zero-mean window: 0/0 = NaN map in the reference
         const double ma = (double)ia / (double)NN, mb = (double)ib / (double)NN;      // torch.mean: exact sum / n
+        // a / mean(a) (B:513-514) as one reciprocal per window plus a residual correction per pixel:
+        // q = a r, q += (a - q m) r  -- the correctly rounded quotient (the residual is exact in an fma)
+        // at a fifth of the instructions of 32 float64 divisions per thread
+        const double ra = dead ? 0.0 : 1.0 / ma, rb = dead ? 0.0 : 1.0 / mb;
+        auto quot = [](double a, double m, double r) {
+            const double q = a * r;
+            return __fma_rn(__fma_rn(-q, m, a), r, q);
+        };
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
             const int i = tid + q * NT;
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const double a = (double)((da[q] >> (8 * k)) & 0xffu), b = (double)((db[q] >> (8 * k)) & 0xffu);
-                    sm.z[y * P + x4 + k] = dead ? cd{0.0, 0.0} : cd{a / ma, b / mb};       // B:513-514
+                    sm.z[y * P + x4 + k] = cd{quot(a, ma, ra), quot(b, mb, rb)};
                 }
             }
         }
@@ -291,16 +308,29 @@ __global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p)
         transform<WS, WS, true, false>(sm);
         transform<WS, WS, false, false>(sm);
 
-        // ---- peak analysis in fftshift coordinates (y' = (y + WS/2) % WS, x' likewise), float64
+        // ---- peak analysis in fftshift coordinates (y' = (y + WS/2) % WS, x' likewise), float64.
+        //      A thread's cells (e = tid + k NT) stay in registers through the three scans: one read of the
+        //      real parts and one write of the finished map instead of four passes over the tile.
         auto dmin = [](double a, double b) { return a < b ? a : b; };
+        constexpr int CPT = (NN + NT - 1) / NT;            // cells per thread
+        double cv[CPT];
         double cmin = 1.7e308;
-        for (int e = tid; e < NN; e += NT) cmin = dmin(cmin, sm.z[(e / WS) * P + e % WS].x);
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = tid + k * NT;
+            cv[k] = e < NN ? sm.z[(e / WS) * P + e % WS].x : 1.7e308;
+            cmin = dmin(cmin, cv[k]);
+        }
         cmin = wg_reduce<G::NW>(cmin, dmin, sm.redd);
         double bv = -1.0;
         int bf = NN;
-        for (int e = tid; e < NN; e += NT) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = tid + k * NT;
+            if (e >= NN) break;
             const int y = e / WS, x = e % WS;
-            const double v = __dadd_rn(__dsub_rn(sm.z[y * P + x].x, cmin), 1e-7);      // B:518, B:381
+            const double v = __dadd_rn(__dsub_rn(cv[k], cmin), 1e-7);      // B:518, B:381
+            cv[k] = v;
             sm.z[y * P + x].x = v;
             const int f = ((y + WS / 2) % WS) * WS + (x + WS / 2) % WS;
             if (v > bv || (v == bv && f < bf)) {
@@ -308,24 +338,30 @@ __global__ __launch_bounds__(F64Geo<WS>::NT) void xcorr_f64_kernel(PassParams p)
                 bf = f;
             }
         }
-        const double gmax = wg_reduce<G::NW>(bv, [](double a, double b) { return a > b ? a : b; }, sm.redd + 4);
+        const double gmax = wg_reduce<G::NW>(bv, [](double a, double b) { return a > b ? a : b; }, sm.redd + 8);
         auto imin = [](int a, int b) { return a < b ? a : b; };
         const int m = wg_reduce<G::NW>(bv == gmax ? bf : NN, imin, sm.redi);           // first flat index (B:383)
-        // (the two reductions above also order the map writes before the reads below)
+        // (the reductions above also order the map writes before the neighbour reads below)
         const int wv = p.val_win;
+        const int my = m / WS, mx = m % WS;
         double sv = -1.0;
-        for (int e = tid; e < NN; e += NT) {
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+            const int e = tid + k * NT;
+            if (e >= NN) break;
             const int y = e / WS, x = e % WS;
-            const int f = ((y + WS / 2) % WS) * WS + (x + WS / 2) % WS;
-            bool excl = false;                             // f in {clamp(m + i + WS j)}: B:352-357
-            for (int j = -wv; j <= wv; ++j) {
-                const int t = f - m - WS * j;
-                if (t >= -wv && t <= wv) excl = true;
-            }
+            const int fy = (y + WS / 2) % WS, fx = (x + WS / 2) % WS;
+            const int f = fy * WS + fx;
+            // f in {clamp(m + i + WS j), |i|, |j| <= wv} (B:352-357): in row fy the columns mx + i (j = fy - my),
+            // mx + i + WS (j = fy - my - 1 ... the row wrap) and mx + i - WS, plus the two clamps
+            const int dj = fy - my;
+            bool excl = false;
+            if (dj >= -wv && dj <= wv) excl |= (fx >= mx - wv && fx <= mx + wv);
+            if (dj + 1 >= -wv && dj + 1 <= wv) excl |= (fx >= mx - wv + WS && fx <= mx + wv + WS);
+            if (dj - 1 >= -wv && dj - 1 <= wv) excl |= (fx >= mx - wv - WS && fx <= mx + wv - WS);
             if (f == 0 && (m - wv - wv * WS) <= 0) excl = true;
             if (f == NN - 1 && (m + wv + wv * WS) >= NN - 1) excl = true;
-            const double v = sm.z[y * P + x].x;
-            if (!excl && v > sv) sv = v;
+            if (!excl && cv[k] > sv) sv = cv[k];
         }
         sv = wg_reduce<G::NW>(sv, [](double a, double b) { return a > b ? a : b; }, sm.redd);
         if (tid < 8) {
@@ -356,7 +392,7 @@ template <int WS>
 hipError_t launch_f64(const PassParams& p, int n_cu, hipStream_t stream) {
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
     if (items <= 0) return hipErrorInvalidValue;
-    const int per_cu = WS == 64 ? 2 : (WS == 32 ? 4 : 8);       // LDS: 67.7 KB / 17.5 KB / ... per workgroup
+    const int per_cu = WS == 64 ? 2 : (WS == 32 ? 8 : 16);      // LDS: 67.7 KB / 17.5 KB / ... per workgroup
     long long blocks = items < (long long)n_cu * per_cu ? items : (long long)n_cu * per_cu;
     blocks = (blocks + 7) / 8 * 8;
     hipLaunchKernelGGL((xcorr_f64_kernel<WS>), dim3((unsigned)blocks), dim3(F64Geo<WS>::NT), 0, stream, p);
