@@ -47,10 +47,14 @@ enum tpiv_mode {
 };
 
 enum tpiv_precision {
-    TPIV_PREC_FAST = 0,      /* pass 1 in float32 (mean-removed windows; observed deviation ~1e-6 px) */
+    TPIV_PREC_FAST = 0,      /* pass 1 in float32 (observed deviation ~1e-6 px); shifted passes form the CWS
+                                sample as row lerps + a column lerp with the reference's float32 weights
+                                (float32 rounding differences against B:187-193) */
     TPIV_PREC_REFERENCE = 1  /* pass 1 in float64 like the reference (B:513-514 promotes the windows to
-                                float64 before the FFT); passes >= 2 are float32 + float64 epilogue in
-                                the reference itself (B:249-257, B:382), so they are the same in both */
+                                float64 before the FFT); shifted passes evaluate B:187-193 operation by
+                                operation, so the staged windows are bit-identical to the reference's
+                                (the transforms of passes >= 2 are float32 in the reference itself,
+                                B:249-257, with a float64 epilogue, B:382) */
 };
 
 typedef struct tpiv_plan tpiv_plan;
@@ -112,7 +116,7 @@ int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf,
 int tpiv_iter(int mode, const uint8_t* a_dev, const uint8_t* b_dev, int batch, int H, int W,
               int ws, int ov,
               const double* u0_dev, const double* v0_dev, const double* u2_dev, const double* v2_dev,
-              double val_ratio, int val_win,
+              double val_ratio, int val_win, int precision,
               double* u_dev, double* v_dev, uint8_t* invalid_dev,
               double* du_dev, double* dv_dev, void* work_dev, size_t work_bytes, void* stream);
 
@@ -175,12 +179,12 @@ int tpiv_plan_get_timing(tpiv_plan* plan, double* avg_ms, int n_slots, int* n_ru
 
 /* ---- test hook ------------------------------------------------------------------ */
 
-/* Runs one pass like tpiv_pass1 (mode 0, float32 precision) / tpiv_iter (mode DWS/CWS; zero_dev =
+/* Runs one pass like tpiv_pass1 (mode 0, float32) / tpiv_iter (mode DWS/CWS at `precision`; zero_dev =
  * [batch, n_rows, n_cols] float64 zeros, used as u0 = v0) and additionally writes the staged
  * windows win_dev [batch, N, 2, ws, ws] float32 (frame a, frame b, after the shift) and the
  * correlation maps corr_dev [batch, N, ws, ws] float32 (corr - min + 1e-7, fftshift layout).
  * Either may be NULL. */
-int tpiv_debug_pass(int mode, const uint8_t* a_dev, const uint8_t* b_dev, int batch, int H, int W,
+int tpiv_debug_pass(int mode, int precision, const uint8_t* a_dev, const uint8_t* b_dev, int batch, int H, int W,
                     int ws, int ov, const double* u2_dev, const double* v2_dev, const double* zero_dev,
                     double* u_dev, double* v_dev, uint8_t* invalid_dev,
                     float* win_dev, float* corr_dev, void* work_dev, size_t work_bytes, void* stream);

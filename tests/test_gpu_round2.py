@@ -314,3 +314,29 @@ def test_resident_generator_equals_host_post_validation(eng):
     assert st["pairs"] == 6 and st["device_complete"] + st["host_fallback"] - st["dropped_by_qhull"] == n_kept
     assert list(piv()) and len(list(piv())) == n_kept
     plan.close()
+
+
+@pytest.mark.parametrize("ws", [16, 32, 64])
+def test_fast_staging_close_to_reference_order(eng, ws):
+    """precision="fast" forms the CWS sample as row lerps + a column lerp with the reference's float32
+    weights: the staged windows differ from the bit-exact (reference-order) ones by float32 rounding only,
+    and wavefronts that hold an integral row shift (the "nearest sample" quirk) are bit-exact."""
+    rng = np.random.default_rng(900 + ws)
+    H, W, ov = 5 * ws + 8, 6 * ws + 4, ws // 2
+    fa = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
+    fb = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
+    nr, nc = O.field_shape((H, W), ws, ov)
+    n = nr * nc
+    vx = rng.uniform(-0.4 * ws, 0.4 * ws, n).astype(np.float32)
+    vy = rng.uniform(-0.4 * ws, 0.4 * ws, n).astype(np.float32)
+    vy[::9] = np.rint(vy[::9])
+    vxd = torch.from_numpy(vx.astype(np.float64)).cuda().view(1, nr, nc)
+    vyd = torch.from_numpy(vy.astype(np.float64)).cuda().view(1, nr, nc)
+    _, _, _, w_ref, _ = eng.debug_pass("CWS", dev(fa), dev(fb), ws, ov, vxd, vyd, precision="reference")
+    _, _, _, w_fast, _ = eng.debug_pass("CWS", dev(fa), dev(fb), ws, ov, vxd, vyd, precision="fast")
+    d = (w_ref - w_fast).abs()
+    print(f"  ws {ws}: fast vs reference-order staging: max |d| {d.max().item():.2e} grey levels, "
+          f"{(d > 0).float().mean().item():.3f} of the samples differ")
+    assert d.max().item() <= 1e-4            # a few float32 ulp of 255
+    integral = torch.from_numpy(vy == np.rint(vy)).cuda()
+    assert torch.equal(w_ref[0][integral], w_fast[0][integral])

@@ -55,7 +55,7 @@ SIGNATURES = {
     "tpiv_predict": (C.c_int, [_int, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p, _f64p, _u8p,
                                _f64p, _f64p, _f64p, _f64p, _f64p, _vp]),
     "tpiv_iter": (C.c_int, [_int, _u8p, _u8p, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p, _f64p,
-                            _dbl, _int, _f64p, _f64p, _u8p, _f64p, _f64p, _vp, C.c_size_t, _vp]),
+                            _dbl, _int, _int, _f64p, _f64p, _u8p, _f64p, _f64p, _vp, C.c_size_t, _vp]),
     "tpiv_plan_create": (C.c_int, [C.POINTER(C.c_void_p), _int, _int, _int, _int, _int, _int, _dbl, _dbl,
                                    _int, _int, _int]),
     "tpiv_plan_kernel_name": (C.c_char_p, [C.c_void_p, _int, C.c_char_p, _int]),
@@ -72,7 +72,7 @@ SIGNATURES = {
     "tpiv_plan_debug_predict": (C.c_int, [C.c_void_p, _int, _int, _f64p, _f64p, _u8p, _f64p, _f64p, _f64p,
                                           _f64p, _vp]),
     "tpiv_debug_peaks": (C.c_int, [_f32p, _int, _int, _int, _dbl, _int, _f64p, _f64p, _u8p, _vp, C.c_size_t, _vp]),
-    "tpiv_debug_pass": (C.c_int, [_int, _u8p, _u8p, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p, _f64p,
+    "tpiv_debug_pass": (C.c_int, [_int, _int, _u8p, _u8p, _int, _int, _int, _int, _int, _f64p, _f64p, _f64p, _f64p,
                                   _f64p, _u8p, _f32p, _f32p, _vp, C.c_size_t, _vp]),
 }
 

@@ -468,13 +468,15 @@ int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf, const 
     return TPIV_OK;
 }
 
-static int run_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
+static int run_iter(int mode, int precision, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
                     int ov, const double* u0, const double* v0, const double* u2, const double* v2,
                     double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, double* du,
                     double* dv, float* dbg_win, float* dbg_corr, void* work, size_t work_bytes, void* stream) {
     if (mode != TPIV_MODE_DWS && mode != TPIV_MODE_CWS) return fail(TPIV_EKEY, "unknown multipass mode");
     int rc = check_window(H, W, ws, ov, val_win);
     if (rc) return rc;
+    if (precision != TPIV_PREC_FAST && precision != TPIV_PREC_REFERENCE)
+        return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST or TPIV_PREC_REFERENCE");
     if (batch <= 0) return TPIV_OK;
     tpiv::PassParams p{};
     p.A = a;
@@ -484,6 +486,7 @@ static int run_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int
     p.W = W;
     p.ws = ws;
     p.ov = ov;
+    p.precision = precision;
     field_shape(H, W, ws, ov, &p.n_rows, &p.n_cols);
     p.u0 = u0;
     p.v0 = v0;
@@ -511,21 +514,21 @@ static int run_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int
 
 int tpiv_iter(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws, int ov,
               const double* u0, const double* v0, const double* u2, const double* v2,
-              double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, double* du,
+              double val_ratio, int val_win, int precision, double* u, double* v, uint8_t* invalid, double* du,
               double* dv, void* work, size_t work_bytes, void* stream) {
-    return run_iter(mode, a, b, batch, H, W, ws, ov, u0, v0, u2, v2, val_ratio, val_win, u, v, invalid,
+    return run_iter(mode, precision, a, b, batch, H, W, ws, ov, u0, v0, u2, v2, val_ratio, val_win, u, v, invalid,
                     du, dv, nullptr, nullptr, work, work_bytes, stream);
 }
 
-int tpiv_debug_pass(int mode, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
+int tpiv_debug_pass(int mode, int precision, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
                     int ov, const double* u2, const double* v2, const double* zero, double* u, double* v,
                     uint8_t* invalid, float* win, float* corr, void* work, size_t work_bytes, void* stream) {
     if (mode == 0)
         return pass1_impl(a, b, batch, H, W, ws, ov, 1.2, 3, TPIV_PREC_FAST, u, v, invalid, work, work_bytes, win,
                           corr, stream);
     if (!zero || !u2 || !v2) return fail(TPIV_EINVAL, "tpiv_debug_pass: shifted passes need u2, v2 and a zero field");
-    return run_iter(mode, a, b, batch, H, W, ws, ov, zero, zero, u2, v2, 1.2, 3, u, v, invalid, nullptr, nullptr,
-                    win, corr, work, work_bytes, stream);
+    return run_iter(mode, precision, a, b, batch, H, W, ws, ov, zero, zero, u2, v2, 1.2, 3, u, v, invalid, nullptr,
+                    nullptr, win, corr, work, work_bytes, stream);
 }
 
 int tpiv_debug_peaks(const float* maps, int n_maps, int ws, int planar, double val_ratio, int val_win, double* u,
@@ -773,7 +776,7 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
             mark(2 * p - 1, 1);
             mark(2 * p, 0);
             if (!rc)
-                rc = run_iter(plan->mode, a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->u0, plan->v0,
+                rc = run_iter(plan->mode, plan->precision, a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->u0, plan->v0,
                               plan->u2, plan->v2, plan->val_ratio, plan->val_win, pu, pv, pval, nullptr,
                               nullptr, nullptr, nullptr, plan->peak_raw, plan->peak_raw_bytes, stream);
             mark(2 * p, 1);

@@ -147,12 +147,15 @@ const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int le
 hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t stream) {
     hipError_t e;
     PassParams p = p_in;
-    const bool f64 = p.precision != 0;
-    if (f64 && mode != MODE_PASS1) return hipErrorInvalidValue;     // the reference's later passes are float32
+    // float64 exists for pass 1 only (the reference's later passes are float32, B:249-257); for shifted
+    // passes precision != 0 selects the tile kernel's reference-order arithmetic (xcorr_tile.hpp)
+    const bool f64 = p.precision != 0 && mode == MODE_PASS1;
     auto generic = [&]() {
         if (p.ws < 2 || p.ws > 256) return hipErrorInvalidValue;
-        void* scratch = reinterpret_cast<char*>(p.peak_raw) + peak_bytes(p.batch, p.n_rows * p.n_cols, p.precision);
-        return launch_xcorr_generic(p, mode, 256, scratch, stream);
+        void* scratch = reinterpret_cast<char*>(p.peak_raw) + peak_bytes(p.batch, p.n_rows * p.n_cols, f64 ? 1 : 0);
+        PassParams q = p;
+        q.precision = f64 ? 1 : 0;
+        return launch_xcorr_generic(q, mode, 256, scratch, stream);
     };
     if (f64) {
         e = tile_size(p.ws) ? launch_xcorr_f64(p, n_cu, stream) : generic();

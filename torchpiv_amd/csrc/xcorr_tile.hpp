@@ -521,7 +521,7 @@ __device__ __forceinline__ void fix_row(uint32_t (&d)[N], int cls) {
 // a PHI copy, and the compiler then waits for the data right behind the load -- which would
 // cancel the prefetch.  Rows that need the slow path (frame border / rounding corner cases) load
 // from the un-shifted row instead (always inside the frame) and ignore the data.
-template <int WS, int MODE>
+template <int WS, int MODE, bool FAST = false>
 __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& g, int r, float vx, float vy,
                                            RawRows<WS, MODE>& raw) {
     const int HW = p.H * p.W;
@@ -567,8 +567,10 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         int la0, la1, lb0, lb1;
         const int c0 = classify_row32(qa0, WS + 1, 4 * NB, HW, la0), c1 = classify_row32(qa1, WS + 1, 4 * NB, HW, la1);
         const int c2 = classify_row32(qb0, WS + 1, 4 * NB, HW, lb0), c3 = classify_row32(qb1, WS + 1, 4 * NB, HW, lb1);
+        // (FAST: an integral row coordinate -- B:170, B:193 return the nearest sample -- is left to the
+        //  per-pixel path, which implements the quirk; the lerp form of convert_rows does not)
         const bool reg = c0 != 3 && c1 != 3 && c2 != 3 && c3 != 3 && frac > thr && frac < 1.0f - thr &&
-                         fabsf(vx) < (float)p.W;
+                         fabsf(vx) < (float)p.W && !(FAST && (c.ydeg_a | c.ydeg_b));
         raw.reg = __all(reg) ? 1 : 0;
         raw.cls = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
         raw.fix = (raw.reg && __any(raw.cls != 0)) ? 1 : 0;
@@ -586,7 +588,12 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
 // raw rows -> float samples x[k] = (a, b) and the lane's partial sums
 // RBH: the per-pixel slow paths park a row in LDS in RBH pieces (2 when the planar 64x64 layout
 // leaves only 64 x 33 floats)
-template <int WS, int MODE, int RBH = 1>
+// FAST (precision "fast"): the CWS sample is formed as two row lerps and one column lerp with the SAME
+// float32 weights (6 instead of 11 multiply/add instructions; differs from the reference's evaluation
+// order by float32 rounding only), and the per-sample window sums are not formed here (the mean is
+// removed in the DC bin after the row transform, see the kernel).  !FAST keeps the reference's
+// operation order: staged windows bit-identical to biliniar_interpolation_CWS (B:187-193).
+template <int WS, int MODE, int RBH = 1, bool FAST = false>
 __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom& g, int r, int lane, float vx,
                                              float vy, RawRows<WS, MODE>& raw, cf (&x)[WS], float& sa,
                                              float& sb, float* lds) {
@@ -642,10 +649,12 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         }
         sa = 0.f;
         sb = 0.f;
+        if constexpr (!FAST) {
 #pragma unroll
-        for (int k = 0; k < WS; ++k) {
-            sa += x[k].x;
-            sb += x[k].y;
+            for (int k = 0; k < WS; ++k) {
+                sa += x[k].x;
+                sb += x[k].y;
+            }
         }
     } else {
         constexpr int NB = WS / 4 + 1;
@@ -673,6 +682,23 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                 wbuf[r] = make_float4(uxa_f - nxa, nxa - dxa_f, uxb_f - nxb, nxb - dxb_f);
                 wave_sync();
             }
+            // (FAST: a wavefront that holds a lane with an integral row coordinate -- the "nearest sample"
+            //  quirk of B:170, B:193 -- never gets here: issue_rows sends it down the per-pixel path)
+            if constexpr (FAST) {
+                static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (k % 8 == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
+                    const float4 wx = wbuf[k];
+                    const float a11 = byte_f<k, NB>(raw.a0), a21 = byte_f<k + 1, NB>(raw.a0);
+                    const float a12 = byte_f<k, NB>(raw.a1), a22 = byte_f<k + 1, NB>(raw.a1);
+                    const float b11 = byte_f<k, NB>(raw.b0), b21 = byte_f<k + 1, NB>(raw.b0);
+                    const float b12 = byte_f<k, NB>(raw.b1), b22 = byte_f<k + 1, NB>(raw.b1);
+                    const float ha1 = fmaf(a21, wx.y, a11 * wx.x), ha2 = fmaf(a22, wx.y, a12 * wx.x);
+                    const float hb1 = fmaf(b21, wx.w, b11 * wx.z), hb2 = fmaf(b22, wx.w, b12 * wx.z);
+                    x[k].x = fmaf(ha2, c.wya_dn, ha1 * c.wya_up);
+                    x[k].y = fmaf(hb2, c.wyb_dn, hb1 * c.wyb_up);
+                });
+            } else {
             unsigned dmask_a = c.ydeg_a ? ~0u : 0u, dmask_b = c.ydeg_b ? ~0u : 0u;
             asm volatile("" : "+v"(dmask_a), "+v"(dmask_b));       // keep them masks (not re-derived selects)
             static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
@@ -685,6 +711,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                 x[k].y = bilerp_ref_m(byte_f<k, NB>(raw.b0), byte_f<k + 1, NB>(raw.b0), byte_f<k, NB>(raw.b1),
                                       byte_f<k + 1, NB>(raw.b1), wx.z, wx.w, c.wyb_up, c.wyb_dn, dmask_b);
             });
+            }
             wave_sync();
         } else {          // generic per-pixel gather with the flat-index clamp (rare: rolled loops
                           // that park the row in LDS)
@@ -722,10 +749,12 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         }
         sa = 0.f;
         sb = 0.f;
+        if constexpr (!FAST) {
 #pragma unroll
-        for (int k = 0; k < WS; ++k) {
-            sa += x[k].x;
-            sb += x[k].y;
+            for (int k = 0; k < WS; ++k) {
+                sa += x[k].x;
+                sb += x[k].y;
+            }
         }
     }
 }
@@ -733,9 +762,9 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
 // ---- peak analysis of one correlation row per lane (B:346-358, B:381-392, B:518) -----------------
 // in: lane (w, r) holds row y = r of its window's circular correlation, value at column x in row[x]
 // (un-shifted coordinates; the callers' copies into `row` are register renames).  Writes the window's 8-float record for finalize_kernel.
-template <int WS, bool PLANAR>
+template <int WS, bool PLANAR, bool SCALED = false>
 __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (&row)[WS], float* tile, int w, int r,
-                                              bool active, bool dead, size_t fidx) {
+                                              bool active, bool dead, size_t fidx, float scale = 1.0f) {
     using G = TileGeo<WS, PLANAR>;
     // ---- correlation map in fftshift coordinates: y' = (r + WS/2) % WS, x' = (x + WS/2) % WS
     // SMALLMAP (planar 64x64, 8.4 KB of LDS): only the rows ywin-1..ywin+1 around the peak are parked in
@@ -744,9 +773,14 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
     static_assert(G::WPW * 3 * G::MAP_PITCH <= G::LDS_FLOATS, "map rows must fit the tile LDS");
     float* my_map = tile + w * ((SMALLMAP ? 3 : WS) * G::MAP_PITCH);
     const int ys = (r + WS / 2) % WS;
-    float cmin = 3.4e38f;
+    // one pass over the raw row gives its minimum AND its maximum: v = (row - min) + eps is monotonic
+    // in row, so the row maximum of v is v(max row) -- no second scan for it
+    float cmin = 3.4e38f, rraw = -3.4e38f;
 #pragma unroll
-    for (int k = 0; k < WS; ++k) cmin = fminf(cmin, row[k]);
+    for (int k = 0; k < WS; ++k) {
+        cmin = fminf(cmin, row[k]);
+        rraw = fmaxf(rraw, row[k]);
+    }
     cmin = grp_min<WS>(cmin);
     // The scans below avoid per-element compare/select chains (SGPR-pair results and masks, and the
     // registers that tracking an index per lane costs): the arg-max is a plain max per row, and its
@@ -754,17 +788,23 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
     // variant that also replaced the integer sign-bit scan of the second peak by a lane = column pass
     // over the 2 wv + 1 band rows measured no faster in a same-box A/B: integer ops interleaved with
     // fp32 ops issue for free on MI355X, tools/micro/gen_issue_rate.py.)
+    // B:518 corr - min; B:381 corr += eps (float32 arithmetic in passes >= 2).  SCALED: the transforms ran
+    // on un-normalised samples and the constant factor of the map (1/n^2, the 1/4 of the packed spectrum,
+    // pass 1: 1/(mean a * mean b)) is applied here, inside the same two instructions.
+    const float ncs = -(cmin * scale);
+    auto shifted = [&](float c_) TPIV_LAMBDA_INLINE {
+        if constexpr (SCALED) return __fadd_rn(fmaf(c_, scale, ncs), 1e-7f);
+        else return __fadd_rn(__fsub_rn(c_, cmin), 1e-7f);
+    };
     float c[WS];                                      // shifted row: c[x'] = corr - min + eps
-    float rmax = 0.f;                                 // every c is >= 1e-7 > 0
     static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
         constexpr int xsft = decltype(kc)::value;     // ascending shifted column
         constexpr int xo = (xsft + WS / 2) % WS;
-        // B:518 corr - min; B:381 corr += eps (float32 arithmetic in passes >= 2)
-        const float v = __fadd_rn(__fsub_rn(row[xo], cmin), 1e-7f);
+        const float v = shifted(row[xo]);
         c[xsft] = v;
         if constexpr (!SMALLMAP) my_map[ys * G::MAP_PITCH + xsft] = v;
-        rmax = fmaxf(rmax, v);
     });
+    const float rmax = shifted(rraw);                 // = max of the row's c[] (monotonic); every c is >= 1e-7 > 0
     const float gmax = grp_reduce<WS>(rmax, [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); });
     auto imin = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
     // arg-max = FIRST flat index holding the maximum (torch.argmax, B:383): the smallest row y' whose
@@ -849,7 +889,9 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int WS, int MODE, int OCC>
+// FAST (PassParams::precision == 0): cheaper arithmetic that differs from the !FAST form by float32
+// rounding only -- see convert_rows, the mean handling after the row transform and peak_analysis<.., SCALED>.
+template <int WS, int MODE, int OCC, bool FAST>
 __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
     constexpr bool PLANAR = OCC > 2;
     using G = TileGeo<WS, PLANAR>;
@@ -950,7 +992,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         const int l0 = fresh_lane();
         gcur = geom_of(item, l0 / WS);
         shift_of(gcur, vx, vy);
-        issue_rows<WS, MODE>(p, gcur, l0 % WS, vx, vy, raw);
+        issue_rows<WS, MODE, FAST>(p, gcur, l0 % WS, vx, vy, raw);
     }
 
     TPIV_STAMP_DECL
@@ -975,7 +1017,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         cf x[WS];
         float sa, sb;                      // window sums (for the mean)
         TPIV_STAMP(0);      // loop head: geometry, next shifts, combine loads
-        convert_rows<WS, MODE, RBH>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile);
+        convert_rows<WS, MODE, RBH, FAST>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile);
         TPIV_STAMP(1);      // wait for the rows + conversion / bilinear sampling
         // 64x64 (register-bound): the dequeue issued at the loop head has landed by now; move it to a
         // scalar register (kept in a VGPR to the loop end it would be spilled, and the reload would
@@ -984,7 +1026,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         if constexpr (WS >= 64) nnitem = q_take(q_raw);
         // small tiles: the row registers are free again, so the next item's loads go out now and
         // have the whole iteration to land (64x64 is register-bound: it waits until the peak search)
-        if constexpr (WS <= 32) issue_rows<WS, MODE>(p, gnext, r, nvx, nvy, raw);
+        if constexpr (WS <= 32) issue_rows<WS, MODE, FAST>(p, gnext, r, nvx, nvy, raw);
 
         if (p.dbg_win != nullptr && active) {     // test hook: the staged (shifted) windows
             // (the row index is made opaque here: otherwise the WS loop-invariant store addresses get
@@ -1001,31 +1043,52 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
 
         // ---- mean removal: any constant offset leaves corr - min(corr) unchanged and only
         //      conditions the float32 transform.  Pass 1 also divides by the mean (B:513-514).
-        sa = grp_sum<WS>(sa);
-        sb = grp_sum<WS>(sb);
-        const float ma = sa * (1.0f / (WS * WS)), mb = sb * (1.0f / (WS * WS));
         bool dead = false;        // pass 1: zero-mean window -> 0/0 = NaN map in the reference
-        float ka = 1.f, kb = 1.f;
-        if constexpr (MODE == MODE_PASS1) {
-            dead = (sa == 0.f) || (sb == 0.f);
-            ka = dead ? 0.f : 1.0f / ma;
-            kb = dead ? 0.f : 1.0f / mb;
-        }
-        // The 1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra are applied
-        // HERE, as the power of two 0.5/WS on both inputs: exact (no rounding anywhere changes), and
-        // it saves the per-bin scaling multiplies of the cross-spectrum.
-        constexpr float PRE = 0.5f / (float)WS;
-        const float oa = -ma * ka, ob = -mb * kb;
-        const float kas = ka * PRE, kbs = kb * PRE, oas = oa * PRE, obs = ob * PRE;
+        float end_scale = 1.0f;
+        if constexpr (!FAST) {
+            sa = grp_sum<WS>(sa);
+            sb = grp_sum<WS>(sb);
+            const float ma = sa * (1.0f / (WS * WS)), mb = sb * (1.0f / (WS * WS));
+            float ka = 1.f, kb = 1.f;
+            if constexpr (MODE == MODE_PASS1) {
+                dead = (sa == 0.f) || (sb == 0.f);
+                ka = dead ? 0.f : 1.0f / ma;
+                kb = dead ? 0.f : 1.0f / mb;
+            }
+            // The 1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra are applied
+            // HERE, as the power of two 0.5/WS on both inputs: exact (no rounding anywhere changes), and
+            // it saves the per-bin scaling multiplies of the cross-spectrum.
+            constexpr float PRE = 0.5f / (float)WS;
+            const float oa = -ma * ka, ob = -mb * kb;
+            const float kas = ka * PRE, kbs = kb * PRE, oas = oa * PRE, obs = ob * PRE;
 #pragma unroll
-        for (int k = 0; k < WS; ++k) {
-            x[k].x = fmaf(x[k].x, kas, oas);        // (x - mean) * k * 0.5/WS
-            x[k].y = fmaf(x[k].y, kbs, obs);
+            for (int k = 0; k < WS; ++k) {
+                x[k].x = fmaf(x[k].x, kas, oas);        // (x - mean) * k * 0.5/WS
+                x[k].y = fmaf(x[k].y, kbs, obs);
+            }
         }
 
         TPIV_STAMP(2);      // mean reduction + normalisation
         // ---- forward 2-D transform of a + i*b: rows in registers, transpose, columns in registers
         fft_inreg<WS, 1>(x, tw);                          // over x; bin kx at x[FFT_POS<kx>]
+        if constexpr (FAST) {
+            // The samples went in as they are.  Bin kx = 0 of a lane's row is the row sum (a in .x, b in .y):
+            // the window mean is removed THERE (one subtraction per lane instead of one per sample; only
+            // the row transform has seen the pedestal), and the constant factor of the map -- 1/n^2, the
+            // 1/4 of the packed spectrum, pass 1: 1/(mean a * mean b) -- is applied by peak_analysis.
+            constexpr int P0 = FFT_POS<0, WS>;
+            // pass 1: the exact integer row sums (v_sad_u8) decide `dead` and give the exact means
+            const float ta = grp_sum<WS>(MODE == MODE_PASS1 ? sa : x[P0].x);
+            const float tb = grp_sum<WS>(MODE == MODE_PASS1 ? sb : x[P0].y);
+            x[P0].x -= ta * (1.0f / WS);
+            x[P0].y -= tb * (1.0f / WS);
+            end_scale = 0.25f / (float)(WS * WS);
+            if constexpr (MODE == MODE_PASS1) {
+                dead = (ta == 0.f) || (tb == 0.f);
+                const float ma = ta * (1.0f / (WS * WS)), mb = tb * (1.0f / (WS * WS));
+                end_scale = dead ? 0.f : (end_scale / ma) / mb;
+            }
+        }
         TPIV_STAMP(3);      // forward row FFT
         transpose_tile<WS, true, PLANAR>(x, tile, fresh_lane());  // lane = kx, x[y] natural
         TPIV_STAMP(4);      // transposition 1
@@ -1113,7 +1176,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         // ---- prefetch: the next item's row loads fly while this item's peak search runs
         if constexpr (WS > 32) {
             const int lane_p = fresh_lane();
-            issue_rows<WS, MODE>(p, geom_of(nit, lane_p / WS), lane_p % WS, nvx, nvy, raw);
+            issue_rows<WS, MODE, FAST>(p, geom_of(nit, lane_p / WS), lane_p % WS, nvx, nvy, raw);
         }
         vx = nvx;
         vy = nvy;
@@ -1129,9 +1192,9 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             const bool active_e = win_raw_e < N;
             const int win_e = active_e ? win_raw_e : N - 1;
             const size_t fidx_e = (size_t)pair_e * N + win_e;
-            peak_analysis<WS, PLANAR>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e);
+            peak_analysis<WS, PLANAR, FAST>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e, end_scale);
         } else {
-            peak_analysis<WS, PLANAR>(p, crow, tile, w, r, active, dead, fidx);
+            peak_analysis<WS, PLANAR, FAST>(p, crow, tile, w, r, active, dead, fidx, end_scale);
         }
         wave_sync();
         if constexpr (WS < 64) nnitem = q_take(q_raw);
@@ -1207,29 +1270,38 @@ static hipError_t launch_tile(const PassParams& p_in, int n_cu, hipStream_t stre
     // Only the chosen variant is instantiated (tile_occ_c, piv_kernels.h); -DTPIV_EXPERIMENT builds all
     // of them and lets TPIV_OCC=2|3|4 pick one at run time.
     constexpr int OCC = tile_occ_c(WS, MODE);
+    // precision "reference": shifted passes keep the reference's operation order (bit-identical staged
+    // windows); pass 1 at that precision is the float64 kernel (xcorr_f64.hip), so the float32 pass 1
+    // exists in the fast form only
+    if constexpr (MODE != MODE_PASS1) {
+        if (p.precision != 0) {
+            hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, OCC, false>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+            return hipGetLastError();
+        }
+    }
 #ifdef TPIV_EXPERIMENT
     static const int occ_env = [] {
         const char* e = getenv("TPIV_OCC");
         return e ? atoi(e) : 0;
     }();
     if (occ_env == 2 && OCC != 2) {
-        hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 2>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 2, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
         return hipGetLastError();
     }
     if constexpr (WS <= 32 || MODE != MODE_CWS) {
         if (occ_env == 3 && OCC != 3) {
-            hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 3>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+            hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 3, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
             return hipGetLastError();
         }
     }
     if constexpr (WS <= 32) {
         if (occ_env == 4 && OCC != 4) {
-            hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 4>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+            hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, 4, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
             return hipGetLastError();
         }
     }
 #endif
-    hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, OCC>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, OCC, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -116,8 +116,10 @@ def predict(mode, Ay, Ax, u_c, v_c, inv_c):
     return outs
 
 
-def iterate(mode, a, b, ws, ov, u0, v0, u2, v2, val_ratio=1.2, val_win=3, want_raw=False):
-    """Device part of piv_iteration_{DWS,CWS}.__call__ after the predictor."""
+def iterate(mode, a, b, ws, ov, u0, v0, u2, v2, val_ratio=1.2, val_win=3, want_raw=False, precision="fast"):
+    """Device part of piv_iteration_{DWS,CWS}.__call__ after the predictor.  precision="reference" keeps
+    the reference's operation order in the CWS bilinear sampling (bit-identical staged windows)."""
+    prec = _precision(precision)
     a, b = _frames(a, b)
     _need_cuda(u0, v0, u2, v2)
     B, H, W = a.shape
@@ -133,7 +135,7 @@ def iterate(mode, a, b, ws, ov, u0, v0, u2, v2, val_ratio=1.2, val_win=3, want_r
         check(lib.tpiv_iter(MODES[mode], a.data_ptr(), b.data_ptr(), B, H, W, ws, ov,
                             u0.contiguous().data_ptr(), v0.contiguous().data_ptr(),
                             u2.contiguous().data_ptr(), v2.contiguous().data_ptr(),
-                            val_ratio, val_win, u.data_ptr(), v.data_ptr(), inv.data_ptr(),
+                            val_ratio, val_win, prec, u.data_ptr(), v.data_ptr(), inv.data_ptr(),
                             du.data_ptr() if want_raw else None, dv.data_ptr() if want_raw else None,
                             work.data_ptr(), nbytes, _stream()))
     if want_raw:
@@ -141,8 +143,10 @@ def iterate(mode, a, b, ws, ov, u0, v0, u2, v2, val_ratio=1.2, val_win=3, want_r
     return u, v, inv
 
 
-def debug_pass(mode, a, b, ws, ov, u2=None, v2=None):
-    """Test hook: one pass plus the staged windows and the correlation maps."""
+def debug_pass(mode, a, b, ws, ov, u2=None, v2=None, precision="reference"):
+    """Test hook: one pass plus the staged windows and the correlation maps (shifted passes at
+    `precision`: "reference" = the reference's operation order, bit-identical windows)."""
+    prec = _precision(precision)
     a, b = _frames(a, b)
     B, H, W = a.shape
     nr, nc = field_shape(H, W, ws, ov)
@@ -157,7 +161,7 @@ def debug_pass(mode, a, b, ws, ov, u2=None, v2=None):
     zero = torch.zeros(B, nr, nc, dtype=torch.float64, device=dev) if m else None
     with torch.cuda.device(dev):
         work, nbytes = _work(H, W, ws, ov, B, dev)
-        check(lib.tpiv_debug_pass(m, a.data_ptr(), b.data_ptr(), B, H, W, ws, ov,
+        check(lib.tpiv_debug_pass(m, prec, a.data_ptr(), b.data_ptr(), B, H, W, ws, ov,
                                   u2.contiguous().data_ptr() if u2 is not None else None,
                                   v2.contiguous().data_ptr() if v2 is not None else None,
                                   zero.data_ptr() if zero is not None else None,
