@@ -1045,7 +1045,12 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         //      conditions the float32 transform.  Pass 1 also divides by the mean (B:513-514).
         bool dead = false;        // pass 1: zero-mean window -> 0/0 = NaN map in the reference
         float end_scale = 1.0f;
-        if constexpr (!FAST) {
+        // Pass 1 is compared with a float64 reference and its normalised maps have peak neighbours AT the
+        // map minimum in sparse 8x8 windows, where the log-ratio fit amplifies every rounding error: it
+        // keeps the mean removal in front of the transform (128 fma per 64x64 window row, 2 % of the pass).
+        // The shifted passes are float32 in the reference itself, with the full pedestal in both transforms.
+        constexpr bool FASTN = FAST && MODE != MODE_PASS1;
+        if constexpr (!FASTN) {
             sa = grp_sum<WS>(sa);
             sb = grp_sum<WS>(sb);
             const float ma = sa * (1.0f / (WS * WS)), mb = sb * (1.0f / (WS * WS));
@@ -1071,23 +1076,17 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         TPIV_STAMP(2);      // mean reduction + normalisation
         // ---- forward 2-D transform of a + i*b: rows in registers, transpose, columns in registers
         fft_inreg<WS, 1>(x, tw);                          // over x; bin kx at x[FFT_POS<kx>]
-        if constexpr (FAST) {
+        if constexpr (FASTN) {
             // The samples went in as they are.  Bin kx = 0 of a lane's row is the row sum (a in .x, b in .y):
             // the window mean is removed THERE (one subtraction per lane instead of one per sample; only
-            // the row transform has seen the pedestal), and the constant factor of the map -- 1/n^2, the
-            // 1/4 of the packed spectrum, pass 1: 1/(mean a * mean b) -- is applied by peak_analysis.
+            // the row transform has seen the pedestal), and the constant factor of the map -- 1/n^2 and the
+            // 1/4 of the packed spectrum -- is applied by peak_analysis.
             constexpr int P0 = FFT_POS<0, WS>;
-            // pass 1: the exact integer row sums (v_sad_u8) decide `dead` and give the exact means
-            const float ta = grp_sum<WS>(MODE == MODE_PASS1 ? sa : x[P0].x);
-            const float tb = grp_sum<WS>(MODE == MODE_PASS1 ? sb : x[P0].y);
+            const float ta = grp_sum<WS>(x[P0].x);
+            const float tb = grp_sum<WS>(x[P0].y);
             x[P0].x -= ta * (1.0f / WS);
             x[P0].y -= tb * (1.0f / WS);
             end_scale = 0.25f / (float)(WS * WS);
-            if constexpr (MODE == MODE_PASS1) {
-                dead = (ta == 0.f) || (tb == 0.f);
-                const float ma = ta * (1.0f / (WS * WS)), mb = tb * (1.0f / (WS * WS));
-                end_scale = dead ? 0.f : (end_scale / ma) / mb;
-            }
         }
         TPIV_STAMP(3);      // forward row FFT
         transpose_tile<WS, true, PLANAR>(x, tile, fresh_lane());  // lane = kx, x[y] natural
@@ -1192,9 +1191,9 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             const bool active_e = win_raw_e < N;
             const int win_e = active_e ? win_raw_e : N - 1;
             const size_t fidx_e = (size_t)pair_e * N + win_e;
-            peak_analysis<WS, PLANAR, FAST>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e, end_scale);
+            peak_analysis<WS, PLANAR, FASTN>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e, end_scale);
         } else {
-            peak_analysis<WS, PLANAR, FAST>(p, crow, tile, w, r, active, dead, fidx, end_scale);
+            peak_analysis<WS, PLANAR, FASTN>(p, crow, tile, w, r, active, dead, fidx, end_scale);
         }
         wave_sync();
         if constexpr (WS < 64) nnitem = q_take(q_raw);
