@@ -133,7 +133,7 @@ int tpiv_plan_n_pass(const tpiv_plan* plan);
 int tpiv_plan_pass_geometry(const tpiv_plan* plan, int pass, int* ws, int* ov, int* n_rows, int* n_cols);
 
 /* Name of the cross-correlation kernel pass `pass` launches (for bench / profile labels), e.g.
- * "xcorr_tile_kernel<32, 2, 3>" (the demangled form profilers print; second argument: 0 pass 1, 1 DWS, 2 CWS).  Returns buf. */
+ * "xcorr_tile_kernel<32, 2, 3, true>" (the demangled form profilers print; second argument: 0 pass 1, 1 DWS, 2 CWS; last: fast arithmetic).  Returns buf. */
 const char* tpiv_plan_kernel_name(const tpiv_plan* plan, int pass, char* buf, int len);
 
 /* Pass 1 and every further pass (B:873-882) for `batch` <= max_batch pairs; the last

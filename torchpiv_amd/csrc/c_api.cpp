@@ -688,7 +688,7 @@ const char* tpiv_plan_kernel_name(const tpiv_plan* plan, int pass, char* buf, in
     buf[0] = 0;
     if (!plan || pass < 0 || pass >= plan->n_pass) return buf;
     const int mode = pass == 0 ? (int)tpiv::MODE_PASS1 : plan->mode;
-    return tpiv::xcorr_kernel_name(plan->geo[pass].ws, mode, pass == 0 ? plan->precision : 0, buf, len);
+    return tpiv::xcorr_kernel_name(plan->geo[pass].ws, mode, plan->precision, buf, len);
 }
 
 int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u, double** v, uint8_t** invalid) {

@@ -135,7 +135,8 @@ const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int le
         if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_kernel<%d>", ws);
         else snprintf(buf, len, "xcorr_generic_kernel<0, double>");
     } else if (tile_size(ws)) {
-        snprintf(buf, len, "xcorr_tile_kernel<%d, %d, %d>", ws, mode, tile_occ(ws, mode));
+        snprintf(buf, len, "xcorr_tile_kernel<%d, %d, %d, %s>", ws, mode, tile_occ(ws, mode),
+                 (precision && mode != MODE_PASS1) ? "false" : "true");
     } else if (ws == 128 && mode == MODE_PASS1) {
         snprintf(buf, len, "xcorr_big128_kernel");
     } else {
