@@ -165,6 +165,18 @@ int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u_dev, doubl
 int tpiv_postval(double* u_dev, double* v_dev, const uint8_t* invalid_dev, int batch, int n_rows, int n_cols,
                  uint8_t* cls_dev, int32_t* counts_dev, void* stream);
 
+/* ---- image ingest (PIVDataset.__getitem__, B:129-144) ------------------------------- */
+
+/* Unpacks n_files uncompressed BMP files that were uploaded as RAW FILE BYTES into uint8 frames
+ * out_dev [n_files, H, W] (top-down rows, what cv2.imdecode(..., IMREAD_GRAYSCALE) returns): header
+ * skip, bottom-up row flip, row-padding strip, palette look-up (1 byte per pixel) or OpenCV's
+ * fixed-point BGR -> gray weights (3 / 4 bytes per pixel).  The host parses the 54-byte headers
+ * (torchpiv_amd/io.py) and passes, per file, desc_dev[f][6] int64 = {offset of the file in raw_dev,
+ * offset of the pixel data in the file, row stride in bytes, bytes per pixel (1, 3, 4), rows stored
+ * bottom-up (0/1), reserved} and lut_dev[f][256] (palette entries already converted to gray). */
+int tpiv_bmp_unpack(const uint8_t* raw_dev, const int64_t* desc_dev, const uint8_t* lut_dev, int n_files,
+                    int H, int W, uint8_t* out_dev, void* stream);
+
 /* ---- measurement ------------------------------------------------------------------ */
 
 /* Per-kernel timing with hipEvents recorded on the run's own stream (torch.cuda.Event only

@@ -340,3 +340,51 @@ def test_fast_staging_close_to_reference_order(eng, ws):
     assert d.max().item() <= 1e-4            # a few float32 ulp of 255
     integral = torch.from_numpy(vy == np.rint(vy)).cuda()
     assert torch.equal(w_ref[0][integral], w_fast[0][integral])
+
+
+def test_bmp_unpack_on_device_equals_host_decode(eng, tmp_path):
+    """tpiv_bmp_unpack against io.decode_bmp_gray, byte for byte: 8-bit grey-ramp and arbitrary palettes,
+    24- and 32-bit colour, bottom-up and top-down rows, widths that need row padding."""
+    import struct
+    from PIL import Image
+    from torchpiv_amd import io as pio
+    rng = np.random.default_rng(12)
+    H, W = 37, 50                                     # W % 4 != 0: padded rows
+    files = []
+    gray = rng.integers(0, 256, size=(H, W)).astype(np.uint8)
+    Image.fromarray(gray, "L").save(tmp_path / "g8.bmp")
+    files.append("g8.bmp")
+    rgb = rng.integers(0, 256, size=(H, W, 3)).astype(np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c24.bmp")
+    files.append("c24.bmp")
+    pal = Image.fromarray(gray, "L").convert("P", palette=Image.ADAPTIVE, colors=200)
+    pal.putpalette(list(rng.integers(0, 256, size=768).astype(np.uint8)))
+    pal.save(tmp_path / "p8.bmp")
+    files.append("p8.bmp")
+    # top-down 32-bit file written by hand (negative height)
+    bgra = rng.integers(0, 256, size=(H, W, 4)).astype(np.uint8)
+    hdr = b"BM" + struct.pack("<IHHI", 54 + H * W * 4, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, W, -H, 1, 32, 0, H * W * 4,
+                                                                                2835, 2835, 0, 0)
+    (tmp_path / "t32.bmp").write_bytes(hdr + bgra.tobytes())
+    files.append("t32.bmp")
+    cap = max((tmp_path / f).stat().st_size for f in files)
+    stage = torch.zeros(len(files), cap, dtype=torch.uint8).pin_memory()
+    desc, luts, want = [], [], []
+    for k, f in enumerate(files):
+        lay = pio.stage_raw(str(tmp_path / f), stage[k].numpy(), H, W)
+        assert lay is not None, f
+        desc.append([k * cap, lay[0], lay[1], lay[2], lay[3], 0])
+        luts.append(lay[4])
+        want.append(pio.decode_bmp_gray((tmp_path / f).read_bytes()))
+    out = eng.bmp_unpack(stage.cuda().view(-1), torch.tensor(desc, dtype=torch.int64).cuda(),
+                         torch.from_numpy(np.stack(luts)).cuda(), H, W).cpu().numpy()
+    for k, f in enumerate(files):
+        assert np.array_equal(out[k], want[k]), f
+    assert np.array_equal(want[0], gray)
+    # a PNG goes through the host decoder and travels as headerless pixels
+    Image.fromarray(gray, "L").save(tmp_path / "g.png")
+    lay = pio.stage_raw(str(tmp_path / "g.png"), stage[0].numpy(), H, W)
+    assert lay[:4] == (0, W, 1, 0)
+    out = eng.bmp_unpack(stage.cuda().view(-1), torch.tensor([[0, lay[0], lay[1], lay[2], lay[3], 0]], dtype=torch.int64).cuda(),
+                         torch.from_numpy(lay[4][None].copy()).cuda(), H, W).cpu().numpy()
+    assert np.array_equal(out[0], gray)

@@ -432,12 +432,14 @@ class OfflinePIV:
 
     # ---- extension: batched processing (same results, many pairs per launch) ------------
     def batched(self, batch_size: int = 32, indices=None) -> Generator:
-        """Like __call__, but decodes, uploads and processes `batch_size` pairs per launch: a loader
-        thread decodes the next batch straight into pinned staging memory while the GPU works on the
-        current one (double buffered).  Yields (pair_index, x, y, u, v); dropped pairs yield nothing."""
+        """Like __call__, but reads, uploads and processes `batch_size` pairs per launch.  A loader
+        thread puts the next batch's files into pinned staging memory -- uncompressed BMPs as their RAW
+        FILE BYTES (no host decode: header skip, row flip, padding strip and palette / gray conversion
+        run on the device, tpiv_bmp_unpack), other formats decoded on the host -- while the GPU works on
+        the current batch (double buffered).  Yields (pair_index, x, y, u, v); dropped pairs yield nothing."""
         import queue
         import threading
-        from .io import decode_into
+        from .io import stage_raw
         idx = list(range(len(self._dataset))) if indices is None else list(indices)
         if not idx:
             return
@@ -445,14 +447,18 @@ class OfflinePIV:
         for i in idx:                       # frame shape from the first decodable pair
             a0, _ = self._dataset[i]
             if a0 is not None:
-                first = tuple(a0.shape)
+                first = (i, tuple(a0.shape))
                 break
         if first is None:
             return
-        H, W = first
+        H, W = first[1]
         plan = self._get_plan(H, W, max_batch=batch_size)
-        stage = [(torch.empty(batch_size, H, W, dtype=torch.uint8).pin_memory(),
-                  torch.empty(batch_size, H, W, dtype=torch.uint8).pin_memory()) for _ in range(2)]
+        import os as _os
+        # one staging slot per file: the largest of the first pair's files (a run's files share one format)
+        # and a headerless frame, rounded up to 4 KiB
+        sizes = [H * W] + [_os.path.getsize(p_) for p_ in self._dataset.img_pairs[first[0]] if _os.path.exists(p_)]
+        cap = (max(sizes) + 4095) // 4096 * 4096
+        stage = [torch.empty(2 * batch_size, cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
         free = [threading.Event(), threading.Event()]
         for e in free:
             e.set()
@@ -460,18 +466,26 @@ class OfflinePIV:
 
         def loader():
             try:
-                for n, s in enumerate(range(0, len(idx), batch_size)):
+                for n, s0 in enumerate(range(0, len(idx), batch_size)):
                     buf = n % 2
                     free[buf].wait()
                     free[buf].clear()
-                    sa, sb = stage[buf][0].numpy(), stage[buf][1].numpy()
-                    chunk = []
-                    for i in idx[s:s + batch_size]:
-                        pa, pb = self._dataset.img_pairs[i]
+                    raw = stage[buf].numpy()
+                    chunk, desc_a, desc_b, lut_a, lut_b = [], [], [], [], []
+                    for i in idx[s0:s0 + batch_size]:
+                        pa, pb = self._dataset.img_pairs[i][0], self._dataset.img_pairs[i][-1]
                         k = len(chunk)
-                        if decode_into(pb, sb[k]) and decode_into(pa, sa[k]):
-                            chunk.append(i)
-                    q.put((buf, chunk))
+                        lb = stage_raw(pb, raw[2 * k + 1], H, W)           # (the reference reads b first)
+                        la = stage_raw(pa, raw[2 * k], H, W) if lb is not None else None
+                        if la is None or lb is None:
+                            continue                                     # undecodable: pair skipped (B:138-139)
+                        desc_a.append([2 * k * cap, la[0], la[1], la[2], la[3], 0])
+                        desc_b.append([(2 * k + 1) * cap, lb[0], lb[1], lb[2], lb[3], 0])
+                        lut_a.append(la[4])
+                        lut_b.append(lb[4])
+                        chunk.append(i)
+                    # unpacked frame order: every a of the batch, then every b (two contiguous stacks)
+                    q.put((buf, chunk, desc_a + desc_b, lut_a + lut_b))
             finally:
                 q.put(None)
 
@@ -479,20 +493,23 @@ class OfflinePIV:
         th.start()
         w, o, _, _ = plan.geometry[-1]
         x, y = get_coordinates((H, W), w, o)
+        dev = self._device
         while True:
             item = q.get()
             if item is None:
                 break
-            buf, chunk = item
+            buf, chunk, desc, luts = item
             if not chunk:
                 free[buf].set()
                 continue
             n = len(chunk)
-            A = stage[buf][0][:n].to(self._device, non_blocking=True)
-            B = stage[buf][1][:n].to(self._device, non_blocking=True)
+            raw_d = stage[buf][:2 * n].to(dev, non_blocking=True)
             up = torch.cuda.Event()
             up.record()
-            u, v, inv = plan.run(A, B)
+            desc_d = torch.tensor(desc, dtype=torch.int64).to(dev, non_blocking=True)
+            lut_d = torch.from_numpy(np.stack(luts)).to(dev, non_blocking=True)
+            frames = engine.bmp_unpack(raw_d.view(-1), desc_d, lut_d, H, W)      # [2n, H, W]: a_0..a_n-1, b_0..b_n-1
+            u, v, inv = plan.run(frames[:n], frames[n:])
             up.synchronize()                  # staging buffer may be refilled now
             free[buf].set()
             for i, uv in zip(chunk, self._post_validate_batch(u, v, inv)):
@@ -500,7 +517,6 @@ class OfflinePIV:
                 if out is not None:
                     yield (i,) + out
         th.join()
-
 
 class ResidentPIV(OfflinePIV):
     """OfflinePIV over frame pairs that already live on the GPU (uint8 tensors [n, H, W]): the same

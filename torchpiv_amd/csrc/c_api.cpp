@@ -806,6 +806,16 @@ int tpiv_postval(double* u, double* v, const uint8_t* invalid, int batch, int n_
     return TPIV_OK;
 }
 
+int tpiv_bmp_unpack(const uint8_t* raw, const int64_t* desc, const uint8_t* lut, int n_files, int H, int W,
+                    uint8_t* out, void* stream) {
+    if (n_files < 0 || H <= 0 || W <= 0) return fail(TPIV_EINVAL, "tpiv_bmp_unpack: bad shape");
+    if (n_files == 0) return TPIV_OK;
+    if (!raw || !desc || !lut || !out) return fail(TPIV_EINVAL, "tpiv_bmp_unpack: null pointer");
+    HIP_TRY(tpiv::launch_bmp_unpack(raw, reinterpret_cast<const long long*>(desc), lut, n_files, H, W, out,
+                                    (hipStream_t)stream));
+    return TPIV_OK;
+}
+
 // Diagnostic builds (make stamps): device buffer of 32 uint64 that the tile kernels add their
 // per-phase s_memtime deltas to.  Not declared in the public header: the production library
 // ignores it (the stamp code is compiled out).

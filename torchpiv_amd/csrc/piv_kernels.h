@@ -98,6 +98,10 @@ struct PostvalParams {
 };
 hipError_t launch_postval(const PostvalParams& p, hipStream_t stream);
 
+// image ingest (ingest.hip): raw uncompressed BMP files -> uint8 frames
+hipError_t launch_bmp_unpack(const uint8_t* raw, const long long* desc, const uint8_t* lut, int n_files, int H, int W,
+                             uint8_t* out, hipStream_t stream);
+
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 // wavefronts per SIMD the tile kernel of (ws, mode) is built for (the OCC template argument of
 // xcorr_tile_kernel); 0 for sizes that run another kernel

@@ -206,6 +206,23 @@ def postval(u, v, inv):
     return cls, counts
 
 
+def bmp_unpack(raw, desc, lut, H, W, out=None):
+    """Device unpack of raw uncompressed BMP files (tpiv_bmp_unpack).  raw uint8 [bytes] on the GPU, desc
+    int64 [n, 6] and lut uint8 [n, 256] (device), see include/torchpiv_hip.h.  Returns uint8 [n, H, W]."""
+    _need_cuda(raw, desc, lut)
+    n = desc.shape[0]
+    if desc.dtype != torch.int64 or lut.dtype != torch.uint8 or raw.dtype != torch.uint8 or tuple(desc.shape) != (n, 6) \
+            or tuple(lut.shape) != (n, 256) or not (desc.is_contiguous() and lut.is_contiguous() and raw.is_contiguous()):
+        raise ValueError("bmp_unpack: raw uint8 [bytes], desc int64 [n, 6], lut uint8 [n, 256], all contiguous")
+    if out is None:
+        out = torch.empty(n, H, W, dtype=torch.uint8, device=raw.device)
+    elif out.dtype != torch.uint8 or tuple(out.shape) != (n, H, W) or not out.is_contiguous() or out.device != raw.device:
+        raise ValueError("bmp_unpack: out must be a contiguous uint8 [n, H, W] tensor on the same device")
+    with torch.cuda.device(raw.device):
+        check(lib.tpiv_bmp_unpack(raw.data_ptr(), desc.data_ptr(), lut.data_ptr(), n, H, W, out.data_ptr(), _stream()))
+    return out
+
+
 class Plan:
     """The multipass pipeline of OfflinePIV.__call__ (PIVbackend.py:873-882) for batches of
     pairs resident on one GPU.  Owns the device workspace; `run` only enqueues kernels."""

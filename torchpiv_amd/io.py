@@ -17,13 +17,17 @@ import numpy as np
 import torch
 
 
-def atoi(text):
-    return int(text) if text.isdigit() else text
+_DIGIT_RUNS = re.compile(r"(\d+)")
 
 
 def natural_keys(text):
-    """Sort key for 'human' ordering: image9 < image10 (PlotterFunctions.py:31-37)."""
-    return [atoi(c) for c in re.split(r"(\d+)", text)]
+    """Sort key for 'human' ordering (image9 < image10), the order the reference lists a folder in
+    (PlotterFunctions.py:27-37): the name split at its digit runs, the runs compared as numbers."""
+    return [int(part) if part.isdigit() else part for part in _DIGIT_RUNS.split(text)]
+
+
+def atoi(text):          # kept for callers of the reference's helper name
+    return natural_keys(text)[0] if text.isdigit() else text
 
 
 def _bgr_to_gray(b, g, r):
@@ -32,9 +36,11 @@ def _bgr_to_gray(b, g, r):
             >> 14).astype(np.uint8)
 
 
-def decode_bmp_gray(buf: bytes):
-    """Uncompressed 8/24/32-bit BMP -> uint8 [H, W] grayscale; None if not such a file."""
-    if len(buf) < 54 or buf[:2] != b"BM":
+def bmp_layout(buf):
+    """Header of an uncompressed 8/24/32-bit BMP -> dict(w, h, data_off, stride, bytes_pp, flip, lut) or
+    None if `buf` (bytes-like, at least the header and palette) is not such a file.  `lut` (uint8 [256]) maps a
+    palette index to its gray value (OpenCV's BGR2GRAY of the palette entry); None for 24/32-bit files."""
+    if len(buf) < 54 or bytes(buf[:2]) != b"BM":
         return None
     data_off = struct.unpack_from("<I", buf, 10)[0]
     hdr = struct.unpack_from("<I", buf, 14)[0]
@@ -44,27 +50,66 @@ def decode_bmp_gray(buf: bytes):
     ncol = struct.unpack_from("<I", buf, 46)[0]
     if comp not in (0, 3) or bpp not in (8, 24, 32) or w <= 0 or h == 0:
         return None
-    flip = h > 0
-    h = abs(h)
-    row = ((w * bpp + 31) // 32) * 4
-    if len(buf) < data_off + row * h:
-        return None
-    raw = np.frombuffer(buf, dtype=np.uint8, count=row * h, offset=data_off).reshape(h, row)
+    lut = None
     if bpp == 8:
         n = ncol if ncol else 256
+        if n > 256 or len(buf) < 14 + hdr + 4 * n:
+            return None
         pal = np.frombuffer(buf, dtype=np.uint8, count=n * 4, offset=14 + hdr).reshape(n, 4)
         lut = np.zeros(256, dtype=np.uint8)
         lut[:n] = _bgr_to_gray(pal[:, 0], pal[:, 1], pal[:, 2])
-        if n == 256 and np.array_equal(lut, np.arange(256, dtype=np.uint8)):
+    return {"w": w, "h": abs(h), "data_off": data_off, "stride": ((w * bpp + 31) // 32) * 4,
+            "bytes_pp": bpp // 8, "flip": h > 0, "lut": lut}
+
+
+def decode_bmp_gray(buf: bytes):
+    """Uncompressed 8/24/32-bit BMP -> uint8 [H, W] grayscale; None if not such a file."""
+    lay = bmp_layout(buf)
+    if lay is None:
+        return None
+    w, h, row, nb = lay["w"], lay["h"], lay["stride"], lay["bytes_pp"]
+    if len(buf) < lay["data_off"] + row * h:
+        return None
+    raw = np.frombuffer(buf, dtype=np.uint8, count=row * h, offset=lay["data_off"]).reshape(h, row)
+    if nb == 1:
+        lut = lay["lut"]
+        if np.array_equal(lut, np.arange(256, dtype=np.uint8)):
             img = raw[:, :w]            # grey ramp palette (what cameras write): the index IS the value
         else:
             img = lut[raw[:, :w]]
     else:
-        px = raw[:, : w * (bpp // 8)].reshape(h, w, bpp // 8)
+        px = raw[:, : w * nb].reshape(h, w, nb)
         img = _bgr_to_gray(px[..., 0], px[..., 1], px[..., 2])
-    if flip:
+    if lay["flip"]:
         img = img[::-1]
     return np.ascontiguousarray(img)
+
+
+IDENTITY_LUT = np.arange(256, dtype=np.uint8)
+
+
+def stage_raw(path: str, slot: np.ndarray, H: int, W: int):
+    """Put the file `path` into `slot` (a uint8 view of pinned staging memory) for the device unpack
+    (tpiv_bmp_unpack): an uncompressed BMP of the right shape goes in as its raw file bytes; anything
+    else is decoded on the host (imdecode_gray) and stored as headerless top-down pixels.  Returns
+    (data_off, stride, bytes_pp, flip, lut) or None when the file cannot be decoded / has another shape."""
+    try:
+        with open(path, "rb", buffering=0) as f:
+            size = os.fstat(f.fileno()).st_size
+            if size <= slot.size:
+                got = f.readinto(memoryview(slot)[:size])
+                lay = bmp_layout(slot[:size]) if got == size else None
+                if lay is not None and (lay["h"], lay["w"]) == (H, W) and \
+                        lay["data_off"] + lay["stride"] * H <= size:
+                    lut = lay["lut"] if lay["lut"] is not None else IDENTITY_LUT
+                    return lay["data_off"], lay["stride"], lay["bytes_pp"], int(lay["flip"]), lut
+    except OSError:
+        return None
+    img = imdecode_gray(path)
+    if img is None or img.shape != (H, W) or H * W > slot.size:
+        return None
+    slot[:H * W] = img.reshape(-1)
+    return 0, W, 1, 0, IDENTITY_LUT
 
 
 def imdecode_gray(path: str):
@@ -143,13 +188,14 @@ class PIVDataset(torch.utils.data.Dataset):
         return len(self.img_pairs)
 
     def __getitem__(self, index):
-        if torch.is_tensor(index):
-            index = index.tolist()
-        pair = self.img_pairs[index]
-        frame_b = imdecode_gray(pair[-1])
-        frame_a = imdecode_gray(pair[0])
-        if frame_a is None or frame_b is None:
+        """(frame_a, frame_b) of pair `index`, or (None, None) when either file cannot be decoded
+        (the reference then skips the pair, B:138-139)."""
+        index = index.tolist() if torch.is_tensor(index) else index
+        path_a, path_b = self.img_pairs[index][0], self.img_pairs[index][-1]
+        frames = [imdecode_gray(path_b), imdecode_gray(path_a)]          # (the reference reads b first)
+        if any(f is None for f in frames):
             return None, None
-        if self.transform:
-            return self.transform(frame_a), self.transform(frame_b)
-        return frame_a, frame_b
+        frame_b, frame_a = frames
+        if self.transform is None:
+            return frame_a, frame_b
+        return self.transform(frame_a), self.transform(frame_b)
