@@ -1,28 +1,83 @@
-"""End-to-end rate of the drop-in generator on BMP files (decode + H2D + kernels + D2H + host hole fill)."""
-import os, sys, tempfile, time
+"""End-to-end rate of the drop-in generator (development aid; `bench.py --e2e` prints the same figures as JSON).
+
+  resident   ResidentPIV.batched over frames already in HBM: passes + device post-validation + counted
+             host fallbacks + flip/scale + yield
+  files      OfflinePIV.batched over 8-bit BMP files: read into pinned staging, upload of the raw bytes,
+             device unpack, then as above
+"""
+import os
+import sys
+import tempfile
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-from PIL import Image
+import numpy as np
+import torch
+
 import torchpiv_amd as T
 from torchpiv_amd import synth
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-H = W = 2048
-d = tempfile.mkdtemp()
-for i in range(n):
-    a, b = synth.make_pair(H, W, i, noise=3.0, device="cuda")
-    a, b = a.cpu().numpy().copy(), b.cpu().numpy().copy()
-    a[100:140, 200:260] = 0; b[100:140, 200:260] = 0          # a dead patch -> some invalid vectors
-    Image.fromarray(a, "L").save(os.path.join(d, f"img{i:04d}_a.bmp"))
-    Image.fromarray(b, "L").save(os.path.join(d, f"img{i:04d}_b.bmp"))
-piv = T.OfflinePIV(d, "cuda:0", "bmp", 64, 32, multipass=2, multipass_mode="CWS")
-t0 = time.perf_counter(); r = list(piv()); t1 = time.perf_counter()
-print(f"generator: {len(r)}/{len(piv)} pairs in {t1 - t0:.2f} s -> {len(piv) / (t1 - t0):.1f} pairs/s (first call incl. plan creation)")
-t0 = time.perf_counter(); r = list(piv()); t1 = time.perf_counter()
-print(f"generator: {len(r)}/{len(piv)} pairs in {t1 - t0:.2f} s -> {len(piv) / (t1 - t0):.1f} pairs/s")
-t0 = time.perf_counter(); r = list(piv.batched(8)); t1 = time.perf_counter()
-print(f"batched(8): {len(r)}/{len(piv)} pairs in {t1 - t0:.2f} s -> {len(piv) / (t1 - t0):.1f} pairs/s")
-# where does the time go (one pair)
-import cProfile, pstats
-pr = cProfile.Profile(); pr.enable(); list(piv()); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+
+def make_frames(n, H, W, kind):
+    """kind: 'clean' (no invalid vector: every pair is dropped by the reference's quirk), 'runs' (short
+    straight runs of dead windows: device-complete post-validation), 'spots' (isolated dead spots: the
+    co-circular case that needs the host triangulation)."""
+    A, B = synth.make_batch(n, H, W, device="cuda", noise=2.0)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for i in range(n):
+        if kind == "clean":
+            continue
+        for _ in range(6):
+            y = int(torch.randint(100, H - 200, (1,), generator=g))
+            x = int(torch.randint(100, W - 200, (1,), generator=g))
+            if kind == "runs":            # a 40 x 72 px black bar: two horizontally adjacent dead 32x32 windows
+                A[i, y:y + 40, x:x + 72] = 0
+                B[i, y:y + 40, x:x + 72] = 0
+            else:                          # a 40 x 40 px black spot: one dead 32x32 window at 16 px pitch
+                A[i, y:y + 40, x:x + 40] = 0
+                B[i, y:y + 40, x:x + 40] = 0
+    return A, B
+
+
+def rate(gen, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = sum(1 for _ in gen)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return n / dt, k
+
+
+def main(n=128, H=2048, W=2048, batch=32, workers=0):
+    out = {}
+    for kind in ("clean", "runs", "spots"):
+        A, B = make_frames(n, H, W, kind)
+        piv = T.ResidentPIV(A, B, 64, 32, multipass=2, multipass_mode="CWS")
+        piv.fill_workers = workers
+        rate(piv.batched(batch), n)                      # warm-up: plan creation
+        piv.reset_stats()
+        r, k = rate(piv.batched(batch), n)
+        out[kind] = r
+        print(f"resident {kind:6s}: {r:8.1f} pairs/s ({k} of {n} yielded)  {piv.stats}")
+        if kind == "spots":
+            from PIL import Image
+            d = tempfile.mkdtemp()
+            for i in range(n):
+                Image.fromarray(A[i].cpu().numpy(), "L").save(os.path.join(d, f"img{i:04d}_a.bmp"))
+                Image.fromarray(B[i].cpu().numpy(), "L").save(os.path.join(d, f"img{i:04d}_b.bmp"))
+            fp = T.OfflinePIV(d, "cuda:0", "bmp", 64, 32, multipass=2, multipass_mode="CWS")
+            fp.fill_workers = workers
+            rate(fp.batched(batch), n)
+            fp.reset_stats()
+            r, k = rate(fp.batched(batch), n)
+            out["files"] = r
+            print(f"files    {kind:6s}: {r:8.1f} pairs/s ({k} of {n} yielded; 8-bit BMP in the page cache)  {fp.stats}")
+            r, k = rate(fp(), n)
+            print(f"files    __call__ (one pair per launch): {r:8.1f} pairs/s")
+        piv.close()
+        del A, B
+    return out
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 128, workers=int(sys.argv[2]) if len(sys.argv) > 2 else 0)

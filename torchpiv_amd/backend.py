@@ -260,23 +260,38 @@ def post_validate(u, v, val):
     return u, v
 
 
-def fill_holes_host(u: np.ndarray, v: np.ndarray, hole: np.ndarray):
-    """fillMissingValues (B:284-308) for u AND v with ONE triangulation: both fields carry the same
-    holes, so the reference's two interpolators triangulate the same ring points in the same order
-    and apply the same barycentric weights; evaluating a two-column interpolator is bit-identical.
-    u, v are filled in place; returns False when the reference would drop the pair (Qhull refuses
-    the ring, e.g. collinear points; the size test is done by the caller from the ring count)."""
-    from scipy.interpolate import LinearNDInterpolator
+def _ring_of(hole: np.ndarray) -> np.ndarray:
+    """Valid cells 4-adjacent to a hole (getPixelsForInterp, B:266-282: 3x3 cross, zero border)."""
     ring = np.zeros_like(hole)
     ring[1:, :] |= hole[:-1, :]
     ring[:-1, :] |= hole[1:, :]
     ring[:, 1:] |= hole[:, :-1]
     ring[:, :-1] |= hole[:, 1:]
     ring &= ~hole
+    return ring
+
+
+def qhull_fill(points: np.ndarray, values: np.ndarray, targets: np.ndarray):
+    """The triangulation step of fillMissingValues (B:300-302) on plain arrays: Delaunay-linear
+    interpolation of `values` [n, k] given at integer `points` [n, 2], evaluated at `targets` [m, 2].
+    None when Qhull refuses the points (the reference's bare `except` then drops the pair).  A pure
+    function of small arrays, so that it can run in worker processes (OfflinePIV.fill_workers)."""
+    from scipy.interpolate import LinearNDInterpolator
     try:
-        interp = LinearNDInterpolator(np.argwhere(ring), np.stack([u[ring], v[ring]], axis=1))
-        vals = interp(np.argwhere(hole))
+        return LinearNDInterpolator(points, values)(targets)
     except Exception:
+        return None
+
+
+def fill_holes_host(u: np.ndarray, v: np.ndarray, hole: np.ndarray, solve=qhull_fill):
+    """fillMissingValues (B:284-308) for u AND v with ONE triangulation: both fields carry the same
+    holes, so the reference's two interpolators triangulate the same ring points in the same order
+    and apply the same barycentric weights; evaluating a two-column interpolator is bit-identical.
+    u, v are filled in place; returns False when the reference would drop the pair (Qhull refuses
+    the ring, e.g. collinear points; the size test is done by the caller from the ring count)."""
+    ring = _ring_of(hole)
+    vals = solve(np.argwhere(ring), np.stack([u[ring], v[ring]], axis=1), np.argwhere(hole))
+    if vals is None:
         return False
     u[hole] = vals[:, 0]
     v[hole] = vals[:, 1]
@@ -354,14 +369,53 @@ class OfflinePIV:
         self.stats = {"pairs": 0, "dropped_no_invalid": 0, "dropped_too_many": 0, "device_complete": 0,
                       "host_fallback": 0, "dropped_by_qhull": 0}
 
-    def _post_validate_batch(self, u, v, inv):
-        """B:884-892 for a batch of final fields on the device.  u, v float64 [n, nr, nc] (modified in
-        place), inv uint8.  Returns a list with one entry per pair: None (dropped) or (u, v) numpy
-        arrays before the flip / scaling.  One small D2H (the census) decides the drops; only the
-        surviving pairs are copied back."""
-        n, nr, nc = u.shape
+    fill_workers = 0         # > 0: the host triangulations of a batch run in that many worker processes
+    read_threads = 4         # file reader threads of batched()
+
+    def _fill_pool(self):
+        if self.fill_workers <= 0:
+            return None
+        pool = getattr(self, "_pool", None)
+        if pool is None or getattr(self, "_pool_size", 0) != self.fill_workers:
+            import multiprocessing as mp
+            if pool is not None:
+                pool.terminate()
+            # spawn: the workers never see this process's HIP state; they only run scipy on small arrays
+            self._pool = pool = mp.get_context("spawn").Pool(self.fill_workers)
+            self._pool_size = self.fill_workers
+        return pool
+
+    def close(self):
+        pool = getattr(self, "_pool", None)
+        if pool is not None:
+            pool.terminate()
+            self._pool = None
+        if getattr(self, "_plan", None) is not None:
+            self._plan.close()
+            self._plan = None
+
+    def _post_submit(self, u, v, inv):
+        """Device half of B:884-892 for a batch of final fields (u, v float64 [n, nr, nc], modified in
+        place; inv uint8): tpiv_postval, then ASYNCHRONOUS copies of the census, the fields and the
+        class map into pinned memory.  Nothing here waits for the GPU: the caller may enqueue the next
+        batch before it collects this one."""
         cls, counts = engine.postval(u, v, inv)
-        cnt = counts.cpu().numpy().astype(np.int64)                  # [n, 4] holes, ring, ambiguous, general
+        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (counts, u, v, cls)]
+        for h, t in zip(host, (counts, u, v, cls)):
+            h.copy_(t, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return done, host, (u, v, cls, counts)          # (the device tensors stay referenced until collected)
+
+    def _post_collect(self, ticket):
+        """Host half: drop decisions from the census, host triangulation for the pairs that hold an
+        ambiguous or wide hole (counted).  Returns one entry per pair: None (dropped) or (u, v) numpy
+        arrays before the flip / scaling."""
+        done, host, _keep_alive = ticket
+        done.synchronize()
+        cnt = host[0].numpy().astype(np.int64)                       # [n, 4] holes, ring, ambiguous, general
+        uk, vk, ck = host[1].numpy(), host[2].numpy(), host[3].numpy()
+        n, nr, nc = uk.shape
         ring = cnt[:, 1]
         no_ring = ring == 0                  # nothing to interpolate from (B:300-304; the clean-pair quirk)
         too_many = ~no_ring & (4 * ring >= nr * nc)                  # points.size >= mask.size / 2 (B:299, 305)
@@ -374,27 +428,31 @@ class OfflinePIV:
         for _ in range(2 * int(too_many.sum())):                  # once for u, once for v (B:306, B:889-890)
             print("Warning! to many false vectors")
         out = [None] * n
-        idx = np.flatnonzero(keep)
-        if idx.size == 0:
-            return out
-        sel = torch.from_numpy(idx).to(u.device)
-        uk = u.index_select(0, sel).cpu().numpy()
-        vk = v.index_select(0, sel).cpu().numpy()
-        hidx = np.flatnonzero(need_host[idx])
-        ck = cls.index_select(0, sel[torch.from_numpy(hidx).to(u.device)]).cpu().numpy() if hidx.size else None
-        pos = {int(h): j for j, h in enumerate(hidx)}
-        for k, i in enumerate(idx):
-            if k in pos:
-                st["host_fallback"] += 1
-                c = ck[pos[k]]
-                hole = (c >= 1) & (c <= 4)
-                if not fill_holes_host(uk[k], vk[k], hole):
-                    st["dropped_by_qhull"] += 1
-                    continue
+        jobs = []
+        for i in np.flatnonzero(keep):
+            if need_host[i]:
+                hole = (ck[i] >= 1) & (ck[i] <= 4)
+                rg = _ring_of(hole)
+                jobs.append((int(i), hole, (np.argwhere(rg), np.stack([uk[i][rg], vk[i][rg]], axis=1), np.argwhere(hole))))
             else:
                 st["device_complete"] += 1
-            out[int(i)] = (uk[k], vk[k])
+                out[int(i)] = (uk[i], vk[i])
+        if jobs:
+            pool = self._fill_pool()
+            sols = pool.starmap(qhull_fill, [j[2] for j in jobs], chunksize=max(1, len(jobs) // (4 * self.fill_workers))) \
+                if pool is not None else [qhull_fill(*j[2]) for j in jobs]
+            for (i, hole, _), vals in zip(jobs, sols):
+                st["host_fallback"] += 1
+                if vals is None:
+                    st["dropped_by_qhull"] += 1
+                    continue
+                uk[i][hole] = vals[:, 0]
+                vk[i][hole] = vals[:, 1]
+                out[i] = (uk[i], vk[i])
         return out
+
+    def _post_validate_batch(self, u, v, inv):
+        return self._post_collect(self._post_submit(u, v, inv))
 
     def _finish(self, uv, x, y):
         """Flip and unit scaling of B:894-898 (numpy, the reference's own expressions)."""
@@ -465,27 +523,34 @@ class OfflinePIV:
         q = queue.Queue(maxsize=2)
 
         def loader():
+            from concurrent.futures import ThreadPoolExecutor
             try:
-                for n, s0 in enumerate(range(0, len(idx), batch_size)):
-                    buf = n % 2
-                    free[buf].wait()
-                    free[buf].clear()
-                    raw = stage[buf].numpy()
-                    chunk, desc_a, desc_b, lut_a, lut_b = [], [], [], [], []
-                    for i in idx[s0:s0 + batch_size]:
-                        pa, pb = self._dataset.img_pairs[i][0], self._dataset.img_pairs[i][-1]
-                        k = len(chunk)
-                        lb = stage_raw(pb, raw[2 * k + 1], H, W)           # (the reference reads b first)
-                        la = stage_raw(pa, raw[2 * k], H, W) if lb is not None else None
-                        if la is None or lb is None:
-                            continue                                     # undecodable: pair skipped (B:138-139)
-                        desc_a.append([2 * k * cap, la[0], la[1], la[2], la[3], 0])
-                        desc_b.append([(2 * k + 1) * cap, lb[0], lb[1], lb[2], lb[3], 0])
-                        lut_a.append(la[4])
-                        lut_b.append(lb[4])
-                        chunk.append(i)
-                    # unpacked frame order: every a of the batch, then every b (two contiguous stacks)
-                    q.put((buf, chunk, desc_a + desc_b, lut_a + lut_b))
+                # file reads release the GIL (readinto straight into pinned memory): a few reader threads
+                # overlap the page-cache / disk copies of a batch
+                with ThreadPoolExecutor(max_workers=self.read_threads) as ex:
+                    for n, s0 in enumerate(range(0, len(idx), batch_size)):
+                        buf = n % 2
+                        free[buf].wait()
+                        free[buf].clear()
+                        raw = stage[buf].numpy()
+                        ids = idx[s0:s0 + batch_size]
+                        tasks = []
+                        for k, i in enumerate(ids):
+                            pa, pb = self._dataset.img_pairs[i][0], self._dataset.img_pairs[i][-1]
+                            tasks += [(pb, raw[2 * k + 1]), (pa, raw[2 * k])]       # (the reference reads b first)
+                        lays = list(ex.map(lambda t: stage_raw(t[0], t[1], H, W), tasks))
+                        chunk, desc_a, desc_b, lut_a, lut_b = [], [], [], [], []
+                        for k, i in enumerate(ids):
+                            lb, la = lays[2 * k], lays[2 * k + 1]
+                            if la is None or lb is None:
+                                continue                                 # undecodable: pair skipped (B:138-139)
+                            desc_a.append([2 * k * cap, la[0], la[1], la[2], la[3], 0])
+                            desc_b.append([(2 * k + 1) * cap, lb[0], lb[1], lb[2], lb[3], 0])
+                            lut_a.append(la[4])
+                            lut_b.append(lb[4])
+                            chunk.append(i)
+                        # unpacked frame order: every a of the batch, then every b (two contiguous stacks)
+                        q.put((buf, len(ids), chunk, desc_a + desc_b, lut_a + lut_b))
             finally:
                 q.put(None)
 
@@ -494,25 +559,35 @@ class OfflinePIV:
         w, o, _, _ = plan.geometry[-1]
         x, y = get_coordinates((H, W), w, o)
         dev = self._device
+        pending = None
         while True:
             item = q.get()
             if item is None:
                 break
-            buf, chunk, desc, luts = item
+            buf, n_slots, chunk, desc, luts = item
             if not chunk:
                 free[buf].set()
                 continue
             n = len(chunk)
-            raw_d = stage[buf][:2 * n].to(dev, non_blocking=True)
+            raw_d = stage[buf][:2 * n_slots].to(dev, non_blocking=True)
             up = torch.cuda.Event()
             up.record()
             desc_d = torch.tensor(desc, dtype=torch.int64).to(dev, non_blocking=True)
             lut_d = torch.from_numpy(np.stack(luts)).to(dev, non_blocking=True)
             frames = engine.bmp_unpack(raw_d.view(-1), desc_d, lut_d, H, W)      # [2n, H, W]: a_0..a_n-1, b_0..b_n-1
             u, v, inv = plan.run(frames[:n], frames[n:])
+            ticket = self._post_submit(u, v, inv)
+            # the host work of the PREVIOUS batch runs while the GPU works on this one
+            if pending is not None:
+                for i, uv in zip(pending[0], self._post_collect(pending[1])):
+                    out = self._finish(uv, x, y)
+                    if out is not None:
+                        yield (i,) + out
+            pending = (chunk, ticket)
             up.synchronize()                  # staging buffer may be refilled now
             free[buf].set()
-            for i, uv in zip(chunk, self._post_validate_batch(u, v, inv)):
+        if pending is not None:
+            for i, uv in zip(pending[0], self._post_collect(pending[1])):
                 out = self._finish(uv, x, y)
                 if out is not None:
                     yield (i,) + out
@@ -554,6 +629,7 @@ class ResidentPIV(OfflinePIV):
         w, o, _, _ = plan.geometry[-1]
         x, y = get_coordinates((H, W), w, o)
         contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
+        pending = None
         for s in range(0, len(idx), batch_size):
             chunk = idx[s:s + batch_size]
             if contiguous:
@@ -562,7 +638,15 @@ class ResidentPIV(OfflinePIV):
                 sel = torch.tensor(chunk, device=self._device)
                 A, B = self._A.index_select(0, sel), self._B.index_select(0, sel)
             u, v, inv = plan.run(A, B)
-            for i, uv in zip(chunk, self._post_validate_batch(u, v, inv)):
+            ticket = self._post_submit(u, v, inv)
+            if pending is not None:          # host work of the previous batch overlaps this batch's kernels
+                for i, uv in zip(pending[0], self._post_collect(pending[1])):
+                    out = self._finish(uv, x, y)
+                    if out is not None:
+                        yield (i,) + out
+            pending = (chunk, ticket)
+        if pending is not None:
+            for i, uv in zip(pending[0], self._post_collect(pending[1])):
                 out = self._finish(uv, x, y)
                 if out is not None:
                     yield (i,) + out
