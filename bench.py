@@ -80,6 +80,11 @@ def parse_args():
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic pairs to render (0 = a whole batch)")
     ap.add_argument("--pmc", default="live", choices=("live", "file", "off"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e", action="store_true",
+                    help="end-to-end generator mode instead of the kernel-path bench: ResidentPIV / OfflinePIV.batched incl. "
+                         "device post-validation, counted host fallbacks, BMP ingest (one JSON line, N = 1)")
+    ap.add_argument("--e2e-pairs", type=int, default=128)
+    ap.add_argument("--fill-workers", type=int, default=8)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.mode is None:
@@ -217,8 +222,31 @@ def pmc_for(pmc, kernel_name):
     return None
 
 
+def e2e_mode(args):
+    """Generator rates end to end (tools/e2e_generator.py): not the BASELINE.json metric -- `value` is the
+    resident-frame rate on frames that all need the host triangulation, the other cases ride along."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import contextlib
+    import io as _io
+    import e2e_generator
+    log = _io.StringIO()
+    with contextlib.redirect_stdout(log):
+        r = e2e_generator.main(n=args.e2e_pairs, workers=args.fill_workers)
+    rec = {"metric": "generator pairs/s end to end at 4 MP, wind=64 ov=32 2-pass CWS (passes + post-validation + flip/scale + yield)",
+           "value": r["spots"], "unit": "pairs/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
+           "config": {"workload": f"{args.e2e_pairs} synthetic 2048x2048 pairs, batch 32, {args.fill_workers} Qhull worker processes",
+                      "cases": {"resident_clean_all_dropped": r["clean"], "resident_straight_runs": r["runs"],
+                                "resident_isolated_spots": r["spots"], "bmp_files_isolated_spots": r.get("files")}},
+           "log": log.getvalue().strip().splitlines()}
+    print(json.dumps(rec), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.e2e:
+        if args.gpus != 1:
+            raise SystemExit("bench.py --e2e is a single-GPU mode")
+        return e2e_mode(args)
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
