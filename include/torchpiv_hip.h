@@ -165,6 +165,15 @@ int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u_dev, doubl
 int tpiv_postval(double* u_dev, double* v_dev, const uint8_t* invalid_dev, int batch, int n_rows, int n_cols,
                  uint8_t* cls_dev, int32_t* counts_dev, void* stream);
 
+/* ---- ensemble statistics (workers.py:85-96 of the reference's job runner) ------------ */
+
+/* Mean and two-pass central moments of n stacked fields u_dev, v_dev [n, cells] float64 (dataset
+ * order): out_dev [5, cells] = mean(u), mean(v), mean((u-U)^2), mean((v-V)^2), mean((u-U)(v-V)),
+ * accumulated along the stack IN ORDER like numpy's np.mean(axis=0) -- bit-identical to the reference's
+ * np.mean(u_inst, axis=0), np.mean((u_inst - avg_u)**2, axis=0), ... */
+int tpiv_ensemble_moments(const double* u_dev, const double* v_dev, int n, long long cells, double* out_dev,
+                          void* stream);
+
 /* ---- image ingest (PIVDataset.__getitem__, B:129-144) ------------------------------- */
 
 /* Unpacks n_files uncompressed BMP files that were uploaded as RAW FILE BYTES into uint8 frames

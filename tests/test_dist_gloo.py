@@ -54,19 +54,22 @@ def _worker(rank, world, port, q):
     t[cyc] = 1
     dist.all_reduce(t)
     assert bool((t == 1).all())
-    # ensemble statistics: one all-reduce of the streaming sums equals the single-process result
+    # ensemble statistics: the ranks' fields gathered onto rank 0 give the single-process table bit for bit
     from torchpiv_amd.runner import EnsembleStats
     rng = np.random.default_rng(11)
     fields = [(rng.standard_normal((4, 5)), rng.standard_normal((4, 5))) for _ in range(6)]
     st = EnsembleStats()
     for k, (u, v) in enumerate(fields):
         if k % world == rank:
-            st.add(u, v)
-    st.allreduce()
-    full = EnsembleStats()
-    for u, v in fields:
-        full.add(u, v)
-    assert st.n == 6 and np.allclose(st.suv, full.suv) and np.allclose(st.su, full.su)
+            st.add(u, v, index=k)
+    st.gather()
+    if rank == 0:
+        full = EnsembleStats()
+        for u, v in fields:
+            full.add(u, v)
+        assert st.n == 6 and all(np.array_equal(a, b) for a, b in zip(st.moments(), full.moments()))
+    else:
+        assert st.n == 0
     dist.barrier()
     dist.destroy_process_group()
 

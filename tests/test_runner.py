@@ -1,79 +1,116 @@
-"""The headless runner (ensemble statistics + export formats of the reference's GUI worker)."""
+"""The headless runner (ensemble statistics + export formats of the reference's GUI worker) against
+goldens made by the reference's OWN PIVWorker.run / save_table / save_binary
+(tests/golden/make_golden_stats.py -> g9_stats.npz): the files must come out byte for byte."""
 import os
 
 import numpy as np
 import pytest
 
 
-def _reference_table(x, y, u_inst, v_inst):
-    """The statistics exactly as workers.py:85-118 computes them from the stacked fields."""
-    u_inst, v_inst = np.stack(u_inst), np.stack(v_inst)
-    avg_u = np.mean(u_inst, axis=0, dtype=np.float64)
-    avg_v = np.mean(v_inst, axis=0, dtype=np.float64)
-    uu = np.mean((u_inst - avg_u) ** 2, axis=0, dtype=np.float64)
-    vv = np.mean((v_inst - avg_v) ** 2, axis=0, dtype=np.float64)
-    uv = np.mean((u_inst - avg_u) * (v_inst - avg_v), axis=0, dtype=np.float64)
-    mid_i, mid_j = x.shape[-2] // 2, x.shape[-1] // 2
-    dx = (x[mid_i, mid_j + 1] - x[mid_i, mid_j]) / 1000
-    dy = (y[mid_i + 1, mid_j] - y[mid_i, mid_j]) / 1000
-    dUy, dUx = np.gradient(avg_u, dx, dy, edge_order=2)
-    dVy, dVx = np.gradient(avg_v, dx, dy, edge_order=2)
-    return {"Vx[m/s]": avg_u, "Vy[m/s]": avg_v, "(vx-Vx)(vy-Vy)[m^2/s^2]": uv, "(vx-Vx)^2[m^2/s^2]": uu,
-            "(vy-Vy)^2[m^2/s^2]": vv, "dVx/dx[1/s]": dUx, "dVx/dy[1/s]": dUy, "dVy/dx[1/s]": dVx,
-            "dVy/dy[1/s]": dVy, "W[1/s]": dVx - dUy, "S[1/s]": dVx + dUy}
+def _pairs(g):
+    n = int(g["n_pairs"][0])
+    return [tuple(g[f"pair{j}_{k}"] for k in ("x", "y", "u", "v")) for j in range(n)]
 
 
-def test_streaming_statistics_equal_two_pass():
+def _table(g):
+    return {str(k): g[f"table_{j}"] for j, k in enumerate(g["table_keys"])}
+
+
+def test_statistics_equal_the_reference_bit_for_bit(golden):
     from torchpiv_amd.runner import EnsembleStats
-    rng = np.random.default_rng(5)
-    x, y = np.meshgrid(16.0 + 8 * np.arange(11), 12.0 + 8 * np.arange(9))
-    us = [rng.standard_normal((9, 11)) * 3 + 10 for _ in range(7)]
-    vs = [rng.standard_normal((9, 11)) * 2 - 4 for _ in range(7)]
+    g = golden("g9_stats")
+    pairs = _pairs(g)
     st = EnsembleStats()
-    for u, v in zip(us, vs):
+    for x, y, u, v in pairs:
         st.add(u, v)
-    t = st.table(x, y)
-    ref = _reference_table(x, y, us, vs)
-    assert list(t)[:4] == ["x[mm]", "y[mm]", "Vx[m/s]", "Vy[m/s]"] and len(t) == 13
-    for k, v in ref.items():
-        assert np.allclose(t[k], v, rtol=1e-10, atol=1e-10), k
+    got = st.table(pairs[-1][0], pairs[-1][1])
+    want = _table(g)
+    assert list(got) == list(want) and len(got) == 13
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    # fields added out of order (as ranks deliver them) come out the same
+    st2 = EnsembleStats()
+    for j in (3, 0, 5, 1, 4, 2)[:len(pairs)]:
+        st2.add(pairs[j][2], pairs[j][3], index=j)
+    assert all(np.array_equal(st2.table(pairs[0][0], pairs[0][1])[k], want[k]) for k in want)
 
 
-def test_export_formats(tmp_path):
-    from torchpiv_amd.runner import save_binary, save_table, uniquify
-    d = str(tmp_path / "Out")
-    data = {"x[mm]": np.arange(6.0).reshape(2, 3), "Vx[m/s]": np.arange(6.0).reshape(2, 3) / 7}
-    p1 = save_table("run_pair.txt", d, data.copy())
-    p2 = save_table("run_pair.txt", d, data.copy())          # never overwrites: " (1)" is appended
-    assert os.path.basename(p1) == "run_pair.txt" and os.path.basename(p2) == "run_pair (1).txt"
-    lines = open(p1).read().splitlines()
-    assert lines[0] == "x[mm], Vx[m/s]" and lines[2] == "1.000000, 0.142857" and len(lines) == 7
-    pb = save_binary("run_pair.npy", d, data.copy())
-    arr = np.load(pb)
-    assert arr.shape == (2, 2, 3) and np.array_equal(arr[0], data["x[mm]"])
+def test_export_files_equal_the_reference_byte_for_byte(tmp_path, golden):
+    from torchpiv_amd.runner import EnsembleStats, KEYS_PAIR, save_binary, save_table, uniquify
+    g = golden("g9_stats")
+    pairs = _pairs(g)
+    st = EnsembleStats()
+    for opt, tag, save in (("Save all text", "txt", save_table), ("Save all binary", "bin", save_binary)):
+        d = str(tmp_path / ("Out_" + tag))
+        for x, y, u, v in pairs:
+            st.add(u, v)
+            save(f"run A_pair.{'txt' if tag == 'txt' else 'npy'}", d, dict(zip(KEYS_PAIR, (x, y, u, v))))
+        save_table("run A_statistics.txt", d, _table(g))
+        names = sorted(os.listdir(d))
+        assert names == [str(n) for n in g[f"{tag}_names"]]
+        for j, nm in enumerate(names):
+            assert open(os.path.join(d, nm), "rb").read() == g[f"{tag}_file{j}"].tobytes(), (tag, nm)
     assert uniquify(str(tmp_path / "nothing.txt")).endswith("nothing.txt")
+    # never overwrites: " (n)" is appended
+    p1 = save_table("t.txt", str(tmp_path), {"a": np.arange(3.0)})
+    p2 = save_table("t.txt", str(tmp_path), {"a": np.arange(3.0)})
+    assert os.path.basename(p1) == "t.txt" and os.path.basename(p2) == "t (1).txt"
+
+
+@pytest.mark.gpu
+def test_device_moments_equal_numpy_bit_for_bit(golden):
+    import torch
+    from torchpiv_amd import engine
+    from torchpiv_amd.runner import EnsembleStats
+    g = golden("g9_stats")
+    pairs = _pairs(g)
+    st = EnsembleStats()
+    for x, y, u, v in pairs:
+        st.add(u, v)
+    host = st.moments()
+    dev = st.moments(device="cuda:0")
+    for h, d in zip(host, dev):
+        assert np.array_equal(h, d)
+    rng = np.random.default_rng(4)
+    U = rng.standard_normal((257, 31, 45)) * 1e3 + 5
+    V = rng.standard_normal((257, 31, 45)) * 1e-3 - 2
+    out = engine.ensemble_moments(torch.from_numpy(U).cuda(), torch.from_numpy(V).cuda())
+    mu = np.mean(U, axis=0)
+    assert np.array_equal(out[0].cpu().numpy(), mu)
+    assert np.array_equal(out[2].cpu().numpy(), np.mean((U - mu) ** 2, axis=0))
+    assert np.array_equal(out[4].cpu().numpy(), np.mean((U - mu) * (V - np.mean(V, axis=0)), axis=0))
 
 
 @pytest.mark.gpu
 def test_run_folder_matches_generator(tmp_path, golden):
     from PIL import Image
     import torchpiv_amd as T
-    from torchpiv_amd.runner import run_folder
-    g = golden("g5_generator")
-    d = tmp_path / "pairs"
+    from torchpiv_amd.runner import EnsembleStats, run_folder
+    g = golden("g9_stats")
+    d = tmp_path / "run A"
     d.mkdir()
     for i, (a, b) in enumerate(zip(g["frames_a"], g["frames_b"])):
-        Image.fromarray(a, "L").save(d / f"image{8 + i}_a.bmp")
-        Image.fromarray(b, "L").save(d / f"image{8 + i}_b.bmp")
-    kw = dict(wind_size=32, overlap=16, multipass=3, multipass_mode="CWS", dt=2, scale=0.5)
+        Image.fromarray(a, "L").save(d / f"img{8 + i}_a.bmp")
+        Image.fromarray(b, "L").save(d / f"img{8 + i}_b.bmp")
+    ws, ov, mp_, mode, dt = (int(t) for t in g["kw"])
+    kw = dict(wind_size=ws, overlap=ov, multipass=mp_, multipass_mode=("DWS", "CWS")[mode], dt=dt, scale=float(g["scale"][0]))
     out = str(tmp_path / "Out")
-    table, n = run_folder(str(d), "cuda:0", "bmp", save_opt="Save all text", save_dir=out, batch_size=3, **kw)
+    table, n = run_folder(str(d), "cuda:0", "bmp", save_opt="Save all text", save_dir=out, batch_size=4, **kw)
     res = list(T.OfflinePIV(str(d), "cuda:0", "bmp", **kw)())
-    assert n == len(res) == 4
-    ref = _reference_table(res[0][0], res[0][1], [r[2] for r in res], [r[3] for r in res])
+    assert n == len(res) == int(g["n_pairs"][0])
+    st = EnsembleStats()
+    for x, y, u, v in res:
+        st.add(u, v)
+    ref = st.table(res[0][0], res[0][1])
     for k, v in ref.items():
-        assert np.allclose(table[k], v, rtol=1e-9, atol=1e-9, equal_nan=True), k
+        assert np.array_equal(table[k], v, equal_nan=True), k
     files = sorted(os.listdir(out))
-    assert "pairs_statistics.txt" in files and sum(f.startswith("pairs_pair") for f in files) == 4
-    hdr = open(os.path.join(out, "pairs_statistics.txt")).readline().strip().split(", ")
+    assert files == [str(nm) for nm in g["txt_names"]]
+    hdr = open(os.path.join(out, "run A_statistics.txt")).readline().strip().split(", ")
     assert hdr == list(table.keys())
+    # against the reference's own table: the mean field within the parity tolerance of the kernels
+    want = _table(g)
+    unit = 1000 * kw["scale"] / kw["dt"]
+    close = np.isclose(table["Vx[m/s]"] / unit, want["Vx[m/s]"] / unit, rtol=0, atol=1e-3, equal_nan=True)
+    print(f"  mean field within 1e-3 px of the reference's: {close.mean():.4f}")
+    assert close.mean() > 0.85

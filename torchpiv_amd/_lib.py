@@ -67,6 +67,7 @@ SIGNATURES = {
     "tpiv_plan_pass_fields": (C.c_int, [C.c_void_p, _int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_void_p)]),
     "tpiv_postval": (C.c_int, [_f64p, _f64p, _u8p, _int, _int, _int, _u8p, _vp, _vp]),
+    "tpiv_ensemble_moments": (C.c_int, [_f64p, _f64p, _int, C.c_longlong, _f64p, _vp]),
     "tpiv_bmp_unpack": (C.c_int, [_u8p, _vp, _u8p, _int, _int, _int, _u8p, _vp]),
     "tpiv_plan_set_timing": (C.c_int, [C.c_void_p, _int]),
     "tpiv_plan_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), _int, C.POINTER(C.c_int)]),

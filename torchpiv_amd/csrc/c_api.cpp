@@ -806,6 +806,13 @@ int tpiv_postval(double* u, double* v, const uint8_t* invalid, int batch, int n_
     return TPIV_OK;
 }
 
+int tpiv_ensemble_moments(const double* u, const double* v, int n, long long cells, double* out, void* stream) {
+    if (n <= 0 || cells <= 0) return fail(TPIV_EINVAL, "tpiv_ensemble_moments: needs at least one field");
+    if (!u || !v || !out) return fail(TPIV_EINVAL, "tpiv_ensemble_moments: null pointer");
+    HIP_TRY(tpiv::launch_ensemble_moments(u, v, n, cells, out, (hipStream_t)stream));
+    return TPIV_OK;
+}
+
 int tpiv_bmp_unpack(const uint8_t* raw, const int64_t* desc, const uint8_t* lut, int n_files, int H, int W,
                     uint8_t* out, void* stream) {
     if (n_files < 0 || H <= 0 || W <= 0) return fail(TPIV_EINVAL, "tpiv_bmp_unpack: bad shape");

@@ -97,6 +97,8 @@ struct PostvalParams {
     int batch, n_rows, n_cols;
 };
 hipError_t launch_postval(const PostvalParams& p, hipStream_t stream);
+// ensemble statistics (postval.hip): out [5][cells] = mean u, mean v, <u'u'>, <v'v'>, <u'v'> of n stacked fields
+hipError_t launch_ensemble_moments(const double* U, const double* V, int n, long long cells, double* out, hipStream_t stream);
 
 // image ingest (ingest.hip): raw uncompressed BMP files -> uint8 frames
 hipError_t launch_bmp_unpack(const uint8_t* raw, const long long* desc, const uint8_t* lut, int n_files, int H, int W,

@@ -149,7 +149,42 @@ __global__ __launch_bounds__(256) void postval_classify_kernel(PostvalParams p) 
     }
 }
 
+// ---- ensemble moments (workers.py:85-96): one thread per grid cell walks the stack of fields IN ORDER,
+// like numpy's reduction along the stack axis: mean = ((f0 + f1) + f2 ...) / n, then the two-pass
+// central moments sum_k (f_k - mean)^2 / n.  No contraction: numpy rounds the product and the sum apart.
+__global__ __launch_bounds__(256) void ensemble_moments_kernel(const double* __restrict__ U, const double* __restrict__ V,
+                                                               int n, long long cells, double* __restrict__ out) {
+#pragma clang fp contract(off)
+    const long long c = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (c >= cells) return;
+    double su = 0.0, sv = 0.0;
+    for (int k = 0; k < n; ++k) {
+        su = su + U[(long long)k * cells + c];
+        sv = sv + V[(long long)k * cells + c];
+    }
+    const double mu = su / (double)n, mv = sv / (double)n;
+    double suu = 0.0, svv = 0.0, suv = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double du = U[(long long)k * cells + c] - mu, dv = V[(long long)k * cells + c] - mv;
+        const double a = du * du, b = dv * dv, ab = du * dv;
+        suu = suu + a;
+        svv = svv + b;
+        suv = suv + ab;
+    }
+    out[c] = mu;
+    out[cells + c] = mv;
+    out[2 * cells + c] = suu / (double)n;
+    out[3 * cells + c] = svv / (double)n;
+    out[4 * cells + c] = suv / (double)n;
+}
+
 }  // namespace
+
+hipError_t launch_ensemble_moments(const double* U, const double* V, int n, long long cells, double* out, hipStream_t stream) {
+    if (n <= 0 || cells <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ensemble_moments_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, U, V, n, cells, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_postval(const PostvalParams& p, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(p.counts, 0, (size_t)p.batch * 4 * sizeof(int), stream);

@@ -206,6 +206,20 @@ def postval(u, v, inv):
     return cls, counts
 
 
+def ensemble_moments(U, V):
+    """(mean u, mean v, <u'u'>, <v'v'>, <u'v'>) of stacked fields U, V float64 [n, ...] on the GPU, accumulated in
+    stack order like numpy (tpiv_ensemble_moments)."""
+    _need_cuda(U, V)
+    if U.dtype != torch.float64 or V.dtype != torch.float64 or U.shape != V.shape or U.dim() < 2 or U.shape[0] < 1:
+        raise ValueError("ensemble_moments: two float64 stacks [n >= 1, ...] of one shape")
+    U, V = U.contiguous(), V.contiguous()
+    n, cells = U.shape[0], U[0].numel()
+    out = torch.empty((5,) + tuple(U.shape[1:]), dtype=torch.float64, device=U.device)
+    with torch.cuda.device(U.device):
+        check(lib.tpiv_ensemble_moments(U.data_ptr(), V.data_ptr(), n, cells, out.data_ptr(), _stream()))
+    return tuple(out.unbind(0))
+
+
 def bmp_unpack(raw, desc, lut, H, W, out=None):
     """Device unpack of raw uncompressed BMP files (tpiv_bmp_unpack).  raw uint8 [bytes] on the GPU, desc
     int64 [n, 6] and lut uint8 [n, 256] (device), see include/torchpiv_hip.h.  Returns uint8 [n, H, W]."""

@@ -7,9 +7,8 @@ Export formats are the reference's (PlotterFunctions.py:16-65): `save_table` wri
 comma-separated text table with a header line and `%.6f` numbers, `save_binary` a `.npy` stack of
 the dict's arrays; existing files are not overwritten but get " (n)" appended (`uniquify`).
 
-The statistics are accumulated as streaming sums in float64 (the reference stacks every field and
-takes two-pass means; the results agree to rounding), so a 4000-pair run needs O(1) memory, and the
-sums reduce across ranks with ONE all-reduce for multi-GPU runs.
+The statistics follow the reference's two-pass arithmetic on the stacked fields bit for bit (see
+EnsembleStats); multi-rank runs gather the fields onto rank 0 with the single end-of-run gather.
 """
 from __future__ import annotations
 
@@ -68,85 +67,83 @@ def save_table(name, path, data: dict, sep: str = ", "):
 
 
 class EnsembleStats:
-    """Streaming first and second moments of (u, v) fields."""
+    """Ensemble statistics of workers.py:85-118 -- mean, Reynolds stresses, gradients, vorticity, shear --
+    with the reference's arithmetic: it stacks every field and takes TWO-PASS means with numpy, which
+    accumulates along the stack axis in order, so `mean = ((f0 + f1) + f2 ...) / n` and
+    `uu = sum_k (f_k - mean)^2 / n` in that order are reproduced bit for bit (a streaming
+    E[x^2] - E[x]^2 would cancel where the two-pass form does not).  The fields are kept as a stack --
+    4000 fields of 127 x 127 are 1 GB -- and the moments come from one kernel on the GPU
+    (tpiv_ensemble_moments: one thread per grid cell walks the stack in order) or from numpy."""
 
     def __init__(self):
-        self.n = 0
-        self.su = self.sv = self.suu = self.svv = self.suv = None
+        self.ids, self.u, self.v = [], [], []
 
-    def add(self, u: np.ndarray, v: np.ndarray):
-        u = u.astype(np.float64)
-        v = v.astype(np.float64)
-        if self.su is None:
-            z = np.zeros_like(u)
-            self.su, self.sv, self.suu, self.svv, self.suv = z.copy(), z.copy(), z.copy(), z.copy(), z.copy()
-        self.n += 1
-        self.su += u
-        self.sv += v
-        self.suu += u * u
-        self.svv += v * v
-        self.suv += u * v
+    @property
+    def n(self):
+        return len(self.u)
 
-    def allreduce(self, device=None, group=None):
-        """Sum the accumulators over all ranks (one collective)."""
+    def add(self, u: np.ndarray, v: np.ndarray, index=None):
+        self.ids.append(len(self.ids) if index is None else int(index))
+        self.u.append(np.asarray(u, dtype=np.float64))
+        self.v.append(np.asarray(v, dtype=np.float64))
+
+    def gather(self, device=None, group=None):
+        """Multi-rank runs: bring every rank's fields onto rank 0, in dataset order (one count exchange
+        + one padded gather, torchpiv_amd.dist.gather_fields); other ranks end up empty."""
         import torch
         import torch.distributed as dist
+        from . import dist as pdist
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
-        shape = None if self.su is None else self.su.shape
-        shapes = [None] * dist.get_world_size(group)
-        dist.all_gather_object(shapes, shape, group=group)
-        shape = next((s for s in shapes if s is not None), None)
-        if shape is None:
-            return
-        if self.su is None:
-            z = np.zeros(shape)
-            self.su, self.sv, self.suu, self.svv, self.suv = z.copy(), z.copy(), z.copy(), z.copy(), z.copy()
-        pack = np.concatenate([np.array([float(self.n)]), self.su.ravel(), self.sv.ravel(), self.suu.ravel(),
-                               self.svv.ravel(), self.suv.ravel()])
         dev = device if (device is not None and dist.get_backend(group) == "nccl") else "cpu"
-        t = torch.from_numpy(pack).to(dev)
-        dist.all_reduce(t, group=group)
-        pack = t.cpu().numpy()
-        k = int(np.prod(shape))
-        self.n = int(round(pack[0]))
-        parts = [pack[1 + i * k: 1 + (i + 1) * k].reshape(shape) for i in range(5)]
-        self.su, self.sv, self.suu, self.svv, self.suv = parts
+        f = torch.from_numpy(np.stack([np.stack(self.u), np.stack(self.v)], axis=1)).to(dev) if self.u \
+            else torch.zeros((0, 2, 0, 0), dtype=torch.float64, device=dev)
+        ids, fields = pdist.gather_fields(torch.tensor(self.ids, dtype=torch.int64, device=dev), f, group=group)
+        if ids is None:
+            self.ids, self.u, self.v = [], [], []
+            return
+        fields = fields.cpu().numpy()
+        self.ids = ids.cpu().tolist()
+        self.u = [fields[k, 0] for k in range(fields.shape[0])]
+        self.v = [fields[k, 1] for k in range(fields.shape[0])]
 
-    def table(self, x: np.ndarray, y: np.ndarray) -> dict:
-        """The statistics table of workers.py:85-118 (same keys, same order, same gradient call:
-        np.gradient(avg, dx, dy, edge_order=2) with dx, dy taken at the grid centre in metres)."""
-        n = max(self.n, 1)
-        avg_u, avg_v = self.su / n, self.sv / n
-        uu = self.suu / n - avg_u * avg_u
-        vv = self.svv / n - avg_v * avg_v
-        uv = self.suv / n - avg_u * avg_v
-        mid_i, mid_j = x.shape[-2] // 2, x.shape[-1] // 2
-        dx = (x[mid_i, mid_j + 1] - x[mid_i, mid_j]) / 1000
-        dy = (y[mid_i + 1, mid_j] - y[mid_i, mid_j]) / 1000
-        dUy, dUx = np.gradient(avg_u, dx, dy, edge_order=2)
-        dVy, dVx = np.gradient(avg_v, dx, dy, edge_order=2)
-        return {
-            "x[mm]": x,
-            "y[mm]": y,
-            "Vx[m/s]": avg_u,
-            "Vy[m/s]": avg_v,
-            "(vx-Vx)(vy-Vy)[m^2/s^2]": uv,
-            "(vx-Vx)^2[m^2/s^2]": uu,
-            "(vy-Vy)^2[m^2/s^2]": vv,
-            "dVx/dx[1/s]": dUx,
-            "dVx/dy[1/s]": dUy,
-            "dVy/dx[1/s]": dVx,
-            "dVy/dy[1/s]": dVy,
-            "W[1/s]": (dVx - dUy),
-            "S[1/s]": (dVx + dUy),
-        }
+    def moments(self, device=None):
+        """(avg_u, avg_v, uu, vv, uv) in dataset order of the fields."""
+        order = np.argsort(np.asarray(self.ids), kind="stable")
+        U = np.stack([self.u[k] for k in order])
+        V = np.stack([self.v[k] for k in order])
+        if device is not None:
+            import torch
+            from . import engine
+            out = engine.ensemble_moments(torch.from_numpy(U).to(device), torch.from_numpy(V).to(device))
+            return tuple(o.cpu().numpy() for o in out)
+        avg_u = np.mean(U, axis=0, dtype=np.float64)
+        avg_v = np.mean(V, axis=0, dtype=np.float64)
+        du, dv = U - avg_u, V - avg_v
+        return (avg_u, avg_v, np.mean(du ** 2, axis=0, dtype=np.float64), np.mean(dv ** 2, axis=0, dtype=np.float64),
+                np.mean(du * dv, axis=0, dtype=np.float64))
+
+    def table(self, x: np.ndarray, y: np.ndarray, device=None) -> dict:
+        """The statistics table of workers.py:85-118: same keys, same order.  The gradients are
+        np.gradient(mean, step_x, step_y, edge_order=2) like the reference -- including its argument order
+        (the x step is handed to the ROW axis) and its choice of the grid steps at the centre cell, in
+        metres (the coordinates are millimetres)."""
+        avg_u, avg_v, uu, vv, uv = self.moments(device)
+        cy, cx = x.shape[-2] // 2, x.shape[-1] // 2
+        step_x = (x[cy, cx + 1] - x[cy, cx]) / 1000
+        step_y = (y[cy + 1, cx] - y[cy, cx]) / 1000
+        u_rows, u_cols = np.gradient(avg_u, step_x, step_y, edge_order=2)       # d/d(row), d/d(column)
+        v_rows, v_cols = np.gradient(avg_v, step_x, step_y, edge_order=2)
+        names = ("x[mm]", "y[mm]", "Vx[m/s]", "Vy[m/s]", "(vx-Vx)(vy-Vy)[m^2/s^2]", "(vx-Vx)^2[m^2/s^2]",
+                 "(vy-Vy)^2[m^2/s^2]", "dVx/dx[1/s]", "dVx/dy[1/s]", "dVy/dx[1/s]", "dVy/dy[1/s]", "W[1/s]", "S[1/s]")
+        cols = (x, y, avg_u, avg_v, uv, uu, vv, u_cols, u_rows, v_cols, v_rows, v_cols - u_rows, v_cols + u_rows)
+        return dict(zip(names, cols))
 
 
 def run_folder(folder: str, device: str, file_fmt: str, wind_size: int, overlap: int, multipass: int = 1,
                multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.0, multipass_scale: float = 2.0,
                folder_mode: str = "pairs", save_opt: str = "Dont save", save_dir: str = "Out",
-               batch_size: int = 32, on_pair=None, distributed: bool = False):
+               batch_size: int = 32, on_pair=None, distributed: bool = False, stats_on_device: bool = True):
     """Process a folder like PIVWorker.run.  save_opt: "Dont save" | "Save all binary" |
     "Save all text" | "Save statistics" (anything but "Dont save" also writes the statistics table).
     Returns (table, n_pairs_done); with distributed=True every rank processes its shard of the
@@ -170,7 +167,7 @@ def run_folder(folder: str, device: str, file_fmt: str, wind_size: int, overlap:
     done = 0
     for i, xx, yy, u, v in piv.batched(batch_size, indices=indices):
         x, y = xx, yy
-        stats.add(u, v)
+        stats.add(u, v, index=i)
         done += 1
         output = dict(zip(KEYS_PAIR, (x, y, u, v)))
         # single process: the reference's names (numbered in processing order); several ranks: the
@@ -183,19 +180,21 @@ def run_folder(folder: str, device: str, file_fmt: str, wind_size: int, overlap:
         if on_pair is not None:
             on_pair(i, output)
     if distributed and world > 1:
-        stats.allreduce(device=piv._device)
-        if x is None:                       # a rank whose shard yielded nothing still needs the grid
+        stats.gather(device=piv._device)
+        if x is None and rank == 0:         # rank 0's own shard yielded nothing: the grid depends on the geometry only
             from .backend import get_coordinates
-            plan = piv._plan
-            if plan is not None:
-                w, o, _, _ = plan.geometry[-1]
-                x, y = get_coordinates((plan.H, plan.W), w, o)
+            shape = piv.frame_shape()
+            if shape is not None:
+                w, o = int(wind_size), int(overlap)
+                for _ in range(max(1, int(multipass)) - 1):
+                    w, o = int(w // multipass_scale), int(o // multipass_scale)
+                x, y = get_coordinates(shape, w, o)
                 x, y = x * scale, y * scale
     if rank != 0:
         return None, done
-    if stats.su is None or x is None:
+    if stats.n == 0 or x is None:
         return None, done
-    table = stats.table(x, y)
+    table = stats.table(x, y, device=piv._device if stats_on_device else None)
     if save_opt != "Dont save":
         save_table(f"{name}_statistics.txt", save_dir, table.copy())
     return table, done
