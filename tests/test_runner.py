@@ -112,5 +112,11 @@ def test_run_folder_matches_generator(tmp_path, golden):
     want = _table(g)
     unit = 1000 * kw["scale"] / kw["dt"]
     close = np.isclose(table["Vx[m/s]"] / unit, want["Vx[m/s]"] / unit, rtol=0, atol=1e-3, equal_nan=True)
-    print(f"  mean field within 1e-3 px of the reference's: {close.mean():.4f}")
-    assert close.mean() > 0.85
+    # cells downstream of a coin-toss window in ANY pair of the ensemble may differ (tests/test_gpu_api.py)
+    from test_gpu_api import explained_region
+    region = np.zeros(close.shape, bool)
+    for a, b in zip(g["frames_a"], g["frames_b"]):
+        region |= explained_region(a, b, ws, ov, mp_, ("DWS", "CWS")[mode])
+    print(f"  mean field within 1e-3 px of the reference's: {close.mean():.4f}; unexplained cells "
+          f"{int((~close & ~region).sum())}; explained region {region.mean():.2f}")
+    assert not (~close & ~region).any()
