@@ -1,23 +1,42 @@
 #!/bin/bash
-# Round profile on the GPU box: bench line, rocprofv3 kernel stats of the same command, and the
-# HBM-traffic counters (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, as MI355X_MICROARCH.md
-# prescribes).  Outputs go to gpurun_out/$1/ ; copy the summaries into profiles/ afterwards.
+# Round profile on the GPU box.  Everything the bench line quotes can be re-derived from these outputs:
+#   bench lines (config 1 fast = the headline, with live PMC counters and the CPU baseline; config 1 at
+#   reference precision; configs[2] stream; 2-rank gloo rehearsals of --gpus 2),
+#   rocprofv3 --kernel-trace --stats of the headline command,
+#   configs[3] / configs[4]: quick_bench lines, kernel stats and SQ counters of their kernels,
+#   the end-to-end generator line.
+# Outputs: gpurun_out/$1/ ; copy what is to be judged into profiles/<round>/.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
-mkdir -p $OUT
+mkdir -p $OUT/other_configs
 export TMPDIR=/tmp
-R="--kernel-include-regex xcorr|predict"
-BENCH="python3 bench.py --steps 6 --warmup 2"
-python3 bench.py --steps 8 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv $R -d $OUT/stats -- $BENCH --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-cp $OUT/stats/*/*_kernel_stats.csv $OUT/kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv $R -d $OUT/pmc_fetch -- $BENCH --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv $R -d $OUT/pmc_write -- $BENCH --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv $R -d $OUT/pmc_insts -- $BENCH --no-cpu-baseline > /dev/null 2> $OUT/pmc_insts.err
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv $R -d $OUT/pmc_l2 -- $BENCH --no-cpu-baseline > /dev/null 2> $OUT/pmc_l2.err
-python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_insts $OUT/pmc_l2 > $OUT/pmc_summary.txt
-rm -rf $OUT/stats $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_insts $OUT/pmc_l2
-grep -E "xcorr|predict|Name" $OUT/kernel_stats.csv | cut -c1-150
-cat $OUT/pmc_summary.txt
-tail -c 2500 $OUT/bench.json
+R="--kernel-include-regex xcorr|predict|finalize|postval"
+python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { tail $OUT/bench_n1.err; exit 1; }
+python3 bench.py --precision reference --no-cpu-baseline > $OUT/bench_n1_reference.json 2> $OUT/bench_ref.err || exit 1
+python3 bench.py --config 2 --no-cpu-baseline > $OUT/bench_n1_config2.json 2> $OUT/bench_c2.err || exit 1
+TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 2 --batch 64 --pmc off > $OUT/bench_gloo2_config1.json 2> $OUT/g2.err || exit 1
+TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --config 2 --steps 3 --stream 1000 --batch 250 --pmc off > $OUT/bench_gloo2_config2.json 2> $OUT/g2c2.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv $R -d $OUT/stats -- python3 bench.py --steps 50 --warmup 5 --pmc off --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+cp $OUT/stats/*/*_kernel_stats.csv $OUT/rocprofv3_kernel_stats.csv && rm -rf $OUT/stats
+cfg() {   # name, quick_bench args
+    local name=$1; shift
+    python3 tools/quick_bench.py "$@" 2>&1 | grep -E "pairs/s|us/pair:" > $OUT/other_configs/$name.txt
+    rocprofv3 --kernel-trace --stats --output-format csv $R -d $OUT/other_configs/$name.prof -- python3 tools/quick_bench.py "$@" > /dev/null 2> $OUT/other_configs/$name.err
+    cp $OUT/other_configs/$name.prof/*/*_kernel_stats.csv $OUT/other_configs/${name}_kernel_stats.csv; rm -rf $OUT/other_configs/$name.prof
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv --kernel-include-regex "xcorr|predict" -d $OUT/other_configs/$name.pmc -- python3 tools/quick_bench.py "$@" --iters 2 > /dev/null 2>> $OUT/other_configs/$name.err
+    python3 tools/pmc_summary.py $OUT/other_configs/$name.pmc > $OUT/other_configs/${name}_pmc.txt; rm -rf $OUT/other_configs/$name.pmc
+    cat $OUT/other_configs/$name.txt
+}
+cfg cfg3_4096_32_16_8 --size 4096 --ws 32 --passes 3 --mode CWS --batch 16
+cfg cfg4_128_64 --size 2048 --ws 128 --passes 2 --mode CWS --batch 64
+python3 bench.py --e2e > $OUT/bench_e2e.json 2> $OUT/e2e.err || tail $OUT/e2e.err
+python3 - $OUT <<'PY'
+import json, sys, glob, os
+for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):
+    try:
+        r = json.loads(open(f).read().strip().splitlines()[-1])
+        print(os.path.basename(f), "n_gpus", r.get("n_gpus"), round(r["value"]), r["unit"], r.get("dtype"), (r.get("roofline") or {}).get("kernel"), round((r.get("roofline") or {}).get("frac", 0), 4))
+    except Exception as e:
+        print(f, "unreadable", e)
+PY
