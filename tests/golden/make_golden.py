@@ -355,6 +355,19 @@ def g8_round2():
         u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
         out[f"{name}_{mode}_p1_u"], out[f"{name}_{mode}_p1_v"], out[f"{name}_{mode}_p1_val"] = u.copy(), v.copy(), val.copy()
         print(f"\n  {name} {mode} pass 1: grid {u.shape} invalid {int(val.sum())}")
+    # (c) odd window sizes in a shifted pass: 66/33 -> 33/16 (the reference's irfft2-without-`s` quirk gives a
+    # 33 x 32 correlation map there)
+    name, H, W, ws, ov = "odd66x2", 330, 396, 66, 33
+    a, b = make_frames(H, W, "wavy", 2.0, False, 41)
+    out[name + "_a"], out[name + "_b"] = a.numpy(), b.numpy()
+    out[name + "_cfg"] = np.array([ws, ov, 2])
+    for mode in ("DWS", "CWS"):
+        u, v, x, y, val = ref.extended_search_area_piv(a, b, window_size=ws, overlap=ov, validate=True)
+        out[f"{name}_{mode}_p0_u"], out[f"{name}_{mode}_p0_v"], out[f"{name}_{mode}_p0_val"] = u, v, val
+        it = ref.IterModMap.functions[mode](a.shape, ws // 2, ov // 2, torch.device("cpu"))
+        u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
+        out[f"{name}_{mode}_p1_u"], out[f"{name}_{mode}_p1_v"], out[f"{name}_{mode}_p1_val"] = u.copy(), v.copy(), val.copy()
+        print(f"\n  {name} {mode} pass 1 (ws 33/16): grid {u.shape} invalid {int(val.sum())}")
     H, W = 512, 640
     specs = [("uniform", 0.0, False), ("wavy", 2.0, True), ("vortex", 4.0, True), ("zero", 0.0, False),
              ("shear", 6.0, True)]

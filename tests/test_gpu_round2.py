@@ -71,10 +71,8 @@ def test_pass1_reference_precision_goldens(eng, golden):
     g = golden("g7_generic")
     for name in g["p1_names"]:
         ws, ov = (int(t) for t in g[name + "_cfg"])
-        if ws % 2:
-            continue
         check_reference_precision(eng, g[name + "_a"], g[name + "_b"], ws, ov, g[name + "_u"], g[name + "_v"],
-                                  g[name + "_mask"], name)
+                                  g[name + "_mask"], name)        # (incl. the odd size ws33)
     g = golden("g4_multipass")
     for name in g["names"]:
         ws, ov, _ = (int(t) for t in g[name + "_cfg"])
@@ -388,3 +386,31 @@ def test_bmp_unpack_on_device_equals_host_decode(eng, tmp_path):
     out = eng.bmp_unpack(stage.cuda().view(-1), torch.tensor([[0, lay[0], lay[1], lay[2], lay[3], 0]], dtype=torch.int64).cuda(),
                          torch.from_numpy(lay[4][None].copy()).cuda(), H, W).cpu().numpy()
     assert np.array_equal(out[0], gray)
+
+
+@pytest.mark.parametrize("mode", ["DWS", "CWS"])
+def test_odd_window_in_a_shifted_pass(eng, golden, mode):
+    """66/33 -> 33/16: an ODD window size in a shifted pass (the reference's 33 x 32 correlation map, B:255
+    irfft2 without `s`; flat-index rules with k = 32 columns and d = 33 rows), per pass from the reference's
+    fields and as a whole plan."""
+    g = golden("g8_round2")
+    name = "odd66x2"
+    ws, ov, n_pass = (int(t) for t in g[name + "_cfg"])
+    a, b = g[name + "_a"], g[name + "_b"]
+    H, W = a.shape
+    xc, yc = eng.coordinates_1d(H, W, ws, ov)
+    w, o = ws // 2, ov // 2
+    xf, yf = eng.coordinates_1d(H, W, w, o)
+    Ay, Ax = dev(eng.spline_matrix(yc, yf)), dev(eng.spline_matrix(xc, xf))
+    u0, v0, u2, v2 = eng.predict(mode, Ay, Ax, dev(g[f"{name}_{mode}_p0_u"])[None], dev(g[f"{name}_{mode}_p0_v"])[None],
+                                 dev(g[f"{name}_{mode}_p0_val"].astype(np.uint8))[None])
+    u, v, inv = eng.iterate(mode, dev(a), dev(b), w, o, u0, v0, u2, v2)
+    aa, bb = staged_windows(a, b, H, W, w, o, mode, u2, v2)
+    nr, nc = O.field_shape((H, W), w, o)
+    e, f = check_fields(u[0], v[0], inv[0], g[f"{name}_{mode}_p1_u"], g[f"{name}_{mode}_p1_v"], g[f"{name}_{mode}_p1_val"],
+                        f"{name} {mode} pass 1", max_flip_frac=0.0, max_bad_frac=0.0,
+                        excused=fp32_noise_excuse(aa, bb, nr, nc), constant=constant_windows(aa, bb, nr, nc))
+    print(f"odd window 33 {mode}: max err {e:.2e} px, mask flips {f}")
+    for precision in ("reference", "fast"):
+        cascade_check(eng, g, name, mode, precision, [(ws, ov), (w, o)],
+                      noise_ulps=16.0 if precision == "reference" else 4096.0)

@@ -134,16 +134,16 @@ def test_round2_goldens(golden):
     """g8: 256/128 -> 128/64 multipass (the only route to shifted 128-pixel windows) and the
     generator at configs[0]'s geometry (64/32, one pass)."""
     g = golden("g8_round2")
-    name = "big256x2"
-    ws, ov, n_pass = (int(t) for t in g[name + "_cfg"])
-    a, b = g[name + "_a"], g[name + "_b"]
-    for mode in ("DWS", "CWS"):
-        u, v, x, y, val = O.pass1(a, b, ws, ov, validate=True)
-        assert np.abs(u - g[f"{name}_{mode}_p0_u"]).max() <= TOL
-        it = O.ITER[mode](a.shape, ws // 2, ov // 2)
-        u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
-        assert np.abs(u - g[f"{name}_{mode}_p1_u"]).max() <= 1e-9 and np.abs(v - g[f"{name}_{mode}_p1_v"]).max() <= 1e-9
-        assert np.array_equal(val, g[f"{name}_{mode}_p1_val"])
+    for name in ("big256x2", "odd66x2"):          # odd66x2: a shifted pass with an ODD window (33 x 32 map quirk)
+        ws, ov, n_pass = (int(t) for t in g[name + "_cfg"])
+        a, b = g[name + "_a"], g[name + "_b"]
+        for mode in ("DWS", "CWS"):
+            u, v, x, y, val = O.pass1(a, b, ws, ov, validate=True)
+            assert np.abs(u - g[f"{name}_{mode}_p0_u"]).max() <= TOL
+            it = O.ITER[mode](a.shape, ws // 2, ov // 2)
+            u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
+            assert np.abs(u - g[f"{name}_{mode}_p1_u"]).max() <= 1e-9 and np.abs(v - g[f"{name}_{mode}_p1_v"]).max() <= 1e-9
+            assert np.array_equal(val, g[f"{name}_{mode}_p1_val"])
     ws, ov, mp, mode, dt = (int(t) for t in g["r5_kw"])
     res = list(O.offline_piv(zip(g["r5_frames_a"], g["r5_frames_b"]), ws, ov, multipass=mp,
                              mode=("DWS", "CWS")[mode], dt=dt, scale=float(g["r5_scale"][0])))

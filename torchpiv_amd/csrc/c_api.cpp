@@ -54,10 +54,8 @@ int check_window(int H, int W, int ws, int ov, int val_win) {
     if (ws <= 0 || ov < 0 || H <= 0 || W <= 0) return fail(TPIV_EINVAL, "non-positive size");
     if (!supported_ws(ws))
         return fail(TPIV_EUNSUPPORTED, "window size must be in 2..256 (got " + std::to_string(ws) + ")");
-    if (ws % 2 != 0)
-        return fail(TPIV_EUNSUPPORTED,
-                    "odd window sizes are not supported: the reference's irfft2 (no `s`) returns a "
-                    "ws x (ws-1) correlation map for them and its peak formulas mix the two extents");
+    // (odd sizes: the generic kernel reproduces the reference's ws x (ws-1) irfft2 map; ws = 1 has no map)
+    if (ws % 2 != 0 && ws < 3) return fail(TPIV_EUNSUPPORTED, "window size 1 has an empty correlation map in the reference");
     const bool pow2 = ws == 8 || ws == 16 || ws == 32 || ws == 64 || ws == 128;
     if (val_win < 0 || (pow2 && 2 * val_win >= ws))
         return fail(TPIV_EUNSUPPORTED, "validation half-window must satisfy 2*val_win < window size");

@@ -36,7 +36,9 @@ __device__ __forceinline__ double nan_to_num_f(double x) {      // torch.nan_to_
 template <bool F64>
 __global__ __launch_bounds__(256) void finalize_kernel(PassParams p, int mode) {
     const size_t total = (size_t)p.batch * p.n_rows * p.n_cols;
-    const int ws = p.ws;
+    // the map is d = ws rows by k columns; k = ws - 1 for odd window sizes (the reference's irfft2 quirk, see
+    // xcorr_generic.hip), and the reference's formulas take the column from m % k but the row from m // d
+    const int d_ = p.ws, k_ = (p.ws & 1) ? p.ws - 1 : p.ws;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         double cm, cl, cr, ct, cb, c2;
         int m;
@@ -59,8 +61,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(PassParams p, int mode) {
         const double den1 = 2 * (ll + lr) - 4 * lm;
         const double nom2 = lb - lt;
         const double den2 = 2 * (lb + lt) - 4 * lm;
-        double du = (double)(m % ws) + nom1 / den1 - (double)(ws / 2);
-        double dv = (double)(m / ws) + nom2 / den2 - (double)(ws / 2);
+        double du = (double)(m % k_) + nom1 / den1 - (double)(k_ / 2);      // B:407, B:416-417
+        double dv = (double)(m / d_) + nom2 / den2 - (double)(d_ / 2);      // B:404-406, B:415
         du = nan_to_num_f(du);
         dv = nan_to_num_f(dv);
         bool invalid = (cm / c2) < p.val_ratio;                // B:411

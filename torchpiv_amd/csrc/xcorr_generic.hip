@@ -116,6 +116,7 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
     using cf = cplx<R>;
     constexpr bool F64 = sizeof(R) == 8;
     __shared__ cf tw[256];            // exp(-2 pi i k / n)
+    __shared__ cf tw2[256];           // odd n: exp(-2 pi i k / (n - 1)) for the last inverse transform
     __shared__ R red[GT];
     __shared__ int redi[GT];
     const int n = p.ws, nn = n * n;
@@ -130,6 +131,10 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
         double s, c;
         sincospi(2.0 * (double)k / (double)n, &s, &c);
         tw[k] = cf{(R)c, (R)(-s)};
+        if (n > 1) {
+            sincospi(2.0 * (double)k / (double)(n - 1), &s, &c);
+            tw2[k] = cf{(R)c, (R)(-s)};
+        }
     }
     __syncthreads();
 
@@ -255,32 +260,61 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
             T0[i] = cf{re, im};
         }
         __syncthreads();
-        // ---- inverse DFT over kx, real part only, stored in fftshift coordinates into the map
+        // ---- inverse DFT over kx, real part only, stored in fftshift coordinates into the map.
+        // ODD window sizes: the reference calls irfft2 WITHOUT `s` (B:255), so the (n+1)/2 spectrum columns
+        // of its rfft2 are read as the half spectrum of an EVEN length mc = n - 1: the map is n x (n-1), its
+        // last column bin is treated as a Nyquist bin, the normalisation is 1/(n (n-1)), and every
+        // flat-index rule below runs on that n x (n-1) map (the reference's formulas use k = n-1 columns
+        // and d = n rows, B:404-407, 415-417) -- reproduced as it is.
         R* map = reinterpret_cast<R*>(T1);
-        const int hshift = n / 2;
+        const bool odd = (n & 1) != 0;
+        const int mc = odd ? n - 1 : n;             // map columns (k in the reference)
+        const int nm = n * mc;                      // map cells (k * d)
         R cmin = (R)3.4e38;
-        for (int i = tid; i < nn; i += GT) {
-            const int y = i / n, x = i % n;
-            R re = 0;
-            int idx = 0;
-            for (int kx = 0; kx < n; ++kx) {
-                const cf z = T0[y * n + kx];
-                const cf w = tw[idx];
-                re += z.x * w.x + z.y * w.y;
-                idx += x;
-                if (idx >= n) idx -= n;
+        if (!odd) {
+            const int hshift = n / 2;
+            for (int i = tid; i < nn; i += GT) {
+                const int y = i / n, x = i % n;
+                R re = 0;
+                int idx = 0;
+                for (int kx = 0; kx < n; ++kx) {
+                    const cf z = T0[y * n + kx];
+                    const cf w = tw[idx];
+                    re += z.x * w.x + z.y * w.y;
+                    idx += x;
+                    if (idx >= n) idx -= n;
+                }
+                const int ys = (y + hshift) % n, xs = (x + hshift) % n;
+                map[ys * n + xs] = re;
+                cmin = rmin(cmin, re);
             }
-            const int ys = (y + hshift) % n, xs = (x + hshift) % n;
-            map[ys * n + xs] = re;
-            cmin = rmin(cmin, re);
+        } else {
+            const int hb = mc / 2;                  // index of the bin that plays the Nyquist role
+            const R renorm = (R)n / (R)mc;          // 1/(n mc) instead of the 1/n^2 folded into the spectrum
+            for (int i = tid; i < nm; i += GT) {
+                const int y = i / mc, x = i % mc;
+                R re = T0[y * n].x + ((x & 1) ? -T0[y * n + hb].x : T0[y * n + hb].x);
+                int idx = 0;
+                for (int kx = 1; kx < hb; ++kx) {
+                    idx += x;
+                    if (idx >= mc) idx -= mc;
+                    const cf z = T0[y * n + kx];
+                    const cf w = tw2[idx];
+                    re += (R)2 * (z.x * w.x + z.y * w.y);
+                }
+                re *= renorm;
+                const int ys = (y + n / 2) % n, xs = (x + mc / 2) % mc;
+                map[ys * mc + xs] = re;
+                cmin = rmin(cmin, re);
+            }
         }
         cmin = block_min(cmin, red);
         // ---- corr - min + eps (B:518, B:381), first peak
         AM<R> best{(R)-1, 0};
-        for (int i = tid; i < nn; i += GT) {
+        for (int i = tid; i < nm; i += GT) {
             const R v = add_eps(map[i], cmin);
             map[i] = v;
-            if (p.dbg_corr != nullptr) p.dbg_corr[fidx * nn + i] = (float)v;
+            if (p.dbg_corr != nullptr && !odd) p.dbg_corr[fidx * nn + i] = (float)v;
             if (v > best.v) {
                 best.v = v;
                 best.idx = i;
@@ -290,15 +324,15 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
         const int m = best.idx;
         // ---- second peak outside the flat-index neighbourhood (B:346-358), brute-force membership
         const int wv = p.val_win;
-        AM<R> second{(R)-1, nn};
-        for (int i = tid; i < nn; i += GT) {
+        AM<R> second{(R)-1, nm};
+        for (int i = tid; i < nm; i += GT) {
             bool excl = false;
             for (int j = -wv; j <= wv; ++j) {
-                const int t = i - m - n * j;
+                const int t = i - m - mc * j;
                 if (t >= -wv && t <= wv) excl = true;
             }
-            if (i == 0 && (m - wv - wv * n) <= 0) excl = true;              // clamp to 0
-            if (i == nn - 1 && (m + wv + wv * n) >= nn - 1) excl = true;    // clamp to n*n-1
+            if (i == 0 && (m - wv - wv * mc) <= 0) excl = true;              // clamp to 0
+            if (i == nm - 1 && (m + wv + wv * mc) >= nm - 1) excl = true;    // clamp to k*d-1
             const R v = map[i];
             if (!excl && v > second.v) {
                 second.v = v;
@@ -308,23 +342,23 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
         second = block_argmax(second, red, redi);
         __syncthreads();
         if (tid < 8) {
-            int left = m + 1, right = m - 1, top = m + n, bot = m - n;      // B:385-392
-            if (left >= nn - 1) left = m;
+            int left = m + 1, right = m - 1, top = m + mc, bot = m - mc;    // B:385-392
+            if (left >= nm - 1) left = m;
             if (right <= 0) right = m;
-            if (top >= nn - 1) top = m;
+            if (top >= nm - 1) top = m;
             if (bot <= 0) bot = m;
             int q = m;
             q = (tid == 1) ? left : q;
             q = (tid == 2) ? right : q;
             q = (tid == 3) ? top : q;
             q = (tid == 4) ? bot : q;
-            q = (tid == 5) ? (second.idx < nn ? second.idx : 0) : q;
+            q = (tid == 5) ? (second.idx < nm ? second.idx : 0) : q;
             R outv = map[q];
             // Every cell inside the exclusion zone (maps smaller than 7x7): the reference's second
             // arg-max then runs over an all-zero map and returns index 0 (B:357).  In pass 1 the
             // float64 `cor` aliases the zeroed map (B:382), so c[m2] = 0 and the ratio is +inf;
             // in passes >= 2 `cor` is a float64 copy made before the zeroing, so c[m2] = c[0].
-            if (tid == 5 && second.idx >= nn && MODE == MODE_PASS1) outv = 0;
+            if (tid == 5 && second.idx >= nm && MODE == MODE_PASS1) outv = 0;
             outv = (tid == 6) ? rec_int(R(), m) : outv;
             outv = (tid == 7) ? rec_int(R(), dead ? 1 : 0) : outv;
             reinterpret_cast<R*>(p.peak_raw)[fidx * 8 + tid] = outv;
