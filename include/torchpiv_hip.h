@@ -43,7 +43,11 @@ enum tpiv_status {
 
 enum tpiv_mode {
     TPIV_MODE_DWS = 1, /* discrete window shift,  piv_iteration_DWS  B:744-812 */
-    TPIV_MODE_CWS = 2  /* continuous window shift, piv_iteration_CWS B:677-740 */
+    TPIV_MODE_CWS = 2, /* continuous window shift, piv_iteration_CWS B:677-740 */
+    TPIV_MODE_CWS_FAST = 3 /* piv_iteration_CWS_Fast B:599-675 (bicubic grid_sample of every window inside itself,
+                              u = u0 + du); the reference's OfflinePIV cannot reach it (absent from IterModMap):
+                              tpiv_iter only, generic-size kernel; u2 / v2 unused (may be NULL), u0 / v0 are the
+                              predictor AFTER the invalid-zeroing (tpiv_predict's u0 / v0) */
 };
 
 enum tpiv_precision {

@@ -289,7 +289,55 @@ class IterDWS(IterPass):
         return out[:5]
 
 
-ITER = {"DWS": IterDWS, "CWS": IterCWS}      # B:814-818
+class IterCWSFast(IterPass):
+    """B:599-675 piv_iteration_CWS_Fast (not registered in the reference's IterModMap, so OfflinePIV
+    never reaches it): every window is resampled INSIDE ITSELF by -/+ u0/2 with torch's bicubic
+    grid_sample (border padding, align_corners=False -- third-party arithmetic, called as the reference
+    calls it), normalised by its float32 mean, correlated, and the result is u = u0 + du."""
+
+    def __call__(self, frame_a, frame_b, x0, y0, u0, v0, validation_mask, debug=False):
+        import torch.nn.functional as F
+        u0, v0 = self._predict(x0, y0, u0, v0, validation_mask)
+        validate = False
+        if validation_mask is not None:
+            validate = True
+            val = spline_predict(y0, x0, validation_mask, self.slice_y, self.slice_x) >= .5
+            u0[val] = 0.0                                  # B:630-633
+            v0[val] = 0.0
+        ws = self.ws
+        aa = torch.from_numpy(windows(frame_a, ws, self.ov).copy())[:, None].float()
+        bb = torch.from_numpy(windows(frame_b, ws, self.ov).copy())[:, None].float()
+        theta = torch.tensor([[1., 0., 0.], [0., 1., 0.]]).repeat(aa.shape[0], 1, 1)
+        uflat, vflat = torch.from_numpy(u0.flatten()), torch.from_numpy(v0.flatten())
+        theta[:, 1, 2] = -vflat / ws                        # B:644-648
+        theta[:, 0, 2] = -uflat / ws
+        aa = F.grid_sample(aa, F.affine_grid(theta, aa.size(), align_corners=False), mode="bicubic",
+                           padding_mode="border", align_corners=False)
+        theta[:, 1, 2] = vflat / ws                         # B:650-653
+        theta[:, 0, 2] = uflat / ws
+        bb = F.grid_sample(bb, F.affine_grid(theta, bb.size(), align_corners=False), mode="bicubic",
+                           padding_mode="border", align_corners=False)
+        aa = aa / torch.mean(aa, (-2, -1), dtype=torch.float32, keepdim=True)      # B:656-657
+        bb = bb / torch.mean(bb, (-2, -1), dtype=torch.float32, keepdim=True)
+        corr = xcorr_fft(aa.numpy()[:, 0], bb.numpy()[:, 0])
+        with np.errstate(all="ignore"):
+            corr = corr - corr.min(axis=(-2, -1), keepdims=True)
+        du, dv, val = corr_to_disp(corr, self.n_rows, self.n_cols, validate)
+        v = v0 + dv                                         # B:663-664
+        u = u0 + du
+        mask_u = (du > u0) * (np.rint(u0) > 0)
+        mask_v = (dv > v0) * (np.rint(v0) > 0)
+        if val is not None:
+            mask_u[val] = True
+            mask_v[val] = True
+        v[mask_v] = v0[mask_v]
+        u[mask_u] = u0[mask_u]
+        if debug:
+            return u, v, self.x, self.y, val, du, dv, u0, v0, aa.numpy()[:, 0], bb.numpy()[:, 0]
+        return u, v, self.x, self.y, val
+
+
+ITER = {"DWS": IterDWS, "CWS": IterCWS}      # B:814-818 (IterCWSFast is unreachable there, as in the reference)
 
 
 # --------------------------------------------------------------------------

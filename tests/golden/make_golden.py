@@ -392,9 +392,39 @@ def g8_round2():
     save("g8_round2", **out)
 
 
+# ------------------------------------------------- G10 piv_iteration_CWS_Fast
+def g10_cws_fast():
+    """The reference's bicubic window-deformation iteration (B:599-675), which OfflinePIV cannot reach
+    (it is missing from IterModMap and its __call__ takes three more arguments): called directly."""
+    import warnings
+    out = {}
+    cases = [("wavy64", 256, 320, 64, 32, "wavy", 2.0, False, 70), ("vortex32", 200, 264, 32, 16, "vortex", 3.0, False, 71),
+             ("special32", 192, 256, 32, 16, "wavy", 2.0, True, 72)]
+    names = []
+    for (name, H, W, ws, ov, kind, noise, special, index) in cases:
+        a, b = make_frames(H, W, kind, noise, special, index)
+        u, v, x, y, val = ref.extended_search_area_piv(a, b, window_size=ws, overlap=ov, validate=True)
+        w, o = ws // 2, ov // 2
+        it = ref.piv_iteration_CWS_Fast(a.shape, w, o, torch.device("cpu"))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            u1, v1, x1, y1, val1 = it(a, b, x, y, u.copy(), v.copy(), val.copy(), w, o, torch.device("cpu"))
+        names.append(name)
+        out[name + "_a"], out[name + "_b"] = a.numpy(), b.numpy()
+        out[name + "_cfg"] = np.array([ws, ov])
+        out[name + "_p0_u"], out[name + "_p0_v"], out[name + "_p0_val"] = u, v, val
+        out[name + "_p1_u"], out[name + "_p1_v"], out[name + "_p1_val"] = u1.copy(), v1.copy(), val1.copy()
+        print(f"\n  CWS_Fast {name}: grid {u1.shape} invalid {int(val1.sum())}")
+    out["names"] = np.array(names)
+    save("g10_cws_fast", **out)
+
+
 if __name__ == "__main__":
     import sys as _sys
     only = _sys.argv[1] if len(_sys.argv) > 1 else None
+    if only == "g10":
+        g10_cws_fast()
+        raise SystemExit(0)
     if only == "g7":
         g7_generic()
     elif only == "g8":
@@ -407,3 +437,4 @@ if __name__ == "__main__":
         g6_kats()
         g7_generic()
         g8_round2()
+        g10_cws_fast()

@@ -414,3 +414,38 @@ def test_odd_window_in_a_shifted_pass(eng, golden, mode):
     for precision in ("reference", "fast"):
         cascade_check(eng, g, name, mode, precision, [(ws, ov), (w, o)],
                       noise_ulps=16.0 if precision == "reference" else 4096.0)
+
+
+def test_cws_fast_iteration_golden(eng, golden):
+    """piv_iteration_CWS_Fast (B:599-675; bicubic resampling of each window inside itself) through the
+    drop-in class, against the reference's own output and with the oracle's staged windows for the noise band."""
+    import torchpiv_amd as T
+    g = golden("g10_cws_fast")
+    for name in g["names"]:
+        ws, ov = (int(t) for t in g[name + "_cfg"])
+        a, b = g[name + "_a"], g[name + "_b"]
+        H, W = a.shape
+        w, o = ws // 2, ov // 2
+        x, y = O.coordinates(a.shape, ws, ov)
+        it = T.piv_iteration_CWS_Fast(a.shape, w, o, "cuda:0")
+        u, v, x1, y1, val = it(dev(a), dev(b), x, y, g[name + "_p0_u"].copy(), g[name + "_p0_v"].copy(),
+                               g[name + "_p0_val"].copy(), w, o, "cuda:0")
+        ref = O.IterCWSFast(a.shape, w, o)(a, b, x, y, g[name + "_p0_u"].copy(), g[name + "_p0_v"].copy(),
+                                           g[name + "_p0_val"].copy(), debug=True)
+        aa, bb = ref[9], ref[10]
+        nr, nc = u.shape
+        # the reference correlates mean-normalised float32 windows here: noise band relative to that map
+        exc = fp32_noise_excuse(aa, bb, nr, nc, ulps=64.0)
+        err = np.maximum(np.abs(u - g[name + "_p1_u"]), np.abs(v - g[name + "_p1_v"]))
+        flips = val != g[name + "_p1_val"]
+        const = constant_windows(O.windows(a, w, o), O.windows(b, w, o), nr, nc)
+        bad = ((err > TOL_PX) | flips) & ~exc & ~const
+        print(f"  CWS_Fast {name}: max err {err[~flips & ~exc & ~const].max():.2e} px, flips {int(flips.sum())}, "
+              f"in the noise band {int((exc & ~const).sum())}, constant windows {int(const.sum())}, unexplained {int(bad.sum())}")
+        assert not bad.any(), (name, np.argwhere(bad)[:5].tolist())
+        assert (exc & ~const).mean() <= 0.02
+        assert np.array_equal(x1, it.x)
+    assert "CWS_Fast" not in T.IterModMap.functions            # unreachable from OfflinePIV, as in the reference
+    with pytest.raises(KeyError):
+        T.OnlinePIV("x", "no-such-device", "bmp", 32, 16)
+    assert T.OnlinePIV("x", "cuda:0", "bmp", 32, 16)._device.type == "cuda"

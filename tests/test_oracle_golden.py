@@ -152,3 +152,17 @@ def test_round2_goldens(golden):
         assert np.array_equal(x, g[f"r5_{j}_x"]) and np.array_equal(y, g[f"r5_{j}_y"])
         assert np.allclose(u, g[f"r5_{j}_u"], rtol=0, atol=1e-9, equal_nan=True)
         assert np.allclose(v, g[f"r5_{j}_v"], rtol=0, atol=1e-9, equal_nan=True)
+
+
+def test_cws_fast_iteration(golden):
+    """piv_iteration_CWS_Fast (B:599-675, unreachable from the reference's own OfflinePIV): the oracle's
+    restatement against the reference's output."""
+    g = golden("g10_cws_fast")
+    for name in g["names"]:
+        ws, ov = (int(t) for t in g[name + "_cfg"])
+        a, b = g[name + "_a"], g[name + "_b"]
+        x, y = O.coordinates(a.shape, ws, ov)
+        it = O.IterCWSFast(a.shape, ws // 2, ov // 2)
+        u, v, _, _, val = it(a, b, x, y, g[name + "_p0_u"].copy(), g[name + "_p0_v"].copy(), g[name + "_p0_val"].copy())
+        assert np.abs(u - g[name + "_p1_u"]).max() <= 1e-9 and np.abs(v - g[name + "_p1_v"]).max() <= 1e-9, name
+        assert np.array_equal(val, g[name + "_p1_val"]), name

@@ -17,7 +17,7 @@ _API = {
     "extended_search_area_piv", "piv_iteration_CWS", "piv_iteration_DWS",
     "get_field_shape", "get_coordinates", "moving_window_array",
     "interpolate_boarders", "fillMissingValues", "getPixelsForInterp", "nan_helper",
-    "post_validate", "free_cuda_memory", "ResidentPIV", "fill_holes_host",
+    "post_validate", "free_cuda_memory", "ResidentPIV", "fill_holes_host", "piv_iteration_CWS_Fast", "OnlinePIV",
 }
 
 

@@ -13,8 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TPIV_LIB") or os.path.join(_HERE, "libtorchpiv_hip.so")
 
 OK, EINVAL, EKEY, EHIP, ENOMEM, EUNSUPPORTED = 0, 1, 2, 3, 4, 5
-MODE_DWS, MODE_CWS = 1, 2
-MODES = {"DWS": MODE_DWS, "CWS": MODE_CWS}
+MODE_DWS, MODE_CWS, MODE_CWS_FAST = 1, 2, 3
+MODES = {"DWS": MODE_DWS, "CWS": MODE_CWS}           # the multipass modes of OfflinePIV (IterModMap, B:814-818)
+ITER_MODES = dict(MODES, CWS_Fast=MODE_CWS_FAST)     # + piv_iteration_CWS_Fast (function-level seam only)
 PREC_FAST, PREC_REFERENCE = 0, 1
 PRECISIONS = {"fast": PREC_FAST, "reference": PREC_REFERENCE}
 ABI_VERSION = 2

@@ -167,7 +167,9 @@ class _piv_iteration:
                  else torch.zeros(u0.shape, dtype=torch.uint8))
         u_c = torch.from_numpy(np.ascontiguousarray(u0, dtype=np.float64)).to(dev)[None]
         v_c = torch.from_numpy(np.ascontiguousarray(v0, dtype=np.float64)).to(dev)[None]
-        p_u0, p_v0, p_u2, p_v2 = engine.predict(self.mode, Ay, Ax, u_c, v_c, inv_c.to(dev)[None])
+        # (CWS_Fast: the predictor fields after the invalid-zeroing are all it needs, B:626-633)
+        p_u0, p_v0, p_u2, p_v2 = engine.predict("CWS" if self.mode == "CWS_Fast" else self.mode, Ay, Ax, u_c, v_c,
+                                                inv_c.to(dev)[None])
         # validate=False: the reference skips the peak-ratio test (val stays None)
         ratio = 1.2 if validate else float("-inf")
         u, v, inv = engine.iterate(self.mode, frame_a.to(dev), frame_b.to(dev), self.wind_size,
@@ -184,6 +186,21 @@ class piv_iteration_CWS(_piv_iteration):
 class piv_iteration_DWS(_piv_iteration):
     """Discrete (integer) window shift iteration, B:744-812."""
     mode = "DWS"
+
+
+class piv_iteration_CWS_Fast(_piv_iteration):
+    """The reference's bicubic window-deformation iteration (B:599-675): every window is resampled inside
+    itself by -/+ u0/2 (torch's grid_sample, mode "bicubic", border padding), normalised by its mean and
+    correlated; u = u0 + du.  As in the reference it is NOT in IterModMap (OfflinePIV never uses it) and its
+    call takes three more arguments, which the reference ignores in favour of the constructor's except for
+    the window geometry."""
+    mode = "CWS_Fast"
+
+    def __call__(self, frame_a, frame_b, x0, y0, u0, v0, validation_mask, wind_size=None, overlap=None, device=None):
+        if wind_size is not None and (int(wind_size), int(overlap if overlap is not None else self.overlap)) != \
+                (self.wind_size, self.overlap):
+            raise ValueError("piv_iteration_CWS_Fast: wind_size / overlap differ from the constructor's")
+        return super().__call__(frame_a, frame_b, x0, y0, u0, v0, validation_mask)
 
 
 class IterModMap:
@@ -654,3 +671,20 @@ class ResidentPIV(OfflinePIV):
     def __call__(self) -> Generator:
         for _, x, y, u, v in self.batched(1):
             yield x, y, u, v
+
+
+class OnlinePIV:
+    """The reference's live-acquisition class is a constructor-only stub (B:906-927: it stores its arguments
+    and resolves the device; there is no processing method).  Mirrored as such -- frames acquired straight
+    into GPU memory go through ResidentPIV."""
+
+    def __init__(self, folder: str, device: str, file_fmt: str, wind_size: int, overlap: int, iterations: int = 1,
+                 dt: int = 1, scale: float = 1., resize: int = 2, iter_scale: float = 2.) -> None:
+        self._wind_size = wind_size
+        self._overlap = overlap
+        self._dt = dt
+        self._iter = iterations
+        self._iter_scale = iter_scale
+        self._resize = resize
+        self._scale = scale
+        self._device = DeviceMap.devicies[device]           # KeyError like B:927

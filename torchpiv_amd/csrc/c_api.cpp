@@ -437,7 +437,9 @@ size_t tpiv_work_bytes(int H, int W, int ws, int ov, int batch) {
     if (ov >= ws || ws > H || ws > W || ws <= 0 || ov < 0 || batch <= 0 || !supported_ws(ws)) return 0;
     int nr, nc;
     field_shape(H, W, ws, ov, &nr, &nc);
-    return tpiv::peak_raw_bytes(ws, batch, nr * nc, TPIV_PREC_REFERENCE);      // the larger of the two
+    const size_t a = tpiv::peak_raw_bytes(ws, batch, nr * nc, TPIV_PREC_REFERENCE);      // the larger of the two precisions
+    const size_t b = tpiv::peak_raw_bytes(ws, batch, nr * nc, TPIV_PREC_FAST, true);     // TPIV_MODE_CWS_FAST: generic kernel
+    return a > b ? a : b;
 }
 
 int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf, const double* Ay,
@@ -470,9 +472,13 @@ static int run_iter(int mode, int precision, const uint8_t* a, const uint8_t* b,
                     int ov, const double* u0, const double* v0, const double* u2, const double* v2,
                     double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, double* du,
                     double* dv, float* dbg_win, float* dbg_corr, void* work, size_t work_bytes, void* stream) {
-    if (mode != TPIV_MODE_DWS && mode != TPIV_MODE_CWS) return fail(TPIV_EKEY, "unknown multipass mode");
+    if (mode != TPIV_MODE_DWS && mode != TPIV_MODE_CWS && mode != TPIV_MODE_CWS_FAST)
+        return fail(TPIV_EKEY, "unknown multipass mode");
     int rc = check_window(H, W, ws, ov, val_win);
     if (rc) return rc;
+    if (mode == TPIV_MODE_CWS_FAST && ws < 2) return fail(TPIV_EINVAL, "window too small");
+    if (mode != TPIV_MODE_CWS_FAST && (!u2 || !v2)) return fail(TPIV_EINVAL, "tpiv_iter: u2 / v2 missing");
+    if (!u0 || !v0) return fail(TPIV_EINVAL, "tpiv_iter: u0 / v0 missing");
     if (precision != TPIV_PREC_FAST && precision != TPIV_PREC_REFERENCE)
         return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST or TPIV_PREC_REFERENCE");
     if (batch <= 0) return TPIV_OK;
@@ -500,7 +506,8 @@ static int run_iter(int mode, int precision, const uint8_t* a, const uint8_t* b,
     p.dbg_win = dbg_win;
     p.dbg_corr = dbg_corr;
     p.stamps = g_stamps;
-    rc = check_work(work, work_bytes, tpiv::peak_raw_bytes(ws, batch, p.n_rows * p.n_cols, TPIV_PREC_FAST));
+    rc = check_work(work, work_bytes,
+                    tpiv::peak_raw_bytes(ws, batch, p.n_rows * p.n_cols, TPIV_PREC_FAST, mode == TPIV_MODE_CWS_FAST));
     if (rc) return rc;
     p.peak_raw = static_cast<float*>(work);
     int n_cu;

@@ -6,7 +6,9 @@
 
 namespace tpiv {
 
-enum { MODE_PASS1 = 0, MODE_DWS = 1, MODE_CWS = 2 };
+// MODE_CWSF: the reference's piv_iteration_CWS_Fast (B:599-675): bicubic resampling of every window inside
+// itself; runs the generic-size kernel only
+enum { MODE_PASS1 = 0, MODE_DWS = 1, MODE_CWS = 2, MODE_CWSF = 3 };
 
 struct PassParams {
     const uint8_t* A;      // [batch, H, W] frame a
@@ -115,7 +117,7 @@ inline int tile_occ(int ws, int mode) { return tile_occ_c(ws, mode); }
 // symbol-like name of the kernel launch_xcorr picks for (ws, mode) -- for bench / profile labels
 const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len);
 // bytes of PassParams::peak_raw a pass needs (records, work-queue counters, generic-size DFT scratch)
-size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision);
+size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool force_generic = false);
 // test hook: peak stage + finalize on caller-made maps; planar selects the LDS layout variant of the tile kernel
 hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream);
 hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t stream);

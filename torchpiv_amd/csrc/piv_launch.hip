@@ -76,9 +76,15 @@ __global__ __launch_bounds__(256) void finalize_kernel(PassParams p, int mode) {
             p.v[i] = dv;
             p.val[i] = invalid ? 1 : 0;
         } else {                     // multipass combine (B:728-738 / B:800-810)
-            const double u0 = p.u0[i], v0 = p.v0[i], u2 = p.u2[i], v2 = p.v2[i];
-            double u = 2 * u2 + du;
-            double v = 2 * v2 + dv;
+            const double u0 = p.u0[i], v0 = p.v0[i];
+            double u, v;
+            if (mode == MODE_CWSF) {             // B:663-664: the windows were resampled by -/+ u0/2
+                u = u0 + du;
+                v = v0 + dv;
+            } else {
+                u = 2 * p.u2[i] + du;
+                v = 2 * p.v2[i] + dv;
+            }
             const bool mask_u = ((du > u0) && (rint(u0) > 0)) || invalid;
             const bool mask_v = ((dv > v0) && (rint(v0) > 0)) || invalid;
             if (mask_u) u = u0;
@@ -119,8 +125,8 @@ hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_
 static constexpr size_t WORK_CTR_BYTES = 8 * 16 * sizeof(unsigned);
 static size_t work_ctr_offset(int batch, int n_windows) { return (peak_bytes(batch, n_windows) + 127) / 128 * 128; }
 
-size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision) {
-    if (tile_size(ws)) {
+size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool force_generic) {
+    if (tile_size(ws) && !force_generic) {
         if (precision) return peak_bytes(batch, n_windows, 1);                      // float64 records only
         return work_ctr_offset(batch, n_windows) + WORK_CTR_BYTES;                  // records + item counters
     }
@@ -144,6 +150,7 @@ const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int le
     } else {
         snprintf(buf, len, "xcorr_generic_kernel<%d, float>", mode);
     }
+    if (mode == MODE_CWSF) snprintf(buf, len, "xcorr_generic_kernel<3, float>");
     return buf;
 }
 
@@ -160,7 +167,9 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
         q.precision = f64 ? 1 : 0;
         return launch_xcorr_generic(q, mode, 256, scratch, stream);
     };
-    if (f64) {
+    if (mode == MODE_CWSF) {
+        e = generic();
+    } else if (f64) {
         e = tile_size(p.ws) ? launch_xcorr_f64(p, n_cu, stream) : generic();
     } else if (tile_size(p.ws)) {       // per-XCD work queue of the tile kernel: counters behind the peak records
         p.work_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.peak_raw) +

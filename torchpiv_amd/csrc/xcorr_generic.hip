@@ -49,6 +49,52 @@ __device__ __forceinline__ float cws_sample_g(const uint8_t* __restrict__ f, int
     return degenerate ? f11 : r;
 }
 
+// ---- piv_iteration_CWS_Fast (B:644-653): torch's affine_grid + grid_sample(mode="bicubic",
+// padding_mode="border", align_corners=False) of a window INSIDE ITSELF, in float32.
+// cubic convolution with A = -0.75 (ATen UpSample.h: cubic_convolution1/2, get_cubic_upsample_coefficients)
+__device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
+    constexpr float A = -0.75f;
+    auto cc1 = [](float x) { return ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f; };
+    auto cc2 = [](float x) { return ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A; };
+    c[0] = cc2(t + 1.0f);
+    c[1] = cc1(t);
+    c[2] = cc1(1.0f - t);
+    c[3] = cc2(2.0f - t);
+}
+// base grid coordinate of pixel j of an n-pixel axis: linspace(-1, 1, n)[j] * (n - 1) / n (affine_grid,
+// align_corners=False), plus the translation
+__device__ __forceinline__ float base_coord(int j, int n) {
+    const float step = 2.0f / (float)(n - 1);
+    const float l = j < n / 2 ? -1.0f + step * (float)j : 1.0f - step * (float)(n - 1 - j);
+    return l * (float)(n - 1) / (float)n;
+}
+__device__ __forceinline__ float bicubic_local(const uint8_t* __restrict__ f, int W, int y0, int x0, int n, int x, int y,
+                                               float tx, float ty) {
+    // unnormalise (align_corners=False): ((coord + 1) * size - 1) / 2; the taps are clamped one by one (border)
+    const float ix = ((base_coord(x, n) + tx + 1.0f) * (float)n - 1.0f) * 0.5f;
+    const float iy = ((base_coord(y, n) + ty + 1.0f) * (float)n - 1.0f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    float cx[4], cy[4];
+    cubic_coeffs(ix - fx, cx);
+    cubic_coeffs(iy - fy, cy);
+    const int bx = f2i_sat_g(fx) - 1, by = f2i_sat_g(fy) - 1;
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int yy = by + i;
+        yy = yy < 0 ? 0 : (yy > n - 1 ? n - 1 : yy);
+        float row = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int xx = bx + j;
+            xx = xx < 0 ? 0 : (xx > n - 1 ? n - 1 : xx);
+            row += (float)f[(size_t)(y0 + yy) * W + x0 + xx] * cx[j];
+        }
+        acc += row * cy[i];
+    }
+    return acc;
+}
+
 template <typename R>
 struct cplx {
     R x, y;
@@ -151,6 +197,10 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
             vx = (float)p.u2[fidx];
             vy = (float)p.v2[fidx];
         }
+        if constexpr (MODE == MODE_CWSF) {      // B:644-645: theta[:, 0, 2] = -u0 / wind_size (float64, stored as float32)
+            vx = (float)(p.u0[fidx] / (double)n);
+            vy = (float)(p.v0[fidx] / (double)n);
+        }
         // ---- staging
         R sa = 0, sb = 0;
         for (int i = tid; i < nn; i += GT) {
@@ -164,9 +214,12 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
                 const long long q = (long long)(y0 + y) * p.W + x0 + x;
                 a = fetch_clamped_g(fa, q - sh, HW);
                 b = fetch_clamped_g(fb, q + sh, HW);
-            } else {
+            } else if constexpr (MODE == MODE_CWS) {
                 a = cws_sample_g(fa, HW, p.W, x0 + x, y0 + y, -vx, -vy);
                 b = cws_sample_g(fb, HW, p.W, x0 + x, y0 + y, vx, vy);
+            } else {
+                a = bicubic_local(fa, p.W, y0, x0, n, x, y, -vx, -vy);
+                b = bicubic_local(fb, p.W, y0, x0, n, x, y, vx, vy);
             }
             T0[i] = cf{a, b};
             sa += a;
@@ -181,7 +234,7 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
         R ma = sa / (R)nn, mb = sb / (R)nn;        // (sums of integers: exact in either type)
         bool dead = false;
         R ka = 1, kb = 1;
-        if constexpr (MODE == MODE_PASS1) {
+        if constexpr (MODE == MODE_PASS1 || MODE == MODE_CWSF) {      // a / mean(a): B:513-514, B:656-657
             dead = (sa == 0) || (sb == 0);
             ka = dead ? (R)0 : (R)1 / ma;
             kb = dead ? (R)0 : (R)1 / mb;
@@ -399,6 +452,9 @@ hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, void* s
             break;
         case MODE_CWS:
             hipLaunchKernelGGL((xcorr_generic_kernel<MODE_CWS, float>), dim3(blocks), dim3(GT), 0, stream, p, sc);
+            break;
+        case MODE_CWSF:
+            hipLaunchKernelGGL((xcorr_generic_kernel<MODE_CWSF, float>), dim3(blocks), dim3(GT), 0, stream, p, sc);
             break;
         default: return hipErrorInvalidValue;
     }

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import MODES, PRECISIONS, check, lib
+from ._lib import ITER_MODES, MODES, PRECISIONS, check, lib
 
 
 def _stream() -> int:
@@ -121,6 +121,8 @@ def iterate(mode, a, b, ws, ov, u0, v0, u2, v2, val_ratio=1.2, val_win=3, want_r
     the reference's operation order in the CWS bilinear sampling (bit-identical staged windows)."""
     prec = _precision(precision)
     a, b = _frames(a, b)
+    if mode == "CWS_Fast" and u2 is None:        # B:599-675: the shift is u0 / 2 inside the window; no u2 field
+        u2, v2 = u0, v0
     _need_cuda(u0, v0, u2, v2)
     B, H, W = a.shape
     nr, nc = field_shape(H, W, ws, ov)
@@ -132,7 +134,7 @@ def iterate(mode, a, b, ws, ov, u0, v0, u2, v2, val_ratio=1.2, val_win=3, want_r
     dv = torch.empty_like(u) if want_raw else None
     with torch.cuda.device(dev):
         work, nbytes = _work(H, W, ws, ov, B, dev)
-        check(lib.tpiv_iter(MODES[mode], a.data_ptr(), b.data_ptr(), B, H, W, ws, ov,
+        check(lib.tpiv_iter(ITER_MODES[mode], a.data_ptr(), b.data_ptr(), B, H, W, ws, ov,
                             u0.contiguous().data_ptr(), v0.contiguous().data_ptr(),
                             u2.contiguous().data_ptr(), v2.contiguous().data_ptr(),
                             val_ratio, val_win, prec, u.data_ptr(), v.data_ptr(), inv.data_ptr(),
