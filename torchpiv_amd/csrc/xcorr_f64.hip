@@ -24,12 +24,13 @@
 #include <stdint.h>
 
 #include "piv_kernels.h"
+#include "xcorr_tile.hpp"      // grp_reduce: wavefront reductions in the VALU (DPP / permlane swaps)
 
 namespace tpiv {
 
 namespace {
 
-struct cd {
+struct alignas(16) cd {       // 16-byte alignment: ds_read_b128 / ds_write_b128 instead of ds_read2_b64 / ds_write2_b64
     double x, y;
 };
 __device__ __forceinline__ cd cmul(cd a, cd w) { return cd{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
@@ -67,18 +68,23 @@ struct F64Shared {
     int bin[WS];                      // position -> bin
     double redd[16];
     int redi[8];
-    unsigned redu[16];
+    unsigned long long redu[8];
 };
 
+// Workgroup barrier for LDS exchanges only: __syncthreads() also waits for vmcnt(0), which would drain
+// the next window's pixel prefetch at the first of the ~25 barriers per window.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- workgroup reductions (every thread gets the result) ------------------------------------------
+// (the wavefront step runs in the VALU -- DPP row operations and permlane swaps, xcorr_tile.hpp -- not
+//  through ds_bpermute: six dependent LDS round trips per reduction were a sixth of the window time)
 template <int NW, typename T, typename OP>
 __device__ __forceinline__ T wg_reduce(T v, OP op, T* red) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = op(v, __shfl_xor(v, off, 64));
+    v = grp_reduce<64>(v, op);
     if constexpr (NW == 1) return v;
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     T r = red[0];
 #pragma unroll
     for (int w = 1; w < NW; ++w) r = op(r, red[w]);
@@ -182,7 +188,7 @@ __device__ __forceinline__ void stage(F64Shared<WS>& sm) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // all stages of one dimension: forward = largest block first, inverse = the same stages in reverse order
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
         sm.pos[k] = q;
         sm.bin[q] = k;
     }
-    __syncthreads();
+    lds_barrier();
 
     const int N = p.n_rows * p.n_cols;
     const long long items = (long long)p.batch * N;
@@ -229,16 +235,13 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
     const long long lo = (long long)xcd * chunk;
     const long long hi = lo + chunk < items ? lo + chunk : items;
 
-    for (long long item = lo + slot; item < hi; item += per_xcd) {
-        const int pair = (int)(item / N), win = (int)(item % N);
-        const int y0 = (win / p.n_cols) * st, x0 = (win % p.n_cols) * st;
-        const uint8_t* __restrict__ fa = p.A + (size_t)pair * HW + (size_t)y0 * p.W + x0;
-        const uint8_t* __restrict__ fb = p.B + (size_t)pair * HW + (size_t)y0 * p.W + x0;
-        const size_t fidx = (size_t)item;
-
-        // ---- stage 0: pixels (4 per dword load, any alignment), exact integer window sums
-        uint32_t da[DPT], db[DPT];
-        unsigned ia = 0, ib = 0;
+    // the pixels of the next window are fetched while the current one is transformed (4 dwords per thread)
+    uint32_t da[DPT], db[DPT];
+    auto fetch = [&](long long it) {
+        const int pair_ = (int)(it / N), win_ = (int)(it % N);
+        const int yy0 = (win_ / p.n_cols) * st, xx0 = (win_ % p.n_cols) * st;
+        const uint8_t* __restrict__ fa = p.A + (size_t)pair_ * HW + (size_t)yy0 * p.W + xx0;
+        const uint8_t* __restrict__ fb = p.B + (size_t)pair_ * HW + (size_t)yy0 * p.W + xx0;
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
             const int i = tid + q * NT;
@@ -246,15 +249,28 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
             db[q] = 0;
             if (i < NDW) {
                 const int y = i / (WS / 4), x4 = (i % (WS / 4)) * 4;
-                __builtin_memcpy(&da[q], fa + (size_t)y * p.W + x4, 4);
+                __builtin_memcpy(&da[q], fa + (size_t)y * p.W + x4, 4);      // (unaligned dword loads are fine in global memory)
                 __builtin_memcpy(&db[q], fb + (size_t)y * p.W + x4, 4);
-                ia = __builtin_amdgcn_sad_u8(da[q], 0u, ia);
-                ib = __builtin_amdgcn_sad_u8(db[q], 0u, ib);
             }
         }
-        auto uadd = [](unsigned a, unsigned b) { return a + b; };
-        ia = wg_reduce<G::NW>(ia, uadd, sm.redu);
-        ib = wg_reduce<G::NW>(ib, uadd, sm.redu + 8);
+    };
+    if (lo + slot < hi) fetch(lo + slot);
+    for (long long item = lo + slot; item < hi; item += per_xcd) {
+        const size_t fidx = (size_t)item;
+
+        // ---- stage 0: exact integer window sums of the fetched pixels
+        unsigned ia = 0, ib = 0;
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            ia = __builtin_amdgcn_sad_u8(da[q], 0u, ia);
+            ib = __builtin_amdgcn_sad_u8(db[q], 0u, ib);
+        }
+        {      // both window sums in one reduction (each is below 2^21)
+            auto uadd = [](unsigned long long a, unsigned long long b) { return a + b; };
+            const unsigned long long s2 = wg_reduce<G::NW>((unsigned long long)ia | ((unsigned long long)ib << 32), uadd, sm.redu);
+            ia = (unsigned)s2;
+            ib = (unsigned)(s2 >> 32);
+        }
         const bool dead = ia == 0u || ib == 0u;          // zero-mean window: 0/0 = NaN map in the reference
         const double ma = (double)ia / (double)NN, mb = (double)ib / (double)NN;      // torch.mean: exact sum / n
         // a / mean(a) (B:513-514) as one reciprocal per window plus a residual correction per pixel:
@@ -277,19 +293,28 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        if (item + per_xcd < hi) fetch(item + per_xcd);      // in flight during the transforms
 
+#ifndef TPIV_F64_SKIP
+#define TPIV_F64_SKIP 0
+#endif
         // ---- forward 2-D transform of a + i b, in place: bin (ky, kx) ends at [pos(ky)][pos(kx)]
-        transform<WS, WS, false, true>(sm);
-        transform<WS, WS, true, true>(sm);
+        if (!(TPIV_F64_SKIP & 1)) transform<WS, WS, false, true>(sm);
+        if (!(TPIV_F64_SKIP & 2)) transform<WS, WS, true, true>(sm);
 
         // ---- cross-spectrum P = conj(A) B / n^2 of the packed transform; one thread per pair {k, -k}
-        {
+        if (!(TPIV_F64_SKIP & 4)) {
             constexpr double SC = 0.25 / (double)NN;       // 1/4 of the un-packing, 1/n^2 of the inverse (exact)
+            // digit reversal in closed form (two stages: radix R1 = 8, then WS / 8): bin <-> position are digit
+            // swaps, so the partner cell needs no table look-up (four dependent LDS reads per element before)
+            constexpr int R1 = WS >= 8 ? 8 : WS, R2 = WS / R1;
+            auto bin_of = [](int p_) { return (p_ % R2) * R1 + p_ / R2; };
+            auto pos_of_ = [](int k_) { return (k_ % R1) * R2 + k_ / R1; };
             for (int e = tid; e < NN; e += NT) {
                 const int py = e / WS, px = e % WS;
-                const int ky = sm.bin[py], kx = sm.bin[px];
-                const int qy = sm.pos[(WS - ky) % WS], qx = sm.pos[(WS - kx) % WS];
+                const int ky = bin_of(py), kx = bin_of(px);
+                const int qy = pos_of_((WS - ky) % WS), qx = pos_of_((WS - kx) % WS);
                 const int e2 = qy * WS + qx;
                 if (e2 < e) continue;                      // the partner's thread writes both cells
                 const int a1 = py * P + px, a2 = qy * P + qx;
@@ -301,12 +326,12 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
                 sm.z[a1] = cd{pr, pi};
                 if (e2 != e) sm.z[a2] = cd{pr, -pi};       // P(-k) = conj P(k)
             }
-            __syncthreads();
+            lds_barrier();
         }
 
         // ---- inverse 2-D transform: natural order out; the map is the real plane
-        transform<WS, WS, true, false>(sm);
-        transform<WS, WS, false, false>(sm);
+        if (!(TPIV_F64_SKIP & 2)) transform<WS, WS, true, false>(sm);
+        if (!(TPIV_F64_SKIP & 1)) transform<WS, WS, false, false>(sm);
 
         // ---- peak analysis in fftshift coordinates (y' = (y + WS/2) % WS, x' likewise), float64.
         //      A thread's cells (e = tid + k NT) stay in registers through the three scans: one read of the
@@ -341,6 +366,7 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
         const double gmax = wg_reduce<G::NW>(bv, [](double a, double b) { return a > b ? a : b; }, sm.redd + 8);
         auto imin = [](int a, int b) { return a < b ? a : b; };
         const int m = wg_reduce<G::NW>(bv == gmax ? bf : NN, imin, sm.redi);           // first flat index (B:383)
+        // (two cheap VALU reductions; a fused (value, index) key would need a three-dword exchange per step)
         // (the reductions above also order the map writes before the neighbour reads below)
         const int wv = p.val_win;
         const int my = m / WS, mx = m % WS;
@@ -384,7 +410,7 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
             outv = (tid == 7) ? (dead ? 1.0 : 0.0) : outv;
             reinterpret_cast<double*>(p.peak_raw)[fidx * 8 + tid] = outv;
         }
-        __syncthreads();                                   // planes free for the next window
+        lds_barrier();                                   // planes free for the next window
     }
 }
 
