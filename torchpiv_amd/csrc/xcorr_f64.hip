@@ -50,6 +50,16 @@ constexpr int pos_of(int k, int n) {
     return (k % r) * (n / r) + pos_of(k / r, n / r);
 }
 
+// the closed form the cross-spectrum uses: two stages (radix R1 = min(8, n), then n / R1) make the digit
+// reversal a swap of two digits
+constexpr bool digit_swap_ok(int n) {
+    const int r1 = n >= 8 ? 8 : n, r2 = n / r1;
+    for (int k = 0; k < n; ++k)
+        if (pos_of(k, n) != (k % r1) * r2 + k / r1) return false;
+    return true;
+}
+static_assert(digit_swap_ok(8) && digit_swap_ok(16) && digit_swap_ok(32) && digit_swap_ok(64), "digit reversal closed form");
+
 template <int WS>
 struct F64Geo {
     // threads per workgroup (one window).  64x64: 512, i.e. 16 wavefronts per CU with the two workgroups the
@@ -64,8 +74,6 @@ template <int WS>
 struct F64Shared {
     cd z[WS * (WS + 1)];              // the packed tile a/mean(a) + i b/mean(b): 16-byte elements (ds_*_b128)
     cd tw[WS];                        // exp(-2 pi i k / WS)
-    int pos[WS];                      // bin -> position
-    int bin[WS];                      // position -> bin
     double redd[16];
     int redi[8];
     unsigned long long redu[8];
@@ -219,9 +227,6 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
         double s, c;
         sincospi(2.0 * (double)k / (double)WS, &s, &c);
         sm.tw[k] = cd{c, -s};
-        const int q = pos_of(k, WS);            // (evaluated at run time: small recursion, once per workgroup)
-        sm.pos[k] = q;
-        sm.bin[q] = k;
     }
     lds_barrier();
 
@@ -296,15 +301,12 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
         lds_barrier();
         if (item + per_xcd < hi) fetch(item + per_xcd);      // in flight during the transforms
 
-#ifndef TPIV_F64_SKIP
-#define TPIV_F64_SKIP 0
-#endif
         // ---- forward 2-D transform of a + i b, in place: bin (ky, kx) ends at [pos(ky)][pos(kx)]
-        if (!(TPIV_F64_SKIP & 1)) transform<WS, WS, false, true>(sm);
-        if (!(TPIV_F64_SKIP & 2)) transform<WS, WS, true, true>(sm);
+        transform<WS, WS, false, true>(sm);
+        transform<WS, WS, true, true>(sm);
 
         // ---- cross-spectrum P = conj(A) B / n^2 of the packed transform; one thread per pair {k, -k}
-        if (!(TPIV_F64_SKIP & 4)) {
+        {
             constexpr double SC = 0.25 / (double)NN;       // 1/4 of the un-packing, 1/n^2 of the inverse (exact)
             // digit reversal in closed form (two stages: radix R1 = 8, then WS / 8): bin <-> position are digit
             // swaps, so the partner cell needs no table look-up (four dependent LDS reads per element before)
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
         }
 
         // ---- inverse 2-D transform: natural order out; the map is the real plane
-        if (!(TPIV_F64_SKIP & 2)) transform<WS, WS, true, false>(sm);
-        if (!(TPIV_F64_SKIP & 1)) transform<WS, WS, false, false>(sm);
+        transform<WS, WS, true, false>(sm);
+        transform<WS, WS, false, false>(sm);
 
         // ---- peak analysis in fftshift coordinates (y' = (y + WS/2) % WS, x' likewise), float64.
         //      A thread's cells (e = tid + k NT) stay in registers through the three scans: one read of the
