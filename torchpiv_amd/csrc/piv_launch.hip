@@ -3,12 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "piv_kernels.h"
 
 namespace tpiv {
 
 hipError_t launch_xcorr_ws8(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+hipError_t launch_xcorr_w8(const PassParams& p, int mode, int n_cu, hipStream_t stream);       // xcorr_w8.hip: one window per lane
 hipError_t launch_xcorr_ws16(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws32(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws64(const PassParams& p, int mode, int n_cu, hipStream_t stream);
@@ -142,6 +144,8 @@ const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int le
     if (precision && mode == MODE_PASS1) {
         if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_kernel<%d>", ws);
         else snprintf(buf, len, "xcorr_generic_kernel<0, double>");
+    } else if (ws == 8) {
+        snprintf(buf, len, "xcorr_w8_kernel<%d, %s>", mode, (precision && mode != MODE_PASS1) ? "false" : "true");
     } else if (tile_size(ws)) {
         snprintf(buf, len, "xcorr_tile_kernel<%d, %d, %d, %s>", ws, mode, tile_occ(ws, mode),
                  (precision && mode != MODE_PASS1) ? "false" : "true");
@@ -176,8 +180,13 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
                                                  work_ctr_offset(p.batch, p.n_rows * p.n_cols));
         e = hipMemsetAsync(p.work_ctr, 0, WORK_CTR_BYTES, stream);
         if (e != hipSuccess) return e;
+        // 8x8: one window per lane (xcorr_w8.hip); TPIV_W8=0 selects the lane-per-row tile kernel for A/B runs
+        static const bool w8 = [] {
+            const char* env = getenv("TPIV_W8");
+            return !(env && env[0] == '0');
+        }();
         switch (p.ws) {
-            case 8: e = launch_xcorr_ws8(p, mode, n_cu, stream); break;
+            case 8: e = w8 ? launch_xcorr_w8(p, mode, n_cu, stream) : launch_xcorr_ws8(p, mode, n_cu, stream); break;
             case 16: e = launch_xcorr_ws16(p, mode, n_cu, stream); break;
             case 32: e = launch_xcorr_ws32(p, mode, n_cu, stream); break;
             default: e = launch_xcorr_ws64(p, mode, n_cu, stream); break;
