@@ -23,57 +23,51 @@ constexpr int W8 = 8;
 template <int K>
 inline constexpr int P8 = fft_pos(K, 8);
 
-__device__ __forceinline__ float byte_of(const uint32_t (&d)[3], int k) {      // k compile-time after unrolling
-    return (float)((d[k >> 2] >> (8 * (k & 3))) & 0xffu);
-}
-
 // one frame of the CWS patch: rows py .. py+8, columns px .. px+8 of frame f (all inside the frame), resampled
-// with the reference's float32 weights (B:162-193).  sgn = -1 for frame a, +1 for frame b.
+// with the reference's float32 weights (B:162-193).  IS_B: frame b (imaginary parts).  All indices are
+// compile-time constants (static_for): the patch and the samples stay in registers.
 template <bool FAST, bool IS_B>
 __device__ __forceinline__ void stage_cws_fast(const uint8_t* __restrict__ f, int W, int q0, int gx, int gy, float vx,
                                                float vy, cf (&x)[8][8]) {
 #pragma clang fp contract(off)
+    uint32_t rows[9][3];
+    static_for<0, 9>([&](auto rc) TPIV_LAMBDA_INLINE {
+        constexpr int r = decltype(rc)::value;
+        load_dwords<3>(f + q0 + r * W, rows[r]);
+    });
     float wxu[8], wxd[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    static_for<0, 8>([&](auto kc) TPIV_LAMBDA_INLINE {
+        constexpr int k = decltype(kc)::value;
         const float nx = (float)(gx + k) + vx;
         wxu[k] = ceilf(nx) - nx;
         wxd[k] = nx - floorf(nx);
-    }
-    uint32_t rowA[3], rowB[3];
-    __builtin_memcpy(&rowA[0], f + q0, 12);
+    });
     float h0[8], h1[8];          // FAST: x-lerped rows r and r + 1
     if constexpr (FAST) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) h0[k] = __builtin_fmaf(byte_of(rowA, k + 1), wxd[k], byte_of(rowA, k) * wxu[k]);
+        static_for<0, 8>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            h0[k] = __builtin_fmaf(byte_f<k + 1, 3>(rows[0]), wxd[k], byte_f<k, 3>(rows[0]) * wxu[k]);
+        });
     }
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        __builtin_memcpy(&rowB[0], f + q0 + (r + 1) * W, 12);
+    static_for<0, 8>([&](auto rc) TPIV_LAMBDA_INLINE {
+        constexpr int r = decltype(rc)::value;
         const float ny = (float)(gy + r) + vy;
         const float wyu = ceilf(ny) - ny, wyd = ny - floorf(ny);
-        if constexpr (FAST) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                h1[k] = __builtin_fmaf(byte_of(rowB, k + 1), wxd[k], byte_of(rowB, k) * wxu[k]);
-                const float v = __builtin_fmaf(h1[k], wyd, h0[k] * wyu);
-                if constexpr (IS_B) x[r][k].y = v;
-                else x[r][k].x = v;
+        static_for<0, 8>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            float v;
+            if constexpr (FAST) {
+                h1[k] = __builtin_fmaf(byte_f<k + 1, 3>(rows[r + 1]), wxd[k], byte_f<k, 3>(rows[r + 1]) * wxu[k]);
+                v = __builtin_fmaf(h1[k], wyd, h0[k] * wyu);
                 h0[k] = h1[k];
+            } else {
+                v = bilerp_ref(byte_f<k, 3>(rows[r]), byte_f<k + 1, 3>(rows[r]), byte_f<k, 3>(rows[r + 1]),
+                               byte_f<k + 1, 3>(rows[r + 1]), wxu[k], wxd[k], wyu, wyd, false);
             }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = bilerp_ref(byte_of(rowA, k), byte_of(rowA, k + 1), byte_of(rowB, k), byte_of(rowB, k + 1),
-                                           wxu[k], wxd[k], wyu, wyd, false);
-                if constexpr (IS_B) x[r][k].y = v;
-                else x[r][k].x = v;
-            }
-        }
-        rowA[0] = rowB[0];
-        rowA[1] = rowB[1];
-        rowA[2] = rowB[2];
-    }
+            if constexpr (IS_B) x[r][k].y = v;
+            else x[r][k].x = v;
+        });
+    });
 }
 
 // the per-pixel form of the tile kernel's slow path, for one frame: values go to LDS ([pixel][lane]) in a rolled
@@ -135,17 +129,17 @@ __global__ __launch_bounds__(64, 2) void xcorr_w8_kernel(PassParams p) {
         cf x[8][8];
         // ---------------- staging
         if constexpr (MODE == MODE_PASS1) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            static_for<0, 8>([&](auto rc) TPIV_LAMBDA_INLINE {
+                constexpr int r = decltype(rc)::value;
                 uint32_t da[2], db[2];
-                __builtin_memcpy(&da[0], fa + base + r * p.W, 8);
-                __builtin_memcpy(&db[0], fb + base + r * p.W, 8);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    x[r][k].x = (float)((da[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                    x[r][k].y = (float)((db[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                }
-            }
+                load_dwords<2>(fa + base + r * p.W, da);
+                load_dwords<2>(fb + base + r * p.W, db);
+                static_for<0, 8>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    x[r][k].x = byte_f<k, 2>(da);
+                    x[r][k].y = byte_f<k, 2>(db);
+                });
+            });
         } else if constexpr (MODE == MODE_DWS) {
             // integer shift on the FLAT index (B:213-215): a at idx - (vy W + vx), b at idx + (...), clamped per pixel
             const long long sh = (long long)p.v2[fidx] * p.W + (long long)p.u2[fidx];
@@ -153,42 +147,51 @@ __global__ __launch_bounds__(64, 2) void xcorr_w8_kernel(PassParams p) {
             const long long last = (long long)7 * p.W + 7;
             const bool fast = qa >= 0 && qb >= 0 && qa + last <= (long long)HW - 1 && qb + last <= (long long)HW - 1;
             if (__all(fast)) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
+                static_for<0, 8>([&](auto rc) TPIV_LAMBDA_INLINE {
+                    constexpr int r = decltype(rc)::value;
                     uint32_t da[2], db[2];
-                    __builtin_memcpy(&da[0], fa + qa + r * p.W, 8);
-                    __builtin_memcpy(&db[0], fb + qb + r * p.W, 8);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        x[r][k].x = (float)((da[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                        x[r][k].y = (float)((db[k >> 2] >> (8 * (k & 3))) & 0xffu);
-                    }
-                }
+                    load_dwords<2>(fa + qa + r * p.W, da);
+                    load_dwords<2>(fb + qb + r * p.W, db);
+                    static_for<0, 8>([&](auto kc) TPIV_LAMBDA_INLINE {
+                        constexpr int k = decltype(kc)::value;
+                        x[r][k].x = byte_f<k, 2>(da);
+                        x[r][k].y = byte_f<k, 2>(db);
+                    });
+                });
             } else {
                 stage_slow<MODE_DWS, false>(p, fa, x0, y0, 0.f, 0.f, -sh, lds, lane, x);
                 stage_slow<MODE_DWS, true>(p, fb, x0, y0, 0.f, 0.f, sh, lds, lane, x);
             }
         } else {
             const float vx = (float)p.u2[fidx], vy = (float)p.v2[fidx];          // the float32 cast of B:714-715
-            // Fast path: floor(float(g) + v) == g + floor(v) for every column and row of the window (true unless
-            // frac(v) is within float32 rounding of an integer -- which also keeps the "integral coordinate =>
-            // nearest sample" quirk, B:170/193, out of it) and both 9 x 9 source patches lie inside the frame with
-            // room for the 12-byte row loads.
+            // Fast path: floor(float(g) + v) == g + floor(v) and no exactly integral coordinate (the "nearest
+            // sample" quirk, B:170/193) for every column and row of the window -- checked coordinate by coordinate
+            // with the reference's own float32 sums (a threshold on frac(v) wide enough for float32 rounding at
+            // W = 4096 would send 0.8 % of the windows, i.e. 40 % of the 64-window wavefronts, down the per-pixel
+            // path) -- and both 9 x 9 source patches inside the frame with room for the 12-byte row loads.
             const float fvx = floorf(vx), fvy = floorf(vy);
-            const float frx = vx - fvx, fry = vy - fvy;
-            const float thr_x = (float)(p.W + 64) * 4.76837158e-07f, thr_y = (float)(p.H + 64) * 4.76837158e-07f;
             const int ivx = f2i_sat_t(fminf(fmaxf(fvx, -(float)p.W), (float)p.W));
             const int ivy = f2i_sat_t(fminf(fmaxf(fvy, -(float)p.H), (float)p.H));
+            bool coords_ok = true;
+            static_for<0, 8>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                // frame a samples at g - v (floor = g - floor(v) - 1), frame b at g + v (floor = g + floor(v))
+                const float xa = (float)(x0 + k) - vx, xb = (float)(x0 + k) + vx;
+                const float ya = (float)(y0 + k) - vy, yb = (float)(y0 + k) + vy;
+                const float fxa = floorf(xa), fxb = floorf(xb), fya = floorf(ya), fyb = floorf(yb);
+                coords_ok = coords_ok && fxa == (float)(x0 + k - ivx - 1) && fxb == (float)(x0 + k + ivx) &&
+                            fya == (float)(y0 + k - ivy - 1) && fyb == (float)(y0 + k + ivy) && fxa != xa && fxb != xb &&
+                            fya != ya && fyb != yb;
+            });
             // frame a uses -v: floor(-v) = -floor(v) - 1 when frac != 0
             const long long qa0 = (long long)(y0 - ivy - 1) * p.W + (x0 - ivx - 1);
             const long long qb0 = (long long)(y0 + ivy) * p.W + (x0 + ivx);
             const long long lastb = (long long)8 * p.W + 12;
-            const bool fast = frx > thr_x && frx < 1.0f - thr_x && fry > thr_y && fry < 1.0f - thr_y &&
-                              fabsf(vx) < (float)p.W && fabsf(vy) < (float)p.H && qa0 >= 0 && qb0 >= 0 &&
+            const bool fast = coords_ok && fabsf(vx) < (float)p.W && fabsf(vy) < (float)p.H && qa0 >= 0 && qb0 >= 0 &&
                               qa0 + lastb <= (long long)HW && qb0 + lastb <= (long long)HW;
             // (a patch that crosses a row end wraps into the neighbouring image row exactly as the reference's
             //  flat index does, B:177-180: only the two ends of the frame need the clamp of the slow path)
-            if (__all(fast || !active)) {
+            if (__all(fast)) {           // (idle lanes repeat the last window: same verdict as its own lane)
                 stage_cws_fast<FAST, false>(fa, p.W, (int)qa0, x0, y0, -vx, -vy, x);
                 stage_cws_fast<FAST, true>(fb, p.W, (int)qb0, x0, y0, vx, vy, x);
             } else {
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_w8_kernel(PassParams p) {
             c2r_inreg<8>(Y, h);
             static_for<0, 8>([&](auto xc) TPIV_LAMBDA_INLINE {
                 constexpr int xx = decltype(xc)::value;
-                c[y][xx] = (xx & 1) ? h[fft_pos(xx / 2, 4)].y : h[fft_pos(xx / 2, 4)].x;
+                c[y][xx] = (xx & 1) ? h[FFT_POS<xx / 2, 4>].y : h[FFT_POS<xx / 2, 4>].x;
             });
         });
 
