@@ -546,12 +546,13 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
     } else {
         constexpr int NB = WS / 4 + 1;
         const CwsRow c = cws_row(g.y0 + r, vy);
-        // Fast path: floor(float(gx) + vx) == gx + floor(vx) for every column (true unless
-        // frac(vx) is within float32 rounding of an integer) and all four source rows lie
-        // inside the frame, so that a row is WS+1 consecutive bytes.
+        // Fast path: floor(float(gx) + vx) == gx + floor(vx) for every column, no column exactly integral
+        // (the "nearest sample" quirk, B:170/193), and all four source rows inside the frame, so that a row is
+        // WS+1 consecutive bytes.  The column condition is checked exactly, with the reference's own float32
+        // sums: lane r tests column r of its window (the WS lanes of a window cover its WS columns) -- a
+        // threshold on frac(vx) wide enough for float32 rounding at W = 4096 sent 0.4 % of the windows, i.e.
+        // 1.6 % of the 16x16 wavefronts, down the 4.6x slower per-pixel path.
         const float fvx = floorf(vx);
-        const float frac = vx - fvx;
-        const float thr = (float)(p.W + 64) * 4.76837158e-07f;       // (W + 64) * 2^-21
         // 32-bit flat indices: |floor(vx)| <= W on the fast path, and a source row further than 8
         // rows outside the frame classifies exactly like row -8 / H+7 (the whole run stays before
         // pixel 0 / behind the last pixel), so the clamped values give the same class and address.
@@ -569,7 +570,12 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         const int c2 = classify_row32(qb0, WS + 1, 4 * NB, HW, lb0), c3 = classify_row32(qb1, WS + 1, 4 * NB, HW, lb1);
         // (FAST: an integral row coordinate -- B:170, B:193 return the nearest sample -- is left to the
         //  per-pixel path, which implements the quirk; the lerp form of convert_rows does not)
-        const bool reg = c0 != 3 && c1 != 3 && c2 != 3 && c3 != 3 && frac > thr && frac < 1.0f - thr &&
+        const float gxr = (float)(g.x0 + r);
+        const float nxa_r = gxr - vx, nxb_r = gxr + vx;
+        const float fxa_r = floorf(nxa_r), fxb_r = floorf(nxb_r);
+        const bool col_ok = fxa_r == (float)(g.x0 + r - ivx - 1) && fxb_r == (float)(g.x0 + r + ivx) &&
+                            fxa_r != nxa_r && fxb_r != nxb_r;
+        const bool reg = c0 != 3 && c1 != 3 && c2 != 3 && c3 != 3 && col_ok &&
                          fabsf(vx) < (float)p.W && !(FAST && (c.ydeg_a | c.ydeg_b));
         raw.reg = __all(reg) ? 1 : 0;
         raw.cls = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
