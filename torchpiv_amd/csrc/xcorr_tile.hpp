@@ -678,7 +678,9 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
             // them in LDS; every lane then reads the WS columns back (broadcast reads).
             // In the fast path frac(vx) is away from 0/1, so ceil = floor + 1 and the column is
             // never "integral" (only the row can be, ydeg_*).
-            float4* wbuf = reinterpret_cast<float4*>(lds) + (lane / WS) * WS;
+            // (one spare float4 per window: without it the 64 / WS windows' tables start a multiple of 256 bytes
+            //  apart and their broadcast reads hit the same banks -- a 4-way conflict on every read for 16x16)
+            float4* wbuf = reinterpret_cast<float4*>(lds) + (lane / WS) * (WS + 1);
             {
                 const float gxf = gx0f + (float)r;               // exact: small integers
                 const float nxa = gxf - vx, nxb = gxf + vx;
