@@ -217,8 +217,8 @@ int tpiv_debug_pass(int mode, int precision, const uint8_t* a_dev, const uint8_t
 /* Peak analysis alone -- correlation_to_displacement (B:360-422) + peak2peak_secondpeak
  * (B:346-358) -- on caller-supplied correlation maps [n_maps, ws, ws] float32 in fftshift layout
  * (ws = 8, 16, 32, 64 or 128): runs the kernels' peak stage and finalize on them.  planar != 0
- * selects the LDS layout of the three-wavefront tile kernels (64x64: the three-row map); ignored
- * for ws = 128.  The kernel subtracts the map minimum first (B:518), so feed maps whose minimum is
+ * selects the LDS layout of the three-wavefront tile kernels (64x64: the three-row map); planar = 2 with
+ * ws = 8 the peak stage of the one-window-per-lane kernel; ignored for ws = 128.  The kernel subtracts the map minimum first (B:518), so feed maps whose minimum is
  * 0 to compare with the reference function.  work_dev: n_maps * 32 bytes. */
 int tpiv_debug_peaks(const float* maps_dev, int n_maps, int ws, int planar, double val_ratio, int val_win,
                      double* u_dev, double* v_dev, uint8_t* invalid_dev,

@@ -478,7 +478,7 @@ def test_generic_sizes_multipass(eng, golden, mode):
                           noise_ulps=16.0 if precision == "reference" else 4096.0)
 
 
-@pytest.mark.parametrize("ws,planar", [(8, False), (8, True), (16, False), (16, True), (32, False), (32, True),
+@pytest.mark.parametrize("ws,planar", [(8, False), (8, True), (8, 2), (16, False), (16, True), (32, False), (32, True),
                                        (64, False), (64, True), (128, False)])
 def test_peak_logic_on_handmade_maps(eng, golden, ws, planar):
     """correlation_to_displacement + peak2peak_secondpeak on crafted maps: every one-sided fix-up
@@ -486,7 +486,8 @@ def test_peak_logic_on_handmade_maps(eng, golden, ws, planar):
     of the second-peak exclusion zone, ties, constant maps -- compared with the oracle, which the CPU
     suite pins to the reference on the same tables (tests/golden/g6_kats.npz).  Every peak stage is
     covered: the tile kernel's whole-map form, its planar form (64x64: the three-row map of the
-    three-wavefront kernels) and the 128x128 stage of xcorr_big.hpp."""
+    three-wavefront kernels), the one-window-per-lane 8x8 kernel (planar = 2) and the 128x128 stage of
+    xcorr_big.hpp."""
     g = golden("g6_kats")
     rng = np.random.default_rng(100 + ws)
     maps = []

@@ -11,6 +11,7 @@ namespace tpiv {
 
 hipError_t launch_xcorr_ws8(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_w8(const PassParams& p, int mode, int n_cu, hipStream_t stream);       // xcorr_w8.hip: one window per lane
+hipError_t launch_peak_debug_w8(const PassParams& p, const float* maps, int n_maps, hipStream_t stream);
 hipError_t launch_xcorr_ws16(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws32(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_ws64(const PassParams& p, int mode, int n_cu, hipStream_t stream);
@@ -112,7 +113,9 @@ static size_t peak_bytes(int batch, int n_windows, int precision = 0) {
 hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream) {
     hipError_t e;
     switch (p.ws) {
-        case 8: e = launch_peak_debug_ws8(p, maps, n_maps, planar, stream); break;
+        case 8:          // planar == 2: the one-window-per-lane kernel's peak stage (xcorr_w8.hip)
+            e = planar == 2 ? launch_peak_debug_w8(p, maps, n_maps, stream) : launch_peak_debug_ws8(p, maps, n_maps, planar, stream);
+            break;
         case 16: e = launch_peak_debug_ws16(p, maps, n_maps, planar, stream); break;
         case 32: e = launch_peak_debug_ws32(p, maps, n_maps, planar, stream); break;
         case 64: e = launch_peak_debug_ws64(p, maps, n_maps, planar, stream); break;

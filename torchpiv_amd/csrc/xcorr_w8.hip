@@ -98,6 +98,85 @@ __device__ __forceinline__ void stage_slow(const PassParams& p, const uint8_t* _
     });
 }
 
+// ---- peak analysis of one window per lane (B:346-358, 381-392, 518): c[y][x] in un-shifted coordinates.
+// SCALED: the constant factor of the map is applied here (see xcorr_tile.hpp peak_analysis).
+template <bool FASTN>
+__device__ __forceinline__ void w8_peak(const PassParams& p, const float (&c)[8][8], float* lds, int lane, bool active,
+                                        bool dead, size_t fidx, float end_scale) {
+    // ---------------- peak analysis in fftshift coordinates: flat index f = y' * 8 + x', y' = (y + 4) % 8
+    float cmin = 3.4e38f, raw_max = -3.4e38f;
+    static_for<0, 64>([&](auto ic) TPIV_LAMBDA_INLINE {
+        constexpr int i = decltype(ic)::value;
+        cmin = fminf(cmin, c[i >> 3][i & 7]);
+        raw_max = fmaxf(raw_max, c[i >> 3][i & 7]);
+    });
+    const float ncs = -(cmin * end_scale);
+    auto shifted = [&](float v_) TPIV_LAMBDA_INLINE {            // B:518 corr - min; B:381 corr += eps
+        if constexpr (FASTN) return __fadd_rn(fmaf(v_, end_scale, ncs), 1e-7f);
+        else return __fadd_rn(__fsub_rn(v_, cmin), 1e-7f);
+    };
+    const float gmax = shifted(raw_max);                       // (monotonic: the maximum of the shifted map)
+    float v[64];                                               // v[f], shifted flat order
+    static_for<0, 64>([&](auto fc) TPIV_LAMBDA_INLINE {
+        constexpr int f = decltype(fc)::value;
+        constexpr int y = ((f >> 3) + 4) % 8, xx = ((f & 7) + 4) % 8;
+        v[f] = shifted(c[y][xx]);
+        lds[f * 64 + lane] = v[f];
+    });
+    // arg-max = FIRST flat index holding the maximum (B:383)
+    int m = 63;
+    static_for<0, 64>([&](auto fc) TPIV_LAMBDA_INLINE {
+        constexpr int f = 63 - decltype(fc)::value;
+        m = (v[f] == gmax) ? f : m;
+    });
+    // second peak: maximum outside {clamp(m + i + 8 j), |i|, |j| <= wv} (B:346-358); mask of the flat indices
+    const int wv = p.val_win;
+    unsigned long long ex = 0ull;
+    {
+        const unsigned long long run = (2 * wv + 1) >= 64 ? ~0ull : ((1ull << (2 * wv + 1)) - 1ull);
+        for (int j = -wv; j <= wv; ++j) {
+            const int s = m - wv + 8 * j;                      // first index of this run
+            if (s >= 64 || s + 2 * wv < 0) continue;
+            ex |= s >= 0 ? (run << s) : (run >> (-s));
+        }
+        if (m - wv - 8 * wv <= 0) ex |= 1ull;                  // clamp to 0
+        if (m + wv + 8 * wv >= 63) ex |= 1ull << 63;           // clamp to k*d - 1
+    }
+    const int exl = (int)(unsigned)ex, exh = (int)(unsigned)(ex >> 32);
+    int smax = 0;                                              // float bits; positive floats order like ints
+    static_for<0, 64>([&](auto fc) TPIV_LAMBDA_INLINE {
+        constexpr int f = decltype(fc)::value;
+        const int kill = __builtin_amdgcn_sbfe(f < 32 ? exl : exh, f & 31, 1);
+        const int cand = __float_as_int(v[f]) | kill;
+        smax = cand > smax ? cand : smax;
+    });
+    const float second_v = smax > 0 ? __int_as_float(smax) : gmax;
+    // the five values of the fit (flat-index neighbours and fix-ups of B:385-392) from the parked map
+    int left = m + 1, right = m - 1, top = m + 8, bot = m - 8;
+    if (left >= 63) left = m;
+    if (right <= 0) right = m;
+    if (top >= 63) top = m;
+    if (bot <= 0) bot = m;
+    if (active) {
+        float4 r0, r1;
+        r0.x = gmax;
+        r0.y = lds[left * 64 + lane];
+        r0.z = lds[right * 64 + lane];
+        r0.w = lds[top * 64 + lane];
+        r1.x = lds[bot * 64 + lane];
+        r1.y = second_v;
+        r1.z = __int_as_float(m);
+        r1.w = __int_as_float(dead ? 1 : 0);
+        float4* out = reinterpret_cast<float4*>(p.peak_raw + fidx * 8);
+        out[0] = r0;
+        out[1] = r1;
+        if (p.dbg_corr != nullptr) {
+            float* d = p.dbg_corr + fidx * 64;
+            static_for<0, 64>([&](auto fc) TPIV_LAMBDA_INLINE { d[decltype(fc)::value] = v[decltype(fc)::value]; });
+        }
+    }
+}
+
 template <int MODE, bool FAST>
 __global__ __launch_bounds__(64, 2) void xcorr_w8_kernel(PassParams p) {
     __shared__ float lds[64 * 64];
@@ -293,79 +372,23 @@ __global__ __launch_bounds__(64, 2) void xcorr_w8_kernel(PassParams p) {
             });
         });
 
-        // ---------------- peak analysis in fftshift coordinates: flat index f = y' * 8 + x', y' = (y + 4) % 8
-        float cmin = 3.4e38f, raw_max = -3.4e38f;
-        static_for<0, 64>([&](auto ic) TPIV_LAMBDA_INLINE {
-            constexpr int i = decltype(ic)::value;
-            cmin = fminf(cmin, c[i >> 3][i & 7]);
-            raw_max = fmaxf(raw_max, c[i >> 3][i & 7]);
-        });
-        const float ncs = -(cmin * end_scale);
-        auto shifted = [&](float v_) TPIV_LAMBDA_INLINE {            // B:518 corr - min; B:381 corr += eps
-            if constexpr (FASTN) return __fadd_rn(fmaf(v_, end_scale, ncs), 1e-7f);
-            else return __fadd_rn(__fsub_rn(v_, cmin), 1e-7f);
-        };
-        const float gmax = shifted(raw_max);                       // (monotonic: the maximum of the shifted map)
-        float v[64];                                               // v[f], shifted flat order
-        static_for<0, 64>([&](auto fc) TPIV_LAMBDA_INLINE {
-            constexpr int f = decltype(fc)::value;
-            constexpr int y = ((f >> 3) + 4) % 8, xx = ((f & 7) + 4) % 8;
-            v[f] = shifted(c[y][xx]);
-            lds[f * 64 + lane] = v[f];
-        });
-        // arg-max = FIRST flat index holding the maximum (B:383)
-        int m = 63;
-        static_for<0, 64>([&](auto fc) TPIV_LAMBDA_INLINE {
-            constexpr int f = 63 - decltype(fc)::value;
-            m = (v[f] == gmax) ? f : m;
-        });
-        // second peak: maximum outside {clamp(m + i + 8 j), |i|, |j| <= wv} (B:346-358); mask of the flat indices
-        const int wv = p.val_win;
-        unsigned long long ex = 0ull;
-        {
-            const unsigned long long run = (2 * wv + 1) >= 64 ? ~0ull : ((1ull << (2 * wv + 1)) - 1ull);
-            for (int j = -wv; j <= wv; ++j) {
-                const int s = m - wv + 8 * j;                      // first index of this run
-                if (s >= 64 || s + 2 * wv < 0) continue;
-                ex |= s >= 0 ? (run << s) : (run >> (-s));
-            }
-            if (m - wv - 8 * wv <= 0) ex |= 1ull;                  // clamp to 0
-            if (m + wv + 8 * wv >= 63) ex |= 1ull << 63;           // clamp to k*d - 1
-        }
-        const int exl = (int)(unsigned)ex, exh = (int)(unsigned)(ex >> 32);
-        int smax = 0;                                              // float bits; positive floats order like ints
-        static_for<0, 64>([&](auto fc) TPIV_LAMBDA_INLINE {
-            constexpr int f = decltype(fc)::value;
-            const int kill = __builtin_amdgcn_sbfe(f < 32 ? exl : exh, f & 31, 1);
-            const int cand = __float_as_int(v[f]) | kill;
-            smax = cand > smax ? cand : smax;
-        });
-        const float second_v = smax > 0 ? __int_as_float(smax) : gmax;
-        // the five values of the fit (flat-index neighbours and fix-ups of B:385-392) from the parked map
-        int left = m + 1, right = m - 1, top = m + 8, bot = m - 8;
-        if (left >= 63) left = m;
-        if (right <= 0) right = m;
-        if (top >= 63) top = m;
-        if (bot <= 0) bot = m;
-        if (active) {
-            float4 r0, r1;
-            r0.x = gmax;
-            r0.y = lds[left * 64 + lane];
-            r0.z = lds[right * 64 + lane];
-            r0.w = lds[top * 64 + lane];
-            r1.x = lds[bot * 64 + lane];
-            r1.y = second_v;
-            r1.z = __int_as_float(m);
-            r1.w = __int_as_float(dead ? 1 : 0);
-            float4* out = reinterpret_cast<float4*>(p.peak_raw + fidx * 8);
-            out[0] = r0;
-            out[1] = r1;
-            if (p.dbg_corr != nullptr) {
-                float* d = p.dbg_corr + fidx * 64;
-                static_for<0, 64>([&](auto fc) TPIV_LAMBDA_INLINE { d[decltype(fc)::value] = v[decltype(fc)::value]; });
-            }
-        }
+        w8_peak<FASTN>(p, c, lds, lane, active, dead, fidx, end_scale);
     }
+}
+
+// test hook: hand-made maps [n_maps, 8, 8] float32 in fftshift layout through w8_peak (one map per lane)
+__global__ __launch_bounds__(64, 2) void peak_debug_w8_kernel(PassParams p, const float* maps, int n_maps) {
+    __shared__ float lds[64 * 64];
+    const int lane = threadIdx.x;
+    const int win_raw = blockIdx.x * 64 + lane;
+    const bool active = win_raw < n_maps;
+    const int win = active ? win_raw : n_maps - 1;
+    float c[8][8];
+    static_for<0, 64>([&](auto ic) TPIV_LAMBDA_INLINE {
+        constexpr int y = decltype(ic)::value >> 3, xx = decltype(ic)::value & 7;
+        c[y][xx] = maps[(size_t)win * 64 + ((y + 4) % 8) * 8 + (xx + 4) % 8];
+    });
+    w8_peak<false>(p, c, lds, lane, active, false, (size_t)win, 1.0f);
 }
 
 template <int MODE>
@@ -386,6 +409,11 @@ hipError_t launch_w8_mode(const PassParams& p_in, int n_cu, hipStream_t stream) 
 }
 
 }  // namespace
+
+hipError_t launch_peak_debug_w8(const PassParams& p, const float* maps, int n_maps, hipStream_t stream) {
+    hipLaunchKernelGGL(peak_debug_w8_kernel, dim3((n_maps + 63) / 64), dim3(64), 0, stream, p, maps, n_maps);
+    return hipGetLastError();
+}
 
 hipError_t launch_xcorr_w8(const PassParams& p, int mode, int n_cu, hipStream_t stream) {
     switch (mode) {

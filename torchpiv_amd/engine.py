@@ -183,7 +183,7 @@ def debug_peaks(maps: torch.Tensor, val_ratio=1.2, val_win=3, planar=False):
     inv = torch.empty(n, dtype=torch.uint8, device=maps.device)
     work = torch.empty(max(n * 32, 16), dtype=torch.uint8, device=maps.device)
     with torch.cuda.device(maps.device):
-        check(lib.tpiv_debug_peaks(maps.data_ptr(), n, ws, 1 if planar else 0, float(val_ratio), int(val_win),
+        check(lib.tpiv_debug_peaks(maps.data_ptr(), n, ws, int(planar), float(val_ratio), int(val_win),
                                    u.data_ptr(), v.data_ptr(), inv.data_ptr(), work.data_ptr(), n * 32, _stream()))
     return u, v, inv
 
