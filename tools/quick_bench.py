@@ -13,8 +13,10 @@ ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--distinct", type=int, default=2)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--kind", default="wavy")
+ap.add_argument("--width", type=int, default=0, help="frame width when it differs from --size (row-pitch experiments)")
 a = ap.parse_args()
-H = W = a.size
+H = a.size
+W = a.width or a.size
 A0, B0 = synth.make_batch(a.distinct, H, W, device="cuda", kind=a.kind)
 A = A0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
 B = B0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()

@@ -208,9 +208,9 @@ struct tpiv_plan {
     std::vector<uint8_t*> val;
     std::vector<double*> Ay, Ax;         // per pass p >= 1: dense operators from pass p-1 to p (debug)
     // banded form used by tpiv_plan_run (piv_kernels.h: BandedPredictParams)
-    std::vector<double*> Wy, AxT, AxG;
-    std::vector<int*> k0y, startx;
-    std::vector<int> ku, bwx, bwg, seg_len;
+    std::vector<double*> Wy32, Ax32;
+    std::vector<int*> k0y32, k0x32;
+    std::vector<int> KY, KX;
     double *u0 = nullptr, *v0 = nullptr, *u2 = nullptr, *v2 = nullptr, *T = nullptr;
     float* peak_raw = nullptr;           // [max_batch, max N_p, 8] hand-off tile kernel -> finalize
     size_t peak_raw_bytes = 0;
@@ -277,88 +277,52 @@ int upload(tpiv_plan* pl, T** dst, const std::vector<T>& src) {
     return TPIV_OK;
 }
 
+// The two spline operators in the form predict_mfma.hip takes: per block of 32 fine rows / columns a dense
+// K x 32 weight tile over the union of the block's 65-tap bands (zero elsewhere).
 int build_banded(tpiv_plan* pl, int p, int nrc, int ncc, int nrf, int ncf, const std::vector<double>& ay,
                  const std::vector<double>& ax) {
-    // ---- column operator: per fine column a band, stored transposed [bw][ncf]
-    const int bwx = ncc < PRED_BW ? ncc : PRED_BW;
-    std::vector<int> sx(ncf);
-    std::vector<double> axT((size_t)bwx * ncf);
     double leak = 0.0;
-    for (int f = 0; f < ncf; ++f) {
-        const double* row = &ax[(size_t)f * ncc];
-        int st = band_start(row, ncc, bwx);
-        if (f > 0 && st < sx[f - 1]) st = sx[f - 1];           // keep the starts monotone
-        sx[f] = st;
-        for (int j = 0; j < ncc; ++j) {
-            if (j >= st && j < st + bwx) axT[(size_t)(j - st) * ncf + f] = row[j];
-            else if (std::fabs(row[j]) > leak) leak = std::fabs(row[j]);
+    // band starts, monotone in the fine index; `leak` = the largest weight left outside a band
+    auto starts = [&leak](const std::vector<double>& op, int nf, int nc, int bw) {
+        std::vector<int> st(nf);
+        for (int f = 0; f < nf; ++f) {
+            const double* row = &op[(size_t)f * nc];
+            int s = band_start(row, nc, bw);
+            if (f > 0 && s < st[f - 1]) s = st[f - 1];
+            st[f] = s;
+            for (int j = 0; j < nc; ++j)
+                if ((j < s || j >= s + bw) && std::fabs(row[j]) > leak) leak = std::fabs(row[j]);
         }
-    }
-    // the kernel stages startx[last] + bw - startx[first] values of a T1 row per 256 fine columns
-    for (int f0 = 0; f0 < ncf; f0 += 256) {
-        const int f1 = f0 + 255 < ncf ? f0 + 255 : ncf - 1;
-        if (sx[f1] + bwx - sx[f0] > 512) return fail(TPIV_EUNSUPPORTED, "predictor band stretch exceeds the LDS stage");
-    }
-    // group-aligned copy: the 4 fine columns of a group read the SAME staged values (base startx[4g]),
-    // each with its weights shifted by its own start offset (zero-padded): one thread then forms 4
-    // outputs from one LDS read per tap (the per-column form was LDS-bandwidth-bound)
-    const int ncf4 = (ncf + 3) / 4 * 4;
-    int dmax = 0;
-    for (int f = 0; f < ncf; ++f) dmax = std::max(dmax, sx[f] - sx[f / 4 * 4]);
-    if (dmax > 8) return fail(TPIV_EUNSUPPORTED, "predictor column groups span more than 8 coarse columns");
-    const int bwg = bwx + dmax;
-    std::vector<double> axG((size_t)bwg * ncf4, 0.0);
-    for (int f = 0; f < ncf; ++f) {
-        const int d = sx[f] - sx[f / 4 * 4];
-        for (int kk = 0; kk < bwx; ++kk) axG[(size_t)(kk + d) * ncf4 + f] = axT[(size_t)kk * ncf + f];
-    }
-    // ---- row operator: blocks of PRED_RB fine rows over the union of their bands
-    const int RB = tpiv::PRED_RB;
-    const int bwy = nrc < PRED_BW ? nrc : PRED_BW;
-    const int nblk = (nrf + RB - 1) / RB;
-    std::vector<int> sy(nrf);
-    for (int f = 0; f < nrf; ++f) {
-        int st = band_start(&ay[(size_t)f * nrc], nrc, bwy);
-        if (f > 0 && st < sy[f - 1]) st = sy[f - 1];
-        sy[f] = st;
-    }
-    int ku = 0;
-    std::vector<int> k0(nblk);
-    for (int b = 0; b < nblk; ++b) {
-        const int f0 = b * RB, f1 = (f0 + RB - 1 < nrf) ? f0 + RB - 1 : nrf - 1;
-        k0[b] = sy[f0];
-        const int len = sy[f1] + bwy - sy[f0];
-        if (len > ku) ku = len;
-    }
-    if (ku > nrc) ku = nrc;
-    std::vector<double> wy((size_t)nblk * ku * RB, 0.0);
-    for (int b = 0; b < nblk; ++b) {
-        if (k0[b] + ku > nrc) k0[b] = nrc - ku;                 // keep the tile inside the matrix
-        for (int i = 0; i < RB; ++i) {
-            const int f = b * RB + i;
-            if (f >= nrf) break;
-            const double* row = &ay[(size_t)f * nrc];
-            for (int j = 0; j < nrc; ++j) {
-                if (j >= k0[b] && j < k0[b] + ku) wy[((size_t)b * ku + (j - k0[b])) * RB + i] = row[j];
-                else if (std::fabs(row[j]) > leak) leak = std::fabs(row[j]);
-            }
+        return st;
+    };
+    auto tiles32 = [](const std::vector<double>& op, const std::vector<int>& st, int nf, int nc, int bw,
+                      std::vector<double>& tile, std::vector<int>& k0v) {
+        const int nb = (nf + 31) / 32;
+        int K = 0;
+        k0v.resize(nb);
+        for (int b = 0; b < nb; ++b) {
+            const int f1 = std::min(32 * b + 31, nf - 1);
+            k0v[b] = st[32 * b];
+            K = std::max(K, st[f1] + bw - st[32 * b]);
         }
-    }
+        K = (K + 7) / 8 * 8;                                     // the kernels take two K-steps of 4 per trip
+        tile.assign((size_t)nb * K * 32, 0.0);
+        for (int f = 0; f < nf; ++f)
+            for (int j = st[f]; j < st[f] + bw; ++j)
+                tile[((size_t)(f / 32) * K + (j - k0v[f / 32])) * 32 + f % 32] = op[(size_t)f * nc + j];
+        return K;
+    };
+    const int bwy = nrc < PRED_BW ? nrc : PRED_BW, bwx = ncc < PRED_BW ? ncc : PRED_BW;
+    const std::vector<int> sy = starts(ay, nrf, nrc, bwy), sx = starts(ax, ncf, ncc, bwx);
     if (leak > 1e-17) return fail(TPIV_EUNSUPPORTED, "spline operator does not fit the 65-tap band");
-    pl->ku[p] = ku;
-    pl->bwx[p] = bwx;
-    pl->bwg[p] = bwg;
-    int seg_len = 0;
-    for (int f0 = 0; f0 < ncf; f0 += 256) {
-        const int f1 = f0 + 255 < ncf ? f0 + 255 : ncf - 1;
-        seg_len = std::max(seg_len, sx[f1] + bwx - sx[f0] + dmax + 8);
-    }
-    pl->seg_len[p] = (seg_len + 1) / 2 * 2;
-    int rc = upload(pl, &pl->Wy[p], wy);
-    if (!rc) rc = upload(pl, &pl->AxT[p], axT);
-    if (!rc) rc = upload(pl, &pl->AxG[p], axG);
-    if (!rc) rc = upload(pl, &pl->k0y[p], k0);
-    if (!rc) rc = upload(pl, &pl->startx[p], sx);
+    std::vector<double> wy32, ax32;
+    std::vector<int> k0y32, k0x32;
+    pl->KY[p] = tiles32(ay, sy, nrf, nrc, bwy, wy32, k0y32);
+    pl->KX[p] = tiles32(ax, sx, ncf, ncc, bwx, ax32, k0x32);
+    int rc = upload(pl, &pl->Wy32[p], wy32);
+    if (!rc) rc = upload(pl, &pl->Ax32[p], ax32);
+    if (!rc) rc = upload(pl, &pl->k0y32[p], k0y32);
+    if (!rc) rc = upload(pl, &pl->k0x32[p], k0x32);
     return rc;
 }
 
@@ -605,15 +569,12 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
     size_t max_fine = 0, max_T = 0;
     pl->Ay.assign(n_pass, nullptr);
     pl->Ax.assign(n_pass, nullptr);
-    pl->Wy.assign(n_pass, nullptr);
-    pl->AxT.assign(n_pass, nullptr);
-    pl->AxG.assign(n_pass, nullptr);
-    pl->k0y.assign(n_pass, nullptr);
-    pl->startx.assign(n_pass, nullptr);
-    pl->ku.assign(n_pass, 0);
-    pl->bwx.assign(n_pass, 0);
-    pl->bwg.assign(n_pass, 0);
-    pl->seg_len.assign(n_pass, 0);
+    pl->Wy32.assign(n_pass, nullptr);
+    pl->Ax32.assign(n_pass, nullptr);
+    pl->k0y32.assign(n_pass, nullptr);
+    pl->k0x32.assign(n_pass, nullptr);
+    pl->KY.assign(n_pass, 0);
+    pl->KX.assign(n_pass, 0);
     pl->u.assign(n_pass, nullptr);
     pl->v.assign(n_pass, nullptr);
     pl->val.assign(n_pass, nullptr);
@@ -640,7 +601,7 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
             }
             if (!rc) rc = build_banded(pl, p, c.n_rows, c.n_cols, g.n_rows, g.n_cols, ay, ax);
             if (N > max_fine) max_fine = N;
-            const size_t t = (size_t)3 * g.n_rows * c.n_cols;     // T1 of the banded path
+            const size_t t = (size_t)3 * ((g.n_rows + 31) / 32 * 32) * c.n_cols;     // T1 of the banded path (transposed, padded pitch)
             const size_t t_dense = (size_t)3 * c.n_rows * g.n_cols;
             if (t > max_T) max_T = t;
             if (t_dense > max_T) max_T = t_dense;
@@ -717,16 +678,13 @@ static int run_banded_predict(tpiv_plan* plan, int p, int batch, const double* u
     q.ncc = c.n_cols;
     q.nrf = g.n_rows;
     q.ncf = g.n_cols;
-    q.ku = plan->ku[p];
-    q.Wy = plan->Wy[p];
-    q.k0y = plan->k0y[p];
-    q.bwx = plan->bwx[p];
-    q.AxT = plan->AxT[p];
-    q.startx = plan->startx[p];
-    q.bwg = plan->bwg[p];
-    q.ncf4 = (g.n_cols + 3) / 4 * 4;
-    q.AxG = plan->AxG[p];
-    q.seg_len = plan->seg_len[p];
+    q.KY = plan->KY[p];
+    q.KX = plan->KX[p];
+    q.nrfp = (g.n_rows + 31) / 32 * 32;
+    q.Wy32 = plan->Wy32[p];
+    q.k0y32 = plan->k0y32[p];
+    q.Ax32 = plan->Ax32[p];
+    q.k0x32 = plan->k0x32[p];
     q.u_c = u_c;
     q.v_c = v_c;
     q.val_c = val_c;
@@ -735,8 +693,8 @@ static int run_banded_predict(tpiv_plan* plan, int p, int batch, const double* u
     q.v0 = v0;
     q.u2 = u2;
     q.v2 = v2;
-    hipError_t he = tpiv::launch_predict_banded(q, st);
-    return he == hipSuccess ? TPIV_OK : hip_fail(he, "launch_predict_banded");
+    hipError_t he = tpiv::launch_predict_mfma(q, st);
+    return he == hipSuccess ? TPIV_OK : hip_fail(he, "launch_predict_mfma");
 }
 
 int tpiv_plan_debug_predict(tpiv_plan* plan, int pass, int batch, const double* u_c, const double* v_c,

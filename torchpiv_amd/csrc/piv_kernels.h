@@ -59,29 +59,23 @@ struct PredictParams {
     double* v2;
 };
 
-// Banded form of the predictor (plan path).  The rows of the spline operator decay like
-// 0.268^|j - j0|, so everything outside a 65-tap band is below float64 rounding of the sum.
-constexpr int PRED_RB = 8;        // fine rows per register block of the row operator
+// Banded form of the predictor (plan path, predict_mfma.hip).  The rows of the spline operator decay like
+// 0.268^|j - j0|, so everything outside a 65-tap band is below float64 rounding of the sum.  Per block of
+// 32 fine rows / columns: a dense K x 32 weight tile over the union of the block's bands (zero elsewhere),
+// K a multiple of 8.
 struct BandedPredictParams {
     int batch, mode;
     int nrc, ncc, nrf, ncf;
-    // row operator Ay: per block of PRED_RB fine rows a zero-padded weight tile over the union band
-    int ku;                       // union band length (same for all blocks)
-    const double* Wy;             // [n_blk_y][ku][PRED_RB]
-    const int* k0y;               // [n_blk_y] first coarse row of the block's union band
-    // column operator Ax: per fine column a band of bwx taps starting at startx[cf]
-    int bwx;
-    const double* AxT;            // [bwx][ncf]
-    const int* startx;            // [ncf], non-decreasing
-    // the same weights re-aligned for groups of 4 fine columns: column c of group g uses taps
-    // basex = startx[4g] + kk, kk = 0..bwg-1 (zero-padded by its own offset startx[c] - startx[4g])
-    int bwg, ncf4;                // taps per group, ncf rounded up to a multiple of 4
-    int seg_len;                  // longest staged stretch of a T1 row per 256 fine columns (+ padding taps)
-    const double* AxG;            // [bwg][ncf4]
+    int KY, KX;                   // taps per row / column block
+    int nrfp;                     // nrf rounded up to a multiple of 32: pitch of the transposed T1
+    const double* Wy32;           // [ceil(nrf / 32)][KY][32]
+    const int* k0y32;             // first coarse row of the block's tile
+    const double* Ax32;           // [ceil(ncf / 32)][KX][32]
+    const int* k0x32;             // first coarse column of the block's tile
     const double* u_c;            // [batch, nrc, ncc]
     const double* v_c;
     const uint8_t* val_c;
-    double* T1;                   // workspace [batch, 3, nrf, ncc]
+    double* T1;                   // workspace [batch, 3, ncc, nrfp]: the row operator's result, transposed
     double* u0;                   // [batch, nrf, ncf]
     double* v0;
     double* u2;
@@ -120,7 +114,7 @@ const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int le
 size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool force_generic = false);
 // test hook: peak stage + finalize on caller-made maps; planar selects the LDS layout variant of the tile kernel
 hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream);
-hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t stream);
+hipError_t launch_predict_mfma(const BandedPredictParams& q, hipStream_t stream);
 hipError_t launch_predict(const PredictParams& q, hipStream_t stream);
 
 }  // namespace tpiv

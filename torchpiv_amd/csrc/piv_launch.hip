@@ -275,224 +275,6 @@ __global__ void predict_rows_kernel(PredictParams q) {
     }
 }
 
-// ---- banded predictor (plan path) ------------------------------------------------------------
-// step A: T1[b, f, rf, cc] = sum_k Ay[rf, k] * Z_f[b, k, cc]; thread = coarse column (coalesced along
-// cc), PRED_RB fine rows per thread in registers, the block's weights are wave-uniform (scalar loads).
-__global__ __launch_bounds__(256) void predict_band_rows_kernel(BandedPredictParams q) {
-    const int cc = blockIdx.x * blockDim.x + threadIdx.x;
-    const int blk = blockIdx.y;
-    const int f = blockIdx.z % 3, b = blockIdx.z / 3;
-    if (cc >= q.ncc) return;
-    const int k0 = q.k0y[blk];
-    const double* __restrict__ w = q.Wy + (size_t)blk * q.ku * PRED_RB;
-    double acc[PRED_RB];
-#pragma unroll
-    for (int i = 0; i < PRED_RB; ++i) acc[i] = 0.0;
-    const size_t zoff = (size_t)b * q.nrc * q.ncc + cc;
-    const int kn = (k0 + q.ku <= q.nrc) ? q.ku : q.nrc - k0;
-    if (f == 2) {
-        const uint8_t* __restrict__ z = q.val_c + zoff;
-#pragma unroll 4
-        for (int kk = 0; kk < kn; ++kk) {
-            const double zv = (double)z[(size_t)(k0 + kk) * q.ncc];
-#pragma unroll
-            for (int i = 0; i < PRED_RB; ++i) acc[i] += w[kk * PRED_RB + i] * zv;
-        }
-    } else {
-        const double* __restrict__ z = (f == 0 ? q.u_c : q.v_c) + zoff;
-#pragma unroll 4
-        for (int kk = 0; kk < kn; ++kk) {
-            const double zv = z[(size_t)(k0 + kk) * q.ncc];
-#pragma unroll
-            for (int i = 0; i < PRED_RB; ++i) acc[i] += w[kk * PRED_RB + i] * zv;
-        }
-    }
-    double* __restrict__ t = q.T1 + (((size_t)b * 3 + f) * q.nrf) * q.ncc + cc;
-#pragma unroll
-    for (int i = 0; i < PRED_RB; ++i) {
-        const int rf = blk * PRED_RB + i;
-        if (rf < q.nrf) t[(size_t)rf * q.ncc] = acc[i];
-    }
-}
-
-// step B: out[b, rf, cf] = sum_k T1[b, f, rf, k] * Ax[cf, k] for the three fields, then the per-mode
-// predictor post-processing.  One block = one fine row x 256 fine columns; the needed stretch of the
-// T1 row is staged in LDS once, the weights are read coalesced from the transposed band table.
-__global__ __launch_bounds__(256) void predict_band_cols_kernel(BandedPredictParams q) {
-    __shared__ double seg[3][512];
-    const int cf0 = blockIdx.x * blockDim.x;
-    const int cf = cf0 + threadIdx.x;
-    const int rf = blockIdx.y, b = blockIdx.z;
-    const int cf_last = (cf0 + (int)blockDim.x - 1 < q.ncf) ? cf0 + (int)blockDim.x - 1 : q.ncf - 1;
-    const int kmin = q.startx[cf0];
-    const int len = q.startx[cf_last] + q.bwx - kmin;          // <= 512 (checked on the host)
-    for (int i = threadIdx.x; i < len; i += blockDim.x) {
-#pragma unroll
-        for (int f = 0; f < 3; ++f)
-            seg[f][i] = q.T1[(((size_t)b * 3 + f) * q.nrf + rf) * q.ncc + kmin + i];
-    }
-    __syncthreads();
-    if (cf >= q.ncf) return;
-    const int s0 = q.startx[cf] - kmin;
-    double u0 = 0.0, v0 = 0.0, vm = 0.0;
-#pragma unroll 5
-    for (int kk = 0; kk < q.bwx; ++kk) {
-        const double a = q.AxT[(size_t)kk * q.ncf + cf];
-        u0 += a * seg[0][s0 + kk];
-        v0 += a * seg[1][s0 + kk];
-        vm += a * seg[2][s0 + kk];
-    }
-    const bool val = vm >= 0.5;                 // B:711 / B:778
-    double u2, v2;
-    if (q.mode == MODE_CWS) {                   // B:705-706: halves taken BEFORE the zeroing
-        u2 = u0 / 2;
-        v2 = v0 / 2;
-    }
-    if (val) {
-        u0 = 0.0;
-        v0 = 0.0;
-    }
-    if (q.mode == MODE_DWS) {                   // B:782-785: AFTER the zeroing, half-even
-        u2 = rint(u0 / 2);
-        v2 = rint(v0 / 2);
-    }
-    const size_t o = ((size_t)b * q.nrf + rf) * q.ncf + cf;
-    q.u0[o] = u0;
-    q.v0[o] = v0;
-    q.u2[o] = u2;
-    q.v2[o] = v2;
-}
-
-// Column operator, 4 fine columns and PRED_CR fine rows per thread: one wavefront = 256 fine columns.
-// The staged stretch of the T1 rows is read ONCE per tap for the 4 columns (group-aligned weights,
-// BandedPredictParams::AxG), so the kernel is bound by the float64 FMAs, not by LDS bandwidth.
-constexpr int PRED_CR = 2;
-__global__ __launch_bounds__(64) void predict_band_cols4_kernel(BandedPredictParams q) {
-    extern __shared__ double seg_dyn[];                        // [PRED_CR][3][seg_len]
-    const int SL = q.seg_len;
-    const int lane = threadIdx.x;
-    const int cf0 = blockIdx.x * 256;
-    const int rf0 = blockIdx.y * PRED_CR, b = blockIdx.z;
-    const int cf_last = (cf0 + 255 < q.ncf) ? cf0 + 255 : q.ncf - 1;
-    const int kmin = q.startx[cf0];
-    const int len = q.startx[cf_last] + q.bwx - kmin;          // <= 512 (checked on the host)
-    const int len_pad = len + (q.bwg - q.bwx) + 8;             // taps beyond `len` carry zero weights
-                                                               // (+8: the tap loop runs in groups of 8)
-#pragma unroll
-    for (int r = 0; r < PRED_CR; ++r) {
-        const bool row_ok = rf0 + r < q.nrf;
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            const double* __restrict__ src = q.T1 + (((size_t)b * 3 + f) * q.nrf + (row_ok ? rf0 + r : 0)) * q.ncc + kmin;
-            for (int i = lane; i < len_pad; i += 64) seg_dyn[(r * 3 + f) * SL + i] = (row_ok && i < len) ? src[i] : 0.0;
-        }
-    }
-    __syncthreads();
-    const int cfb_raw = cf0 + 4 * lane;
-    const int cfb = cfb_raw < q.ncf ? cfb_raw : (q.ncf - 1) / 4 * 4;     // idle lanes redo the last group
-    const int s0 = q.startx[cfb] - kmin;
-    double acc[PRED_CR][3][4];
-#pragma unroll
-    for (int r = 0; r < PRED_CR; ++r)
-#pragma unroll
-        for (int f = 0; f < 3; ++f)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][f][c] = 0.0;
-    const double4* __restrict__ wg = reinterpret_cast<const double4*>(q.AxG) + (cfb >> 2);
-    const int wstride = q.ncf4 >> 2;
-    // taps in groups of 8 with all eight weight loads issued up front: left to the compiler every load
-    // was followed by s_waitcnt vmcnt(0), i.e. one L2 round trip per tap
-    for (int kk0 = 0; kk0 < q.bwg; kk0 += 8) {
-        double4 w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int kk = kk0 + u < q.bwg ? kk0 + u : q.bwg - 1;
-            w[u] = wg[(size_t)kk * wstride];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool live = kk0 + u < q.bwg;                 // tail taps: weight 0 on a zero-filled cell
-            const double4 wu = live ? w[u] : make_double4(0.0, 0.0, 0.0, 0.0);
-#pragma unroll
-            for (int r = 0; r < PRED_CR; ++r)
-#pragma unroll
-                for (int f = 0; f < 3; ++f) {
-                    const double z = seg_dyn[(r * 3 + f) * SL + s0 + kk0 + u];
-                    acc[r][f][0] += wu.x * z;
-                    acc[r][f][1] += wu.y * z;
-                    acc[r][f][2] += wu.z * z;
-                    acc[r][f][3] += wu.w * z;
-                }
-        }
-    }
-    // Outputs go through LDS so that every store instruction writes 64 CONSECUTIVE doubles (a thread
-    // owns 4 adjacent columns: stored directly, each instruction would touch every fourth double of
-    // a 2 KB stretch, four partial passes over every cache line).
-    __syncthreads();                                           // the staged T1 rows are no longer needed
-    double* stage = seg_dyn;                                   // [4 arrays][PRED_CR][256]
-#pragma unroll
-    for (int r = 0; r < PRED_CR; ++r) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            double u0 = acc[r][0][c], v0 = acc[r][1][c];
-            const bool val = acc[r][2][c] >= 0.5;       // B:711 / B:778
-            double u2 = 0.0, v2 = 0.0;
-            if (q.mode == MODE_CWS) {                   // B:705-706: halves taken BEFORE the zeroing
-                u2 = u0 / 2;
-                v2 = v0 / 2;
-            }
-            if (val) {
-                u0 = 0.0;
-                v0 = 0.0;
-            }
-            if (q.mode == MODE_DWS) {                   // B:782-785: AFTER the zeroing, half-even
-                u2 = rint(u0 / 2);
-                v2 = rint(v0 / 2);
-            }
-            const int col = 4 * lane + c;
-            stage[(0 * PRED_CR + r) * 256 + col] = u0;
-            stage[(1 * PRED_CR + r) * 256 + col] = v0;
-            stage[(2 * PRED_CR + r) * 256 + col] = u2;
-            stage[(3 * PRED_CR + r) * 256 + col] = v2;
-        }
-    }
-    __syncthreads();
-    double* const outs[4] = {q.u0, q.v0, q.u2, q.v2};
-#pragma unroll
-    for (int arr = 0; arr < 4; ++arr) {
-#pragma unroll
-        for (int r = 0; r < PRED_CR; ++r) {
-            if (rf0 + r >= q.nrf) break;
-            double* __restrict__ dst = outs[arr] + ((size_t)b * q.nrf + rf0 + r) * q.ncf + cf0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = j * 64 + lane;
-                if (cf0 + col < q.ncf) dst[col] = stage[(arr * PRED_CR + r) * 256 + col];
-            }
-        }
-    }
-}
-
-hipError_t launch_predict_banded(const BandedPredictParams& q, hipStream_t stream) {
-    const int nblk = (q.nrf + PRED_RB - 1) / PRED_RB;
-    const int tx = q.ncc >= 256 ? 256 : (q.ncc >= 128 ? 128 : 64);
-    hipLaunchKernelGGL(predict_band_rows_kernel, dim3((q.ncc + tx - 1) / tx, nblk, q.batch * 3), dim3(tx), 0,
-                       stream, q);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (q.AxG != nullptr) {
-        const size_t seg_d = (size_t)PRED_CR * 3 * q.seg_len, out_d = (size_t)4 * PRED_CR * 256;
-        const size_t lds = (seg_d > out_d ? seg_d : out_d) * sizeof(double);
-        hipLaunchKernelGGL(predict_band_cols4_kernel, dim3((q.ncf + 255) / 256, (q.nrf + PRED_CR - 1) / PRED_CR, q.batch),
-                           dim3(64), lds, stream, q);
-        return hipGetLastError();
-    }
-    const int tc = q.ncf >= 256 ? 256 : (q.ncf >= 128 ? 128 : 64);
-    hipLaunchKernelGGL(predict_band_cols_kernel, dim3((q.ncf + tc - 1) / tc, q.nrf, q.batch), dim3(tc), 0,
-                       stream, q);
-    return hipGetLastError();
-}
-
 hipError_t launch_predict(const PredictParams& q, hipStream_t stream) {
     {
         const long long total = (long long)q.batch * 3 * q.nrc * q.ncf;

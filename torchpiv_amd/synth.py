@@ -51,7 +51,7 @@ def _render(px, py, amp, H, W, sigma, device):
             xx = cx + ox
             w = wy * torch.exp(-((xx - px) ** 2) / (2 * sigma * sigma))
             ok = oky & (xx >= 0) & (xx < W)
-            idx = (yy * W + xx).long()
+            idx = yy.long() * W + xx.long()          # (in float32 the flat index is inexact beyond 2^24 pixels)
             img.index_add_(0, idx[ok], (amp * w)[ok])
     return img.view(H, W)
 
