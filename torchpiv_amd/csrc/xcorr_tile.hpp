@@ -441,9 +441,63 @@ struct RawRows<WS, MODE_DWS> {
     int cls;             // per lane, 2 bits per row: 0 in frame, 1 entirely before it, 2 entirely behind it
     int fix;             // wave-uniform: some lane has a row of class 1 or 2
 };
+// CWS source patches, loaded by the window's lanes TOGETHER (tile sizes 16 and 32).  A shifted window reads
+// (WS+1) x (WS+1) source pixels per frame; with lane = row every load instruction touched 64 different rows,
+// i.e. 64-128 cache lines (TCP_TOTAL_CACHE_ACCESSES: 151 per load instruction against 58 in pass 1, about
+// one tag look-up per CU cycle over the whole kernel), each row was fetched twice (as the upper row of one
+// lane and the lower row of its neighbour), and at a power-of-two row pitch all those lines fall into the
+// same cache banks (2048-pixel frames: the 32x32 CWS pass took 32.8 us per pair, 28.9 us at a pitch of
+// 2064).  Here the patch is cut into 16-byte chunks, chunk ci = row * RPG + part, and lane r of the window
+// loads chunks r, r + WS, ...: consecutive lanes read consecutive pieces of a row.  convert_rows parks the
+// chunks in LDS (row pitch 48 bytes: conflict-free 16-byte reads at any row offset) and every lane reads
+// the two rows it interpolates between.
+template <int WS>
+struct CoopGeo {
+#ifndef TPIV_COOP
+#define TPIV_COOP 1
+#endif
+    static constexpr bool ON = TPIV_COOP && (WS == 16 || WS == 32);
+    static constexpr int NROW = WS + 1;                       // patch rows
+    static constexpr int RPG = (WS + 1 + 15) / 16;            // 16-byte chunks loaded per row
+    static constexpr int LOADED = 16 * RPG;                   // bytes loaded per row
+    static constexpr int T = NROW * RPG;                      // chunks per patch
+    static constexpr int NCH = (T + WS - 1) / WS;             // chunks per lane
+    static constexpr int PITCH4 = 3;                          // LDS row pitch in 16-byte units
+    static constexpr int PATCH4 = NROW * PITCH4;              // 16-byte units per patch
+    static constexpr int FLOATS = (64 / WS) * 2 * PATCH4 * 4; // all patches of a wavefront, in floats
+    static constexpr int LDS_FLOATS = FLOATS + (64 / WS) * (WS + 1) * 4;      // + the x-weight tables
+    static_assert(!ON || RPG <= PITCH4, "patch row pitch");
+    __device__ static __forceinline__ void chunk(int ci, int& j, int& part) {
+        if constexpr (RPG == 2) {
+            j = ci >> 1;
+            part = ci & 1;
+        } else {
+            j = (ci * 171) >> 9;                              // ci / 3 for ci < 171
+            part = ci - 3 * j;
+        }
+    }
+};
+// loop-invariant part of a lane's chunk addresses: row * W + 16 * part (0 for the idle slots of the last round)
+template <int WS>
+struct CoopOff {
+    int o[CoopGeo<WS>::ON ? CoopGeo<WS>::NCH : 1];
+    __device__ __forceinline__ void init(int r, int W) {
+        if constexpr (CoopGeo<WS>::ON) {
+#pragma unroll
+            for (int k = 0; k < CoopGeo<WS>::NCH; ++k) {
+                int j, part;
+                CoopGeo<WS>::chunk(r + WS * k, j, part);
+                o[k] = r + WS * k < CoopGeo<WS>::T ? j * W + 16 * part : 0;
+            }
+        }
+    }
+};
 template <int WS>
 struct RawRows<WS, MODE_CWS> {
-    uint32_t a0[WS / 4 + 1], a1[WS / 4 + 1], b0[WS / 4 + 1], b1[WS / 4 + 1];    // WS+1 bytes per row
+    static constexpr int NB = WS / 4 + 1;
+    // WS+1 bytes per row, or the lane's share of the two patches
+    uint32_t a0[CoopGeo<WS>::ON ? 1 : NB], a1[CoopGeo<WS>::ON ? 1 : NB], b0[CoopGeo<WS>::ON ? 1 : NB], b1[CoopGeo<WS>::ON ? 1 : NB];
+    uint32_t ca[CoopGeo<WS>::ON ? CoopGeo<WS>::NCH : 1][4], cb[CoopGeo<WS>::ON ? CoopGeo<WS>::NCH : 1][4];
     int reg;
     int cls;             // see above (rows a0, a1, b0, b1 in bits 0-1, 2-3, 4-5, 6-7)
     int fix;
@@ -516,6 +570,13 @@ __device__ __forceinline__ void fix_row(uint32_t (&d)[N], int cls) {
 #pragma unroll
     for (int i = 0; i < N; ++i) d[i] = cls != 0 ? px : d[i];
 }
+// (patch rows: the last loaded byte of a row lies beyond the N dwords a lane holds; `last` = that dword)
+template <int N>
+__device__ __forceinline__ void fix_row(uint32_t (&d)[N], int cls, uint32_t last) {
+    const uint32_t px = (cls == 1 ? (d[0] & 0xffu) : (last >> 24)) * 0x01010101u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = cls != 0 ? px : d[i];
+}
 
 // The loads are issued UNCONDITIONALLY: a load under `if` makes the loaded registers the target of
 // a PHI copy, and the compiler then waits for the data right behind the load -- which would
@@ -523,7 +584,7 @@ __device__ __forceinline__ void fix_row(uint32_t (&d)[N], int cls) {
 // from the un-shifted row instead (always inside the frame) and ignore the data.
 template <int WS, int MODE, bool FAST = false>
 __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& g, int r, float vx, float vy,
-                                           RawRows<WS, MODE>& raw) {
+                                           RawRows<WS, MODE>& raw, const CoopOff<WS>& coff) {
     const int HW = p.H * p.W;
     const uint8_t* __restrict__ fa = p.A + (size_t)g.pair * HW;
     const uint8_t* __restrict__ fb = p.B + (size_t)g.pair * HW;
@@ -565,9 +626,11 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         const int xa = g.x0 - ivx - 1, xb = g.x0 + ivx;
         const int qa0 = dya * W_ + xa, qa1 = uya * W_ + xa;
         const int qb0 = dyb * W_ + xb, qb1 = uyb * W_ + xb;
+        using CG = CoopGeo<WS>;
+        constexpr int LOADED = CG::ON ? CG::LOADED : 4 * NB;       // bytes a row load reads
         int la0, la1, lb0, lb1;
-        const int c0 = classify_row32(qa0, WS + 1, 4 * NB, HW, la0), c1 = classify_row32(qa1, WS + 1, 4 * NB, HW, la1);
-        const int c2 = classify_row32(qb0, WS + 1, 4 * NB, HW, lb0), c3 = classify_row32(qb1, WS + 1, 4 * NB, HW, lb1);
+        const int c0 = classify_row32(qa0, WS + 1, LOADED, HW, la0), c1 = classify_row32(qa1, WS + 1, LOADED, HW, la1);
+        const int c2 = classify_row32(qb0, WS + 1, LOADED, HW, lb0), c3 = classify_row32(qb1, WS + 1, LOADED, HW, lb1);
         // (FAST: an integral row coordinate -- B:170, B:193 return the nearest sample -- is left to the
         //  per-pixel path, which implements the quirk; the lerp form of convert_rows does not)
         const float gxr = (float)(g.x0 + r);
@@ -575,8 +638,54 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         const float fxa_r = floorf(nxa_r), fxb_r = floorf(nxb_r);
         const bool col_ok = fxa_r == (float)(g.x0 + r - ivx - 1) && fxb_r == (float)(g.x0 + r + ivx) &&
                             fxa_r != nxa_r && fxb_r != nxb_r;
-        const bool reg = c0 != 3 && c1 != 3 && c2 != 3 && c3 != 3 && col_ok &&
-                         fabsf(vx) < (float)p.W && !(FAST && (c.ydeg_a | c.ydeg_b));
+        bool reg = c0 != 3 && c1 != 3 && c2 != 3 && c3 != 3 && col_ok &&
+                   fabsf(vx) < (float)p.W && !(FAST && (c.ydeg_a | c.ydeg_b));
+        if constexpr (CG::ON) {
+            // the window's patches start at the (clamped) lower source row of its row 0; a lane's two rows must
+            // lie inside them (they do unless float32 rounding makes the row coordinates jump)
+            const float gy0f = (float)g.y0;
+            const int base_a = clamp_i(f2i_sat_t(floorf(gy0f - vy)), rlo, rhi);
+            const int base_b = clamp_i(f2i_sat_t(floorf(gy0f + vy)), rlo, rhi);
+            reg = reg && (unsigned)(dya - base_a) <= (unsigned)WS && (unsigned)(uya - base_a) <= (unsigned)WS &&
+                  (unsigned)(dyb - base_b) <= (unsigned)WS && (unsigned)(uyb - base_b) <= (unsigned)WS;
+            raw.reg = __all(reg) ? 1 : 0;
+            raw.cls = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
+            raw.fix = (raw.reg && __any(raw.cls != 0)) ? 1 : 0;
+            // Wavefronts whose patches lie inside the frame with LOADED bytes to spare in every row (all but the
+            // border windows) add the loop-invariant chunk offsets to the patch origin; the others classify
+            // every chunk's row like a lane's own rows (the first version did that always: +160 VALU
+            // instructions per item).  Only ADDRESSES differ between the branches: the loads stay unconditional.
+            unsigned oa[CG::NCH], ob[CG::NCH];
+            const bool inside = base_a >= 0 && base_a + WS < p.H && base_b >= 0 && base_b + WS < p.H &&
+                                xa >= 0 && xa + LOADED <= W_ && xb >= 0 && xb + LOADED <= W_;
+            if (__all(inside)) {
+                const int qa_o = base_a * W_ + xa, qb_o = base_b * W_ + xb;
+#pragma unroll
+                for (int k = 0; k < CG::NCH; ++k) {
+                    oa[k] = (unsigned)(qa_o + coff.o[k]);
+                    ob[k] = (unsigned)(qb_o + coff.o[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CG::NCH; ++k) {
+                    const int ci = r + WS * k;
+                    int j, part;
+                    CG::chunk(ci, j, part);
+                    int qa_l, qb_l;
+                    const int ra = clamp_i(base_a + j, rlo, rhi), rb = clamp_i(base_b + j, rlo, rhi);
+                    classify_row32(ra * W_ + xa, WS + 1, LOADED, HW, qa_l);
+                    classify_row32(rb * W_ + xb, WS + 1, LOADED, HW, qb_l);
+                    const bool live = ci < CG::T;                  // (the last chunk round is partly idle)
+                    oa[k] = live ? (unsigned)(qa_l + 16 * part) : 0u;
+                    ob[k] = live ? (unsigned)(qb_l + 16 * part) : 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < CG::NCH; ++k) {
+                load_dwords<4>(fa + oa[k], raw.ca[k]);
+                load_dwords<4>(fb + ob[k], raw.cb[k]);
+            }
+        } else {
         raw.reg = __all(reg) ? 1 : 0;
         raw.cls = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
         raw.fix = (raw.reg && __any(raw.cls != 0)) ? 1 : 0;
@@ -588,6 +697,7 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         load_dwords<NB>(fa + (unsigned)(raw.reg ? la1 : safe), raw.a1);
         load_dwords<NB>(fb + (unsigned)(raw.reg ? lb0 : safe), raw.b0);
         load_dwords<NB>(fb + (unsigned)(raw.reg ? lb1 : safe), raw.b1);
+        }
     }
 }
 
@@ -666,12 +776,63 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         constexpr int NB = WS / 4 + 1;
         const CwsRow c = cws_row(g.y0 + r, vy);
         const float gx0f = (float)g.x0;
+        using CG = CoopGeo<WS>;
         if (raw.reg) {
-            if (raw.fix) {            // border windows: rows entirely outside the frame
-                fix_row(raw.a0, raw.cls & 3);
-                fix_row(raw.a1, (raw.cls >> 2) & 3);
-                fix_row(raw.b0, (raw.cls >> 4) & 3);
-                fix_row(raw.b1, (raw.cls >> 6) & 3);
+            uint32_t ra0[NB], ra1[NB], rb0[NB], rb1[NB];
+            if constexpr (CG::ON) {
+                // the chunks go to LDS, the lane's rows come back (same wavefront: program order is enough)
+                uint4* pl = reinterpret_cast<uint4*>(lds);
+                const int w_ = lane / WS;
+                uint4* pa = pl + (w_ * 2) * CG::PATCH4;
+                uint4* pb = pa + CG::PATCH4;
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < CG::NCH; ++k) {
+                    const int ci = r + WS * k;
+                    int j, part;
+                    CG::chunk(ci, j, part);
+                    if (ci < CG::T) {
+                        pa[j * CG::PITCH4 + part] = make_uint4(raw.ca[k][0], raw.ca[k][1], raw.ca[k][2], raw.ca[k][3]);
+                        pb[j * CG::PITCH4 + part] = make_uint4(raw.cb[k][0], raw.cb[k][1], raw.cb[k][2], raw.cb[k][3]);
+                    }
+                }
+                wave_sync();
+                const int rlo = -8, rhi = p.H + 7;
+                const float gy0f = (float)g.y0;
+                const int base_a = clamp_i(f2i_sat_t(floorf(gy0f - vy)), rlo, rhi);
+                const int base_b = clamp_i(f2i_sat_t(floorf(gy0f + vy)), rlo, rhi);
+                const uint4* s0 = pa + (clamp_i(c.dya, rlo, rhi) - base_a) * CG::PITCH4;
+                const uint4* s1 = pa + (clamp_i(c.uya, rlo, rhi) - base_a) * CG::PITCH4;
+                const uint4* s2 = pb + (clamp_i(c.dyb, rlo, rhi) - base_b) * CG::PITCH4;
+                const uint4* s3 = pb + (clamp_i(c.uyb, rlo, rhi) - base_b) * CG::PITCH4;
+                auto fetch = [&](const uint4* src, uint32_t (&d)[NB]) TPIV_LAMBDA_INLINE {
+#pragma unroll
+                    for (int q = 0; q < NB / 4; ++q) {
+                        const uint4 t = src[q];
+                        d[4 * q] = t.x, d[4 * q + 1] = t.y, d[4 * q + 2] = t.z, d[4 * q + 3] = t.w;
+                    }
+                    d[NB - 1] = reinterpret_cast<const uint32_t*>(src)[NB - 1];          // NB = 4 m + 1
+                };
+                fetch(s0, ra0);
+                fetch(s1, ra1);
+                fetch(s2, rb0);
+                fetch(s3, rb1);
+                if (raw.fix) {            // border windows: rows entirely outside the frame
+                    constexpr int LAST = CG::LOADED / 4 - 1;       // dword that holds the last loaded byte
+                    fix_row(ra0, raw.cls & 3, reinterpret_cast<const uint32_t*>(s0)[LAST]);
+                    fix_row(ra1, (raw.cls >> 2) & 3, reinterpret_cast<const uint32_t*>(s1)[LAST]);
+                    fix_row(rb0, (raw.cls >> 4) & 3, reinterpret_cast<const uint32_t*>(s2)[LAST]);
+                    fix_row(rb1, (raw.cls >> 6) & 3, reinterpret_cast<const uint32_t*>(s3)[LAST]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NB; ++q) ra0[q] = raw.a0[q], ra1[q] = raw.a1[q], rb0[q] = raw.b0[q], rb1[q] = raw.b1[q];
+                if (raw.fix) {            // border windows: rows entirely outside the frame
+                    fix_row(ra0, raw.cls & 3);
+                    fix_row(ra1, (raw.cls >> 2) & 3);
+                    fix_row(rb0, (raw.cls >> 4) & 3);
+                    fix_row(rb1, (raw.cls >> 6) & 3);
+                }
             }
             // The x-direction weights depend on the column only (same for every row of the
             // window): lane r evaluates them for column r exactly as B:164-171 does and parks
@@ -680,7 +841,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
             // never "integral" (only the row can be, ydeg_*).
             // (one spare float4 per window: without it the 64 / WS windows' tables start a multiple of 256 bytes
             //  apart and their broadcast reads hit the same banks -- a 4-way conflict on every read for 16x16)
-            float4* wbuf = reinterpret_cast<float4*>(lds) + (lane / WS) * (WS + 1);
+            float4* wbuf = reinterpret_cast<float4*>(lds + (CG::ON ? CG::FLOATS : 0)) + (lane / WS) * (WS + 1);
             {
                 const float gxf = gx0f + (float)r;               // exact: small integers
                 const float nxa = gxf - vx, nxb = gxf + vx;
@@ -697,10 +858,10 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                     constexpr int k = decltype(kc)::value;
                     if constexpr (k % 8 == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
                     const float4 wx = wbuf[k];
-                    const float a11 = byte_f<k, NB>(raw.a0), a21 = byte_f<k + 1, NB>(raw.a0);
-                    const float a12 = byte_f<k, NB>(raw.a1), a22 = byte_f<k + 1, NB>(raw.a1);
-                    const float b11 = byte_f<k, NB>(raw.b0), b21 = byte_f<k + 1, NB>(raw.b0);
-                    const float b12 = byte_f<k, NB>(raw.b1), b22 = byte_f<k + 1, NB>(raw.b1);
+                    const float a11 = byte_f<k, NB>(ra0), a21 = byte_f<k + 1, NB>(ra0);
+                    const float a12 = byte_f<k, NB>(ra1), a22 = byte_f<k + 1, NB>(ra1);
+                    const float b11 = byte_f<k, NB>(rb0), b21 = byte_f<k + 1, NB>(rb0);
+                    const float b12 = byte_f<k, NB>(rb1), b22 = byte_f<k + 1, NB>(rb1);
                     const float ha1 = fmaf(a21, wx.y, a11 * wx.x), ha2 = fmaf(a22, wx.y, a12 * wx.x);
                     const float hb1 = fmaf(b21, wx.w, b11 * wx.z), hb2 = fmaf(b22, wx.w, b12 * wx.z);
                     x[k].x = fmaf(ha2, c.wya_dn, ha1 * c.wya_up);
@@ -714,10 +875,10 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                 // keep the scheduler from hoisting all WS weight reads (4 VGPRs each) to the top
                 if constexpr (k % 8 == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
                 const float4 wx = wbuf[k];
-                x[k].x = bilerp_ref_m(byte_f<k, NB>(raw.a0), byte_f<k + 1, NB>(raw.a0), byte_f<k, NB>(raw.a1),
-                                      byte_f<k + 1, NB>(raw.a1), wx.x, wx.y, c.wya_up, c.wya_dn, dmask_a);
-                x[k].y = bilerp_ref_m(byte_f<k, NB>(raw.b0), byte_f<k + 1, NB>(raw.b0), byte_f<k, NB>(raw.b1),
-                                      byte_f<k + 1, NB>(raw.b1), wx.z, wx.w, c.wyb_up, c.wyb_dn, dmask_b);
+                x[k].x = bilerp_ref_m(byte_f<k, NB>(ra0), byte_f<k + 1, NB>(ra0), byte_f<k, NB>(ra1),
+                                      byte_f<k + 1, NB>(ra1), wx.x, wx.y, c.wya_up, c.wya_dn, dmask_a);
+                x[k].y = bilerp_ref_m(byte_f<k, NB>(rb0), byte_f<k + 1, NB>(rb0), byte_f<k, NB>(rb1),
+                                      byte_f<k + 1, NB>(rb1), wx.z, wx.w, c.wyb_up, c.wyb_dn, dmask_b);
             });
             }
             wave_sync();
@@ -907,7 +1068,9 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
     constexpr int RBH = 64 * (WS + 1) <= G::LDS_FLOATS ? 1 : 2;      // slow-path row buffer pieces
     static_assert(MODE == MODE_PASS1 || 64 * (WS / RBH + 1) <= G::LDS_FLOATS,
                   "slow-path row buffer (shifted passes) must fit the tile LDS");
-    __shared__ float tile[G::LDS_FLOATS];
+    constexpr int LDSF = (MODE == MODE_CWS && CoopGeo<WS>::ON && CoopGeo<WS>::LDS_FLOATS > G::LDS_FLOATS)
+                             ? CoopGeo<WS>::LDS_FLOATS : G::LDS_FLOATS;
+    __shared__ float tile[LDSF];
 
     // 16x16 has registers to spare: its twiddle constants live in VGPRs (plain 4-byte VOP2 multiplies
     // instead of 8-byte literal forms and half-rate SGPR operands): 169 -> 158 us/pair
@@ -996,11 +1159,13 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
     float vx, vy;
     RawRows<WS, MODE> raw;
     ItemGeom gcur;
+    CoopOff<WS> coff;
+    if constexpr (MODE == MODE_CWS) coff.init(fresh_lane() % WS, p.W);
     {
         const int l0 = fresh_lane();
         gcur = geom_of(item, l0 / WS);
         shift_of(gcur, vx, vy);
-        issue_rows<WS, MODE, FAST>(p, gcur, l0 % WS, vx, vy, raw);
+        issue_rows<WS, MODE, FAST>(p, gcur, l0 % WS, vx, vy, raw, coff);
     }
 
     TPIV_STAMP_DECL
@@ -1034,7 +1199,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         if constexpr (WS >= 64) nnitem = q_take(q_raw);
         // small tiles: the row registers are free again, so the next item's loads go out now and
         // have the whole iteration to land (64x64 is register-bound: it waits until the peak search)
-        if constexpr (WS <= 32) issue_rows<WS, MODE, FAST>(p, gnext, r, nvx, nvy, raw);
+        if constexpr (WS <= 32) issue_rows<WS, MODE, FAST>(p, gnext, r, nvx, nvy, raw, coff);
 
         if (p.dbg_win != nullptr && active) {     // test hook: the staged (shifted) windows
             // (the row index is made opaque here: otherwise the WS loop-invariant store addresses get
@@ -1183,7 +1348,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         // ---- prefetch: the next item's row loads fly while this item's peak search runs
         if constexpr (WS > 32) {
             const int lane_p = fresh_lane();
-            issue_rows<WS, MODE, FAST>(p, geom_of(nit, lane_p / WS), lane_p % WS, nvx, nvy, raw);
+            issue_rows<WS, MODE, FAST>(p, geom_of(nit, lane_p / WS), lane_p % WS, nvx, nvy, raw, coff);
         }
         vx = nvx;
         vy = nvy;
