@@ -704,9 +704,9 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
 // raw rows -> float samples x[k] = (a, b) and the lane's partial sums
 // RBH: the per-pixel slow paths park a row in LDS in RBH pieces (2 when the planar 64x64 layout
 // leaves only 64 x 33 floats)
-// FAST (precision "fast"): the CWS sample is formed as two row lerps and one column lerp with the SAME
-// float32 weights (6 instead of 11 multiply/add instructions; differs from the reference's evaluation
-// order by float32 rounding only), and the per-sample window sums are not formed here (the mean is
+// FAST (precision "fast"): the CWS sample is formed as a lerp between the two source rows followed by a
+// lerp between neighbouring columns, with the SAME float32 weights (4 instead of 11 multiply/add
+// instructions per sample; differs from the reference's evaluation order by float32 rounding only), and the per-sample window sums are not formed here (the mean is
 // removed in the DC bin after the row transform, see the kernel).  !FAST keeps the reference's
 // operation order: staged windows bit-identical to biliniar_interpolation_CWS (B:187-193).
 template <int WS, int MODE, int RBH = 1, bool FAST = false>
@@ -854,18 +854,20 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
             // (FAST: a wavefront that holds a lane with an integral row coordinate -- the "nearest sample"
             //  quirk of B:170, B:193 -- never gets here: issue_rows sends it down the per-pixel path)
             if constexpr (FAST) {
+                // rows first, then columns: the WS + 1 column values of the row lerp are each used by two
+                // output samples (130 instead of 192 multiply/add instructions per frame and lane)
+                float va = fmaf(byte_f<0, NB>(ra1), c.wya_dn, byte_f<0, NB>(ra0) * c.wya_up);
+                float vb = fmaf(byte_f<0, NB>(rb1), c.wyb_dn, byte_f<0, NB>(rb0) * c.wyb_up);
                 static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int k = decltype(kc)::value;
                     if constexpr (k % 8 == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
                     const float4 wx = wbuf[k];
-                    const float a11 = byte_f<k, NB>(ra0), a21 = byte_f<k + 1, NB>(ra0);
-                    const float a12 = byte_f<k, NB>(ra1), a22 = byte_f<k + 1, NB>(ra1);
-                    const float b11 = byte_f<k, NB>(rb0), b21 = byte_f<k + 1, NB>(rb0);
-                    const float b12 = byte_f<k, NB>(rb1), b22 = byte_f<k + 1, NB>(rb1);
-                    const float ha1 = fmaf(a21, wx.y, a11 * wx.x), ha2 = fmaf(a22, wx.y, a12 * wx.x);
-                    const float hb1 = fmaf(b21, wx.w, b11 * wx.z), hb2 = fmaf(b22, wx.w, b12 * wx.z);
-                    x[k].x = fmaf(ha2, c.wya_dn, ha1 * c.wya_up);
-                    x[k].y = fmaf(hb2, c.wyb_dn, hb1 * c.wyb_up);
+                    const float na = fmaf(byte_f<k + 1, NB>(ra1), c.wya_dn, byte_f<k + 1, NB>(ra0) * c.wya_up);
+                    const float nb = fmaf(byte_f<k + 1, NB>(rb1), c.wyb_dn, byte_f<k + 1, NB>(rb0) * c.wyb_up);
+                    x[k].x = fmaf(na, wx.y, va * wx.x);
+                    x[k].y = fmaf(nb, wx.w, vb * wx.z);
+                    va = na;
+                    vb = nb;
                 });
             } else {
             unsigned dmask_a = c.ydeg_a ? ~0u : 0u, dmask_b = c.ydeg_b ? ~0u : 0u;
