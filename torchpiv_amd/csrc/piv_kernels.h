@@ -103,9 +103,12 @@ hipError_t launch_bmp_unpack(const uint8_t* raw, const long long* desc, const ui
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream);
 // wavefronts per SIMD the tile kernel of (ws, mode) is built for (the OCC template argument of
 // xcorr_tile_kernel); 0 for sizes that run another kernel
+#ifndef TPIV_OCC64C
+#define TPIV_OCC64C 2      // wavefronts per SIMD of the 64x64 CWS kernel (experiments: 3)
+#endif
 constexpr int tile_occ_c(int ws, int mode) {
     return (ws != 8 && ws != 16 && ws != 32 && ws != 64) ? 0
-           : (ws == 16 ? 4 : ((ws == 32 || (ws == 64 && mode != MODE_CWS)) ? 3 : 2));
+           : (ws == 16 ? 4 : ((ws == 32 || (ws == 64 && (mode != MODE_CWS || TPIV_OCC64C == 3))) ? 3 : 2));
 }
 inline int tile_occ(int ws, int mode) { return tile_occ_c(ws, mode); }
 // symbol-like name of the kernel launch_xcorr picks for (ws, mode) -- for bench / profile labels

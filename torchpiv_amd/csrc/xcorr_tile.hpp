@@ -449,20 +449,20 @@ struct RawRows<WS, MODE_DWS> {
 // same cache banks (2048-pixel frames: the 32x32 CWS pass took 32.8 us per pair, 28.9 us at a pitch of
 // 2064).  Here the patch is cut into 16-byte chunks, chunk ci = row * RPG + part, and lane r of the window
 // loads chunks r, r + WS, ...: consecutive lanes read consecutive pieces of a row.  convert_rows parks the
-// chunks in LDS (row pitch 48 bytes: conflict-free 16-byte reads at any row offset) and every lane reads
+// chunks in LDS (row pitch an odd number of 16-byte units: conflict-free 16-byte reads at any row offset) and every lane reads
 // the two rows it interpolates between.
 template <int WS>
 struct CoopGeo {
 #ifndef TPIV_COOP
 #define TPIV_COOP 1
 #endif
-    static constexpr bool ON = TPIV_COOP && (WS == 16 || WS == 32);
+    static constexpr bool ON = TPIV_COOP && (WS == 16 || WS == 32 || WS == 64);
     static constexpr int NROW = WS + 1;                       // patch rows
     static constexpr int RPG = (WS + 1 + 15) / 16;            // 16-byte chunks loaded per row
     static constexpr int LOADED = 16 * RPG;                   // bytes loaded per row
     static constexpr int T = NROW * RPG;                      // chunks per patch
     static constexpr int NCH = (T + WS - 1) / WS;             // chunks per lane
-    static constexpr int PITCH4 = 3;                          // LDS row pitch in 16-byte units
+    static constexpr int PITCH4 = RPG | 1;                    // LDS row pitch in 16-byte units (odd: see above)
     static constexpr int PATCH4 = NROW * PITCH4;              // 16-byte units per patch
     static constexpr int FLOATS = (64 / WS) * 2 * PATCH4 * 4; // all patches of a wavefront, in floats
     static constexpr int LDS_FLOATS = FLOATS + (64 / WS) * (WS + 1) * 4;      // + the x-weight tables
@@ -471,9 +471,13 @@ struct CoopGeo {
         if constexpr (RPG == 2) {
             j = ci >> 1;
             part = ci & 1;
-        } else {
+        } else if constexpr (RPG == 3) {
             j = (ci * 171) >> 9;                              // ci / 3 for ci < 171
             part = ci - 3 * j;
+        } else {
+            static_assert(RPG == 5, "chunks per row");
+            j = (ci * 205) >> 10;                             // ci / 5 for ci < 404
+            part = ci - 5 * j;
         }
     }
 };
@@ -779,6 +783,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         using CG = CoopGeo<WS>;
         if (raw.reg) {
             uint32_t ra0[NB], ra1[NB], rb0[NB], rb1[NB];
+            const uint4 *lz0 = nullptr, *lz1 = nullptr, *lz2 = nullptr, *lz3 = nullptr;
             if constexpr (CG::ON) {
                 // the chunks go to LDS, the lane's rows come back (same wavefront: program order is enough)
                 uint4* pl = reinterpret_cast<uint4*>(lds);
@@ -813,16 +818,37 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                     }
                     d[NB - 1] = reinterpret_cast<const uint32_t*>(src)[NB - 1];          // NB = 4 m + 1
                 };
-                fetch(s0, ra0);
-                fetch(s1, ra1);
-                fetch(s2, rb0);
-                fetch(s3, rb1);
-                if (raw.fix) {            // border windows: rows entirely outside the frame
+                if (raw.fix) {
+                    // border windows: a source row entirely outside the frame reads the first / last pixel of the
+                    // frame everywhere (flat-index clamp).  Its chunks were loaded from the start / the end of the
+                    // frame; the lanes that use such a row overwrite it with that pixel (several lanes may write
+                    // the same row: same bytes, and the pixel survives the overwrite)
                     constexpr int LAST = CG::LOADED / 4 - 1;       // dword that holds the last loaded byte
-                    fix_row(ra0, raw.cls & 3, reinterpret_cast<const uint32_t*>(s0)[LAST]);
-                    fix_row(ra1, (raw.cls >> 2) & 3, reinterpret_cast<const uint32_t*>(s1)[LAST]);
-                    fix_row(rb0, (raw.cls >> 4) & 3, reinterpret_cast<const uint32_t*>(s2)[LAST]);
-                    fix_row(rb1, (raw.cls >> 6) & 3, reinterpret_cast<const uint32_t*>(s3)[LAST]);
+                    auto fix_lds = [&](const uint4* src, int cls) TPIV_LAMBDA_INLINE {
+                        if (cls != 0) {
+                            const uint32_t* sw = reinterpret_cast<const uint32_t*>(src);
+                            const uint32_t px = (cls == 1 ? (sw[0] & 0xffu) : (sw[LAST] >> 24)) * 0x01010101u;
+                            uint4* dst = const_cast<uint4*>(src);
+#pragma unroll
+                            for (int q = 0; q < CG::RPG; ++q) dst[q] = make_uint4(px, px, px, px);
+                        }
+                    };
+                    fix_lds(s0, raw.cls & 3);
+                    fix_lds(s1, (raw.cls >> 2) & 3);
+                    fix_lds(s2, (raw.cls >> 4) & 3);
+                    fix_lds(s3, (raw.cls >> 6) & 3);
+                    wave_sync();
+                }
+                // (64x64, fast form: the rows come out of LDS 16 pixels at a time inside the sampling loop --
+                //  four whole rows are 68 registers next to the 128 of the samples)
+                constexpr bool LAZY = FAST && WS == 64;
+                if constexpr (LAZY) {
+                    lz0 = s0, lz1 = s1, lz2 = s2, lz3 = s3;
+                } else {
+                    fetch(s0, ra0);
+                    fetch(s1, ra1);
+                    fetch(s2, rb0);
+                    fetch(s3, rb1);
                 }
             } else {
 #pragma unroll
@@ -856,11 +882,30 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
             if constexpr (FAST) {
                 // rows first, then columns: the WS + 1 column values of the row lerp are each used by two
                 // output samples (130 instead of 192 multiply/add instructions per frame and lane)
+                constexpr bool LAZY = CG::ON && WS == 64;
+                auto pull = [&](auto qc) TPIV_LAMBDA_INLINE {      // 16-byte unit q of the four rows (or the last dword)
+                    constexpr int q = decltype(qc)::value;
+                    auto one = [&](const uint4* src, uint32_t (&d)[NB]) TPIV_LAMBDA_INLINE {
+                        if constexpr (4 * q + 3 < NB) {
+                            const uint4 t = src[q];
+                            d[4 * q] = t.x, d[4 * q + 1] = t.y, d[4 * q + 2] = t.z, d[4 * q + 3] = t.w;
+                        } else {
+                            d[NB - 1] = reinterpret_cast<const uint32_t*>(src)[NB - 1];
+                        }
+                    };
+                    one(lz0, ra0), one(lz1, ra1), one(lz2, rb0), one(lz3, rb1);
+                };
+                if constexpr (LAZY) {
+                    pull(std::integral_constant<int, 0>{});
+                    pull(std::integral_constant<int, 1>{});
+                }
                 float va = fmaf(byte_f<0, NB>(ra1), c.wya_dn, byte_f<0, NB>(ra0) * c.wya_up);
                 float vb = fmaf(byte_f<0, NB>(rb1), c.wyb_dn, byte_f<0, NB>(rb0) * c.wyb_up);
                 static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int k = decltype(kc)::value;
                     if constexpr (k % 8 == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
+                    // dwords 4b .. 4b + 4 serve pixels 16b .. 16b + 15 (+1): unit b + 1 arrives at pixel 16b
+                    if constexpr (LAZY && k % 16 == 0 && k > 0) pull(std::integral_constant<int, k / 16 + 1>{});
                     const float4 wx = wbuf[k];
                     const float na = fmaf(byte_f<k + 1, NB>(ra1), c.wya_dn, byte_f<k + 1, NB>(ra0) * c.wya_up);
                     const float nb = fmaf(byte_f<k + 1, NB>(rb1), c.wyb_dn, byte_f<k + 1, NB>(rb0) * c.wyb_up);
