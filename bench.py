@@ -83,7 +83,7 @@ def parse_args():
     ap.add_argument("--e2e", action="store_true",
                     help="end-to-end generator mode instead of the kernel-path bench: ResidentPIV / OfflinePIV.batched incl. "
                          "device post-validation, counted host fallbacks, BMP ingest (one JSON line, N = 1)")
-    ap.add_argument("--e2e-pairs", type=int, default=128)
+    ap.add_argument("--e2e-pairs", type=int, default=256)
     ap.add_argument("--fill-workers", type=int, default=8)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()

@@ -48,7 +48,7 @@ def rate(gen, n):
     return n / dt, k
 
 
-def main(n=128, H=2048, W=2048, batch=32, workers=0):
+def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0):
     out = {}
     for kind in ("clean", "runs", "spots"):
         A, B = make_frames(n, H, W, kind)
@@ -67,6 +67,8 @@ def main(n=128, H=2048, W=2048, batch=32, workers=0):
                 Image.fromarray(B[i].cpu().numpy(), "L").save(os.path.join(d, f"img{i:04d}_b.bmp"))
             fp = T.OfflinePIV(d, "cuda:0", "bmp", 64, 32, multipass=2, multipass_mode="CWS")
             fp.fill_workers = workers
+            if read_threads:
+                fp.read_threads = read_threads
             rate(fp.batched(batch), n)
             fp.reset_stats()
             r, k = rate(fp.batched(batch), n)
@@ -80,4 +82,5 @@ def main(n=128, H=2048, W=2048, batch=32, workers=0):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else 128, workers=int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else 128, workers=int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+         read_threads=int(sys.argv[3]) if len(sys.argv) > 3 else 0)

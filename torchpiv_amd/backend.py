@@ -410,6 +410,7 @@ class OfflinePIV:
         if getattr(self, "_plan", None) is not None:
             self._plan.close()
             self._plan = None
+        self._stage, self._stage_key = None, None
 
     def _post_submit(self, u, v, inv):
         """Device half of B:884-892 for a batch of final fields (u, v float64 [n, nr, nc], modified in
@@ -533,7 +534,13 @@ class OfflinePIV:
         # and a headerless frame, rounded up to 4 KiB
         sizes = [H * W] + [_os.path.getsize(p_) for p_ in self._dataset.img_pairs[first[0]] if _os.path.exists(p_)]
         cap = (max(sizes) + 4095) // 4096 * 4096
-        stage = [torch.empty(2 * batch_size, cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        # (page-locking half a gigabyte takes a tenth of a second: the staging buffers are kept for the next call)
+        key = (batch_size, cap)
+        prev = getattr(self, "_loader", None)            # (an abandoned generator may have left its loader running)
+        if getattr(self, "_stage_key", None) != key or (prev is not None and prev.is_alive()):
+            self._stage = [torch.empty(2 * batch_size, cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self._stage_key = key
+        stage = self._stage
         free = [threading.Event(), threading.Event()]
         for e in free:
             e.set()
@@ -573,6 +580,7 @@ class OfflinePIV:
 
         th = threading.Thread(target=loader, daemon=True)
         th.start()
+        self._loader = th
         w, o, _, _ = plan.geometry[-1]
         x, y = get_coordinates((H, W), w, o)
         dev = self._device
