@@ -632,9 +632,6 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         const int qb0 = dyb * W_ + xb, qb1 = uyb * W_ + xb;
         using CG = CoopGeo<WS>;
         constexpr int LOADED = CG::ON ? CG::LOADED : 4 * NB;       // bytes a row load reads
-        int la0, la1, lb0, lb1;
-        const int c0 = classify_row32(qa0, WS + 1, LOADED, HW, la0), c1 = classify_row32(qa1, WS + 1, LOADED, HW, la1);
-        const int c2 = classify_row32(qb0, WS + 1, LOADED, HW, lb0), c3 = classify_row32(qb1, WS + 1, LOADED, HW, lb1);
         // (FAST: an integral row coordinate -- B:170, B:193 return the nearest sample -- is left to the
         //  per-pixel path, which implements the quirk; the lerp form of convert_rows does not)
         const float gxr = (float)(g.x0 + r);
@@ -642,8 +639,14 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
         const float fxa_r = floorf(nxa_r), fxb_r = floorf(nxb_r);
         const bool col_ok = fxa_r == (float)(g.x0 + r - ivx - 1) && fxb_r == (float)(g.x0 + r + ivx) &&
                             fxa_r != nxa_r && fxb_r != nxb_r;
-        bool reg = c0 != 3 && c1 != 3 && c2 != 3 && c3 != 3 && col_ok &&
-                   fabsf(vx) < (float)p.W && !(FAST && (c.ydeg_a | c.ydeg_b));
+        bool reg = col_ok && fabsf(vx) < (float)p.W && !(FAST && (c.ydeg_a | c.ydeg_b));
+        int la0 = 0, la1 = 0, lb0 = 0, lb1 = 0, cls = 0;
+        auto classify_own = [&]() TPIV_LAMBDA_INLINE {       // the lane's four rows under the flat-index clamp
+            const int c0 = classify_row32(qa0, WS + 1, LOADED, HW, la0), c1 = classify_row32(qa1, WS + 1, LOADED, HW, la1);
+            const int c2 = classify_row32(qb0, WS + 1, LOADED, HW, lb0), c3 = classify_row32(qb1, WS + 1, LOADED, HW, lb1);
+            reg = reg && c0 != 3 && c1 != 3 && c2 != 3 && c3 != 3;
+            cls = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
+        };
         if constexpr (CG::ON) {
             // the window's patches start at the (clamped) lower source row of its row 0; a lane's two rows must
             // lie inside them (they do unless float32 rounding makes the row coordinates jump)
@@ -652,17 +655,20 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
             const int base_b = clamp_i(f2i_sat_t(floorf(gy0f + vy)), rlo, rhi);
             reg = reg && (unsigned)(dya - base_a) <= (unsigned)WS && (unsigned)(uya - base_a) <= (unsigned)WS &&
                   (unsigned)(dyb - base_b) <= (unsigned)WS && (unsigned)(uyb - base_b) <= (unsigned)WS;
-            raw.reg = __all(reg) ? 1 : 0;
-            raw.cls = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
-            raw.fix = (raw.reg && __any(raw.cls != 0)) ? 1 : 0;
             // Wavefronts whose patches lie inside the frame with LOADED bytes to spare in every row (all but the
-            // border windows) add the loop-invariant chunk offsets to the patch origin; the others classify
-            // every chunk's row like a lane's own rows (the first version did that always: +160 VALU
-            // instructions per item).  Only ADDRESSES differ between the branches: the loads stay unconditional.
-            unsigned oa[CG::NCH], ob[CG::NCH];
+            // border windows) add the loop-invariant chunk offsets to the patch origin -- and every row a lane
+            // may use is an ordinary row (class 0); the others classify every chunk's row like a lane's own rows
+            // (the first version did that always: +160 VALU instructions per item).  Only ADDRESSES differ
+            // between the branches: the loads stay unconditional.
             const bool inside = base_a >= 0 && base_a + WS < p.H && base_b >= 0 && base_b + WS < p.H &&
                                 xa >= 0 && xa + LOADED <= W_ && xb >= 0 && xb + LOADED <= W_;
-            if (__all(inside)) {
+            const bool all_in = __all(inside);
+            if (!all_in) classify_own();
+            raw.reg = __all(reg) ? 1 : 0;
+            raw.cls = cls;
+            raw.fix = (raw.reg && __any(raw.cls != 0)) ? 1 : 0;
+            unsigned oa[CG::NCH], ob[CG::NCH];
+            if (all_in) {
                 const int qa_o = base_a * W_ + xa, qb_o = base_b * W_ + xb;
 #pragma unroll
                 for (int k = 0; k < CG::NCH; ++k) {
@@ -690,8 +696,9 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
                 load_dwords<4>(fb + ob[k], raw.cb[k]);
             }
         } else {
+        classify_own();
         raw.reg = __all(reg) ? 1 : 0;
-        raw.cls = c0 | (c1 << 2) | (c2 << 4) | (c3 << 6);
+        raw.cls = cls;
         raw.fix = (raw.reg && __any(raw.cls != 0)) ? 1 : 0;
         const int lim = HW - 4 * NB;
         const int base32 = (g.y0 + r) * W_ + g.x0;
