@@ -25,7 +25,9 @@ cfg() {   # name, quick_bench args
     rocprofv3 --kernel-trace --stats --output-format csv $R -d $OUT/other_configs/$name.prof -- python3 tools/quick_bench.py "$@" > /dev/null 2> $OUT/other_configs/$name.err
     cp $OUT/other_configs/$name.prof/*/*_kernel_stats.csv $OUT/other_configs/${name}_kernel_stats.csv; rm -rf $OUT/other_configs/$name.prof
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv --kernel-include-regex "xcorr|predict" -d $OUT/other_configs/$name.pmc -- python3 tools/quick_bench.py "$@" --iters 2 > /dev/null 2>> $OUT/other_configs/$name.err
-    python3 tools/pmc_summary.py $OUT/other_configs/$name.pmc > $OUT/other_configs/${name}_pmc.txt; rm -rf $OUT/other_configs/$name.pmc
+    # matrix-core utilisation of the predictor kernels (predict_mfma.hip)
+    rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv --kernel-include-regex "predict" -d $OUT/other_configs/$name.pmc2 -- python3 tools/quick_bench.py "$@" --iters 2 > /dev/null 2>> $OUT/other_configs/$name.err
+    python3 tools/pmc_summary.py $OUT/other_configs/$name.pmc $OUT/other_configs/$name.pmc2 > $OUT/other_configs/${name}_pmc.txt; rm -rf $OUT/other_configs/$name.pmc $OUT/other_configs/$name.pmc2
     cat $OUT/other_configs/$name.txt
 }
 cfg cfg3_4096_32_16_8 --size 4096 --ws 32 --passes 3 --mode CWS --batch 16
