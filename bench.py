@@ -236,7 +236,8 @@ def e2e_mode(args):
            "value": r["spots"], "unit": "pairs/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
            "config": {"workload": f"{args.e2e_pairs} synthetic 2048x2048 pairs, batch 32, {args.fill_workers} Qhull worker processes",
                       "cases": {"resident_clean_all_dropped": r["clean"], "resident_straight_runs": r["runs"],
-                                "resident_isolated_spots": r["spots"], "bmp_files_isolated_spots": r.get("files")}},
+                                "resident_isolated_spots": r["spots"], "bmp_files_isolated_spots": r.get("files"),
+                                "bmp_files_generator_call": r.get("files_call")}},
            "log": log.getvalue().strip().splitlines()}
     print(json.dumps(rec), flush=True)
 

@@ -185,3 +185,38 @@ def test_run_sharded_single_process(folder, golden):
     ids, (x, y), uv = pdist.run_sharded(piv, batch_size=2)
     assert ids.tolist() == [0, 1, 2, 3] and uv.shape[1] == 2
     assert _close(uv[0, 0] / 1000, g["r4_0_u"] / 1000) and _close(uv[1, 1] / 1000, g["r4_1_v"] / 1000)
+
+
+def test_generator_reads_ahead_like_the_one_pair_loop(tmp_path):
+    """__call__ runs `call_batch` pairs per launch; what it yields must be what the reference-literal loop
+    (call_batch = 1) yields: same pairs, same order, same fields -- also when a file is undecodable (pair
+    skipped, B:138-139), when a pair has another frame shape (its own plan) and when a batch holds nothing
+    stageable."""
+    from PIL import Image
+    import torchpiv_amd as T
+    from torchpiv_amd import synth
+    shapes = [(512, 640)] * 3 + [(448, 576)] + [(512, 640)] * 3 + [(448, 576), (448, 576)]
+    for i, (h, w) in enumerate(shapes):
+        a, b = synth.make_pair(h, w, 70 + i, kind=("wavy", "vortex", "shear")[i % 3], noise=2.0)
+        a, b = a.numpy().copy(), b.numpy().copy()
+        a[140:170, 150:220] = 0         # dead windows: the pair has invalid vectors and is not dropped as "clean"
+        b[140:170, 150:220] = 0
+        Image.fromarray(a, "L").save(tmp_path / f"im{i:02d}_a.bmp")
+        Image.fromarray(b, "L").save(tmp_path / f"im{i:02d}_b.bmp")
+    (tmp_path / "im01_b.bmp").write_bytes(b"BMnot an image at all")          # undecodable: pair 1 is skipped
+    kw = dict(wind_size=32, overlap=16, multipass=1, multipass_mode="CWS", scale=0.5, dt=2)
+
+    def run(call_batch):
+        piv = T.OfflinePIV(str(tmp_path), "cuda:0", "bmp", **kw)
+        piv.call_batch = call_batch
+        out = [tuple(np.array(t) for t in r) for r in piv()]
+        piv.close()
+        return out
+
+    ref = run(1)
+    assert len(ref) >= 4 and len({r[2].shape for r in ref}) == 2          # (dropped pairs aside) both shapes yield
+    for cb in (2, 4, 16):
+        got = run(cb)
+        assert len(got) == len(ref)
+        for g_, r_ in zip(got, ref):
+            assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(g_, r_)), cb

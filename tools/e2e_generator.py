@@ -75,7 +75,11 @@ def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0):
             out["files"] = r
             print(f"files    {kind:6s}: {r:8.1f} pairs/s ({k} of {n} yielded; 8-bit BMP in the page cache)  {fp.stats}")
             r, k = rate(fp(), n)
-            print(f"files    __call__ (one pair per launch): {r:8.1f} pairs/s")
+            out["files_call"] = r
+            print(f"files    __call__ (the reference's generator API; reads ahead {fp.call_batch} pairs per launch): {r:8.1f} pairs/s")
+            fp.call_batch = 1
+            r, k = rate(fp(), n)
+            print(f"files    __call__ with call_batch = 1 (one pair per launch, host decode): {r:8.1f} pairs/s")
         piv.close()
         del A, B
     return out

@@ -411,6 +411,8 @@ class OfflinePIV:
             self._plan.close()
             self._plan = None
         self._stage, self._stage_key = None, None
+        for pl in self.__dict__.pop("_single_plans", {}).values():
+            pl.close()
 
     def _post_submit(self, u, v, inv):
         """Device half of B:884-892 for a batch of final fields (u, v float64 [n, nr, nc], modified in
@@ -483,22 +485,43 @@ class OfflinePIV:
         v = v * self._scale / self._dt * 1000
         return x * self._scale, y * self._scale, u, v
 
+    # pairs per launch of __call__ (extension): the generator of the reference's API reads ahead and runs
+    # `call_batch` pairs through batched(); the fields it yields, their order and the dropped pairs are those of
+    # the one-pair-per-launch loop (call_batch = 1, the reference's B:868-901 literally)
+    call_batch = 16
+
+    def _one(self, i):
+        """Pair i alone: decode on the host, one launch per pass, post-validation, flip / scale (B:868-898).
+        None for an undecodable or dropped pair.  Plans of this path are kept per frame shape."""
+        a, b = self._dataset[i]
+        if a is None or b is None:
+            return None
+        a = a.to(self._device, non_blocking=True)
+        b = b.to(self._device, non_blocking=True)
+        shape = (int(a.shape[-2]), int(a.shape[-1]))
+        plans = self.__dict__.setdefault("_single_plans", {})
+        plan = plans.get(shape)
+        if plan is None:
+            plan = plans[shape] = engine.Plan(shape[0], shape[1], int(self._wind_size), int(self._overlap),
+                                              n_pass=max(1, int(self._iter)), mode=self._mode,
+                                              pass_scale=self._iter_scale, max_batch=1, device=self._device,
+                                              precision=self._precision)
+        u, v, inv = plan.run(a, b)
+        w, o, _, _ = plan.geometry[-1]
+        x, y = get_coordinates(shape, w, o)
+        return self._finish(self._post_validate_batch(u, v, inv)[0], x, y)
+
     def __call__(self) -> Generator:
+        if int(self.call_batch) > 1 and len(self._dataset) > 1:
+            for _, x, y, u, v in self.batched(int(self.call_batch)):
+                yield x, y, u, v
+            return
         end_time = time()
         for i in range(len(self._dataset)):
-            a, b = self._dataset[i]
-            if a is None or b is None:
-                continue
             if self.verbose:
                 print(f"Load time {(time() - end_time):.3f} sec", end=" ")
             start = time()
-            a = a.to(self._device, non_blocking=True)
-            b = b.to(self._device, non_blocking=True)
-            plan = self._get_plan(a.shape[-2], a.shape[-1])
-            u, v, inv = plan.run(a, b)
-            w, o, _, _ = plan.geometry[-1]
-            x, y = get_coordinates(a.shape, w, o)
-            out = self._finish(self._post_validate_batch(u, v, inv)[0], x, y)
+            out = self._one(i)
             if out is None:
                 continue
             yield out
@@ -506,7 +529,6 @@ class OfflinePIV:
             if self.verbose:
                 print(f"Batch finished in {(end_time - start):.3f} sec")
 
-    # ---- extension: batched processing (same results, many pairs per launch) ------------
     def batched(self, batch_size: int = 32, indices=None) -> Generator:
         """Like __call__, but reads, uploads and processes `batch_size` pairs per launch.  A loader
         thread puts the next batch's files into pinned staging memory -- uncompressed BMPs as their RAW
@@ -563,18 +585,22 @@ class OfflinePIV:
                             pa, pb = self._dataset.img_pairs[i][0], self._dataset.img_pairs[i][-1]
                             tasks += [(pb, raw[2 * k + 1]), (pa, raw[2 * k])]       # (the reference reads b first)
                         lays = list(ex.map(lambda t: stage_raw(t[0], t[1], H, W), tasks))
-                        chunk, desc_a, desc_b, lut_a, lut_b = [], [], [], [], []
+                        chunk, desc_a, desc_b, lut_a, lut_b, order = [], [], [], [], [], []
                         for k, i in enumerate(ids):
                             lb, la = lays[2 * k], lays[2 * k + 1]
+                            order.append((i, la is not None and lb is not None))
                             if la is None or lb is None:
-                                continue                                 # undecodable: pair skipped (B:138-139)
+                                # not stageable (undecodable, or a frame shape other than the batch's): the pair
+                                # takes the one-pair path when its turn comes -- which skips an undecodable
+                                # pair like B:138-139 and gives another shape its own plan
+                                continue
                             desc_a.append([2 * k * cap, la[0], la[1], la[2], la[3], 0])
                             desc_b.append([(2 * k + 1) * cap, lb[0], lb[1], lb[2], lb[3], 0])
                             lut_a.append(la[4])
                             lut_b.append(lb[4])
                             chunk.append(i)
                         # unpacked frame order: every a of the batch, then every b (two contiguous stacks)
-                        q.put((buf, len(ids), chunk, desc_a + desc_b, lut_a + lut_b))
+                        q.put((buf, len(ids), chunk, desc_a + desc_b, lut_a + lut_b, order))
             finally:
                 q.put(None)
 
@@ -585,38 +611,43 @@ class OfflinePIV:
         x, y = get_coordinates((H, W), w, o)
         dev = self._device
         pending = None
+
+        def drain(pend):
+            """Results of a finished batch in dataset order; the pairs that were not staged run now."""
+            order, chunk, ticket = pend
+            res = iter(self._post_collect(ticket)) if chunk else iter(())
+            for i, staged in order:
+                out = self._finish(next(res), x, y) if staged else self._one(i)
+                if out is not None:
+                    yield (i,) + out
+
         while True:
             item = q.get()
             if item is None:
                 break
-            buf, n_slots, chunk, desc, luts = item
-            if not chunk:
-                free[buf].set()
-                continue
-            n = len(chunk)
-            raw_d = stage[buf][:2 * n_slots].to(dev, non_blocking=True)
-            up = torch.cuda.Event()
-            up.record()
-            desc_d = torch.tensor(desc, dtype=torch.int64).to(dev, non_blocking=True)
-            lut_d = torch.from_numpy(np.stack(luts)).to(dev, non_blocking=True)
-            frames = engine.bmp_unpack(raw_d.view(-1), desc_d, lut_d, H, W)      # [2n, H, W]: a_0..a_n-1, b_0..b_n-1
-            u, v, inv = plan.run(frames[:n], frames[n:])
-            ticket = self._post_submit(u, v, inv)
+            buf, n_slots, chunk, desc, luts, order = item
+            ticket = None
+            if chunk:
+                n = len(chunk)
+                raw_d = stage[buf][:2 * n_slots].to(dev, non_blocking=True)
+                up = torch.cuda.Event()
+                up.record()
+                desc_d = torch.tensor(desc, dtype=torch.int64).to(dev, non_blocking=True)
+                lut_d = torch.from_numpy(np.stack(luts)).to(dev, non_blocking=True)
+                frames = engine.bmp_unpack(raw_d.view(-1), desc_d, lut_d, H, W)      # [2n, H, W]: a_0..a_n-1, b_0..b_n-1
+                u, v, inv = plan.run(frames[:n], frames[n:])
+                ticket = self._post_submit(u, v, inv)
             # the host work of the PREVIOUS batch runs while the GPU works on this one
             if pending is not None:
-                for i, uv in zip(pending[0], self._post_collect(pending[1])):
-                    out = self._finish(uv, x, y)
-                    if out is not None:
-                        yield (i,) + out
-            pending = (chunk, ticket)
-            up.synchronize()                  # staging buffer may be refilled now
+                yield from drain(pending)
+            pending = (order, chunk, ticket)
+            if chunk:
+                up.synchronize()                  # staging buffer may be refilled now
             free[buf].set()
         if pending is not None:
-            for i, uv in zip(pending[0], self._post_collect(pending[1])):
-                out = self._finish(uv, x, y)
-                if out is not None:
-                    yield (i,) + out
+            yield from drain(pending)
         th.join()
+
 
 class ResidentPIV(OfflinePIV):
     """OfflinePIV over frame pairs that already live on the GPU (uint8 tensors [n, H, W]): the same
