@@ -392,6 +392,44 @@ def g8_round2():
     save("g8_round2", **out)
 
 
+# ------------------------------------------------- G11 other multipass scales / zero overlap
+SCALE_CASES = [
+    # name, H, W, ws, ov, scale, n_pass, kind, noise, special, index
+    ("s15x3", 330, 420, 64, 32, 1.5, 3, "wavy", 2.0, False, 80),      # 64/32 -> 42/21 -> 28/14 (generic sizes, shifted)
+    ("s4x2", 300, 400, 64, 32, 4.0, 2, "vortex", 2.0, True, 81),      # 64/32 -> 16/8
+    ("ov0x2", 256, 320, 32, 0, 2.0, 2, "shear", 2.0, False, 82),      # 32/0 -> 16/0 (no overlap)
+]
+
+
+def g11_scales():
+    """Per-pass fields of multipass runs with multipass_scale != 2 (window sizes int(ws // scale): generic
+    sizes in shifted passes) and with zero overlap, both modes -- iteration objects built as B:853-857 does."""
+    out = {}
+    names = []
+    for (name, H, W, ws, ov, scale, n_pass, kind, noise, special, index) in SCALE_CASES:
+        a, b = make_frames(H, W, kind, noise, special, index)
+        names.append(name)
+        out[name + "_a"], out[name + "_b"] = a.numpy(), b.numpy()
+        out[name + "_cfg"] = np.array([ws, ov, n_pass])
+        out[name + "_scale"] = np.array([scale])
+        for mode in ("DWS", "CWS"):
+            u, v, x, y, val = ref.extended_search_area_piv(a, b, window_size=ws, overlap=ov, validate=True)
+            out[f"{name}_{mode}_p0_u"], out[f"{name}_{mode}_p0_v"], out[f"{name}_{mode}_p0_val"] = u, v, val
+            w, o = ws, ov
+            geo = [(w, o)]
+            for p in range(1, n_pass):
+                w, o = int(w // scale), int(o // scale)
+                geo.append((w, o))
+                it = ref.IterModMap.functions[mode](a.shape, w, o, torch.device("cpu"))
+                u, v, x, y, val = it(a, b, x, y, u.copy(), v.copy(), val.copy())
+                out[f"{name}_{mode}_p{p}_u"], out[f"{name}_{mode}_p{p}_v"] = u.copy(), v.copy()
+                out[f"{name}_{mode}_p{p}_val"] = val.copy()
+                print(f"\n  {name} {mode} pass {p} ({w}/{o}): grid {u.shape} invalid {int(val.sum())}")
+        out[name + "_geo"] = np.array(geo)
+    out["names"] = np.array(names)
+    save("g11_scales", **out)
+
+
 # ------------------------------------------------- G10 piv_iteration_CWS_Fast (SURVEY 8f-4)
 def g10_cws_fast():
     """The reference's bicubic window-deformation iteration (B:599-675), which OfflinePIV cannot reach
@@ -425,6 +463,9 @@ if __name__ == "__main__":
     if only == "g10":
         g10_cws_fast()
         raise SystemExit(0)
+    if only == "g11":
+        g11_scales()
+        raise SystemExit(0)
     if only == "g7":
         g7_generic()
     elif only == "g8":
@@ -438,3 +479,4 @@ if __name__ == "__main__":
         g7_generic()
         g8_round2()
         g10_cws_fast()
+        g11_scales()

@@ -416,6 +416,19 @@ def test_odd_window_in_a_shifted_pass(eng, golden, mode):
                       noise_ulps=16.0 if precision == "reference" else 4096.0)
 
 
+@pytest.mark.parametrize("precision", ["reference", "fast"])
+@pytest.mark.parametrize("mode", ["DWS", "CWS"])
+def test_other_scales_and_zero_overlap(eng, golden, mode, precision):
+    """Whole plans at multipass_scale 1.5 (64/32 -> 42/21 -> 28/14: generic sizes in shifted passes), 4.0
+    (64/32 -> 16/8) and with zero overlap (32/0 -> 16/0) against the reference's fields of every pass
+    (golden g11), by the threshold-free cascade rule."""
+    g = golden("g11_scales")
+    for name in g["names"]:
+        geo = [tuple(int(t) for t in row) for row in g[name + "_geo"]]
+        cascade_check(eng, g, str(name), mode, precision, geo, scale=float(g[name + "_scale"][0]),
+                      noise_ulps=16.0 if precision == "reference" else 4096.0)
+
+
 def test_cws_fast_iteration_golden(eng, golden):
     """piv_iteration_CWS_Fast (B:599-675; bicubic resampling of each window inside itself) through the
     drop-in class, against the reference's own output and with the oracle's staged windows for the noise band."""

@@ -154,6 +154,26 @@ def test_round2_goldens(golden):
         assert np.allclose(v, g[f"r5_{j}_v"], rtol=0, atol=1e-9, equal_nan=True)
 
 
+@pytest.mark.parametrize("mode", ["DWS", "CWS"])
+def test_other_scales_and_zero_overlap(golden, mode):
+    """g11: multipass_scale 1.5 (64/32 -> 42/21 -> 28/14), 4.0 (64/32 -> 16/8) and zero overlap (32/0 -> 16/0)."""
+    g = golden("g11_scales")
+    for name in g["names"]:
+        ws, ov, n_pass = (int(t) for t in g[name + "_cfg"])
+        scale = float(g[name + "_scale"][0])
+        a, b = g[name + "_a"], g[name + "_b"]
+        u, v, x, y, val = O.pass1(a, b, ws, ov, validate=True)
+        assert np.abs(u - g[f"{name}_{mode}_p0_u"]).max() <= TOL
+        w, o = ws, ov
+        for p in range(1, n_pass):
+            w, o = int(w // scale), int(o // scale)
+            assert [w, o] == [int(t) for t in g[name + "_geo"][p]]
+            u, v, x, y, val = O.ITER[mode](a.shape, w, o)(a, b, x, y, u.copy(), v.copy(), val.copy())
+            assert np.abs(u - g[f"{name}_{mode}_p{p}_u"]).max() <= 1e-9, (name, p)
+            assert np.abs(v - g[f"{name}_{mode}_p{p}_v"]).max() <= 1e-9, (name, p)
+            assert np.array_equal(val, g[f"{name}_{mode}_p{p}_val"]), (name, p)
+
+
 def test_cws_fast_iteration(golden):
     """piv_iteration_CWS_Fast (B:599-675, unreachable from the reference's own OfflinePIV): the oracle's
     restatement against the reference's output."""
