@@ -352,6 +352,7 @@ class OfflinePIV:
         self._iter_function = IterModMap.functions[multipass_mode]      # KeyError like B:850
         self._mode = multipass_mode
         self._plan = None
+        self._single_plans = {}          # plans of the one-pair path, per frame shape
         self.reset_stats()
         if not self:
             return
@@ -411,8 +412,9 @@ class OfflinePIV:
             self._plan.close()
             self._plan = None
         self._stage, self._stage_key = None, None
-        for pl in self.__dict__.pop("_single_plans", {}).values():
+        for pl in getattr(self, "_single_plans", {}).values():
             pl.close()
+        self._single_plans = {}
 
     def _post_submit(self, u, v, inv):
         """Device half of B:884-892 for a batch of final fields (u, v float64 [n, nr, nc], modified in
@@ -499,7 +501,7 @@ class OfflinePIV:
         a = a.to(self._device, non_blocking=True)
         b = b.to(self._device, non_blocking=True)
         shape = (int(a.shape[-2]), int(a.shape[-1]))
-        plans = self.__dict__.setdefault("_single_plans", {})
+        plans = self._single_plans
         plan = plans.get(shape)
         if plan is None:
             plan = plans[shape] = engine.Plan(shape[0], shape[1], int(self._wind_size), int(self._overlap),
