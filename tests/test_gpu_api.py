@@ -157,10 +157,19 @@ def test_function_seam_signatures(golden):
         it = T.IterModMap.functions[mode](a.shape, ws // 2, ov // 2, "cuda:0")
         u2, v2, x2, y2, val2 = it(a, b, x, y, g[f"{name}_{mode}_p0_u"].copy(), g[f"{name}_{mode}_p0_v"].copy(),
                                   g[f"{name}_{mode}_p0_val"].copy())
-        same = val2 == g[f"{name}_{mode}_p1_val"]
-        assert same.mean() > 0.99
-        err = np.maximum(np.abs(u2 - g[f"{name}_{mode}_p1_u"]), np.abs(v2 - g[f"{name}_{mode}_p1_v"]))
-        assert (err[same] < 1e-3).mean() > 0.99, mode
+        # exactly what the engine-level calls give (their parity with the reference is the strict per-pass test
+        # test_iteration_golden_per_pass): same operators, same kernels, nothing in between
+        from torchpiv_amd import engine as E
+        H_, W_ = a.shape
+        xc, yc = E.coordinates_1d(H_, W_, ws, ov)
+        xf, yf = E.coordinates_1d(H_, W_, ws // 2, ov // 2)
+        dv = lambda t: torch.from_numpy(np.ascontiguousarray(t)).cuda()
+        pu0, pv0, pu2, pv2 = E.predict(mode, dv(E.spline_matrix(yc, yf)), dv(E.spline_matrix(xc, xf)),
+                                       dv(g[f"{name}_{mode}_p0_u"])[None], dv(g[f"{name}_{mode}_p0_v"])[None],
+                                       dv(g[f"{name}_{mode}_p0_val"].astype(np.uint8))[None])
+        eu, ev, einv = E.iterate(mode, a, b, ws // 2, ov // 2, pu0, pv0, pu2, pv2)
+        assert np.array_equal(u2, eu[0].cpu().numpy()) and np.array_equal(v2, ev[0].cpu().numpy())
+        assert np.array_equal(val2, einv[0].cpu().numpy().astype(bool))
         assert np.array_equal(x2, it.x) and x2.shape == u2.shape
         # validation_mask=None: no peak-ratio test, val stays None (B:707-709)
         u3, v3, _, _, val3 = it(a, b, x, y, g[f"{name}_{mode}_p0_u"].copy(), g[f"{name}_{mode}_p0_v"].copy(), None)
