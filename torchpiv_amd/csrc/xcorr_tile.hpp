@@ -378,11 +378,44 @@ __device__ __forceinline__ void transpose_tile(cf (&a)[WS], float* lds, int lane
 //      real row is Hermitian).  Only lanes kx <= WS/2 write.
 template <int WS, bool PLANAR>
 __device__ __forceinline__ void transpose_half(const cf (&a)[WS], cf (&g)[WS / 2 + 1], float* lds, int lane) {
-    static_assert(WS <= 32, "one tile per window");
+    static_assert(WS <= 32 || (WS == 64 && PLANAR), "one tile per window");
     using G = TileGeo<WS, PLANAR>;
     constexpr int P = G::PITCH, M = WS / 2;
     const int i = lane % WS;
-    if constexpr (PLANAR) {
+    if constexpr (WS == 64) {
+        // 64x64, planar: element (row y, column kx) at y * 33 + kx -- 64 x 33 floats, exactly the two 32x33 tiles;
+        // lanes kx <= 32 write with stride 1, lane y reads with stride 33: conflict-free, and no lane-half swaps
+        constexpr int Q = M + 1;
+        static_assert(WS * Q <= G::LDS_FLOATS, "half-spectrum plane fits the tile");
+        // (the values are pinned in front of the conditional stores: left alone, the compiler sinks the end of the
+        //  column transform into the branch and keeps its inputs alive across it -- 32 spills at the register cap)
+        cf b[WS];
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            b[k] = a[FFT_POS<k, WS>];
+            asm volatile("" : "+v"(b[k].x), "+v"(b[k].y));
+        });
+        wave_sync();
+        if (i <= M) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                lds[k * Q + i] = b[k].x;
+            });
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r <= M; ++r) g[r].x = lds[i * Q + r];
+        wave_sync();
+        if (i <= M) {
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                lds[k * Q + i] = b[k].y;
+            });
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r <= M; ++r) g[r].y = lds[i * Q + r];
+    } else if constexpr (PLANAR) {
         float* t = lds + (lane / WS) * G::HTILE;
         wave_sync();
         if (i <= M) {
@@ -1373,10 +1406,15 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
 #define TPIV_C2R 1
 #endif
         float crow[WS];
-        // (64x64 was tried too, same-box A/B: with complex tiles it needs ~90 more live registers --
-        //  64x64 CWS pass 44.3 -> 49.4 us/pair, DWS 35.4 -> 34.8; the planar three-wavefront variant
-        //  spills 34 registers at its 168-VGPR cap -- pass 1 26.7 -> 29.4 us/pair.  Not kept.)
-        if constexpr (TPIV_C2R && WS <= 32) {
+        // (64x64: the planar three-wavefront kernels take the c2r form too -- round 1 and the first try of round 2
+        //  ended in 32-42 spills at the 168-VGPR cap, which were the compiler sinking the tail of the column
+        //  transform into the conditional stores of transpose_half; with the values pinned in front of the branch
+        //  the kernel keeps its one spill and pass 1 went from 6.94 to 6.42 ms per 256 pairs.  The complex-tile
+        //  64x64 CWS kernel keeps the complex last transform.)
+#ifndef TPIV_C2R64
+#define TPIV_C2R64 1
+#endif
+        if constexpr (TPIV_C2R && (WS <= 32 || (TPIV_C2R64 && WS == 64 && PLANAR))) {
             // the map rows are real: only spectrum columns 0..WS/2 cross the LDS and a WS/2-point complex
             // transform yields the row as z[m] = corr(y, 2m) + i corr(y, 2m + 1)  (c2r_inreg)
             cf hs[WS / 2 + 1], z[WS / 2];
