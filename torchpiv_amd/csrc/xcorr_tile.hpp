@@ -378,7 +378,7 @@ __device__ __forceinline__ void transpose_tile(cf (&a)[WS], float* lds, int lane
 //      real row is Hermitian).  Only lanes kx <= WS/2 write.
 template <int WS, bool PLANAR>
 __device__ __forceinline__ void transpose_half(const cf (&a)[WS], cf (&g)[WS / 2 + 1], float* lds, int lane) {
-    static_assert(WS <= 32 || (WS == 64 && PLANAR), "one tile per window");
+    static_assert(WS <= 32 || WS == 64, "one tile per window");
     using G = TileGeo<WS, PLANAR>;
     constexpr int P = G::PITCH, M = WS / 2;
     const int i = lane % WS;
@@ -386,7 +386,7 @@ __device__ __forceinline__ void transpose_half(const cf (&a)[WS], cf (&g)[WS / 2
         // 64x64, planar: element (row y, column kx) at y * 33 + kx -- 64 x 33 floats, exactly the two 32x33 tiles;
         // lanes kx <= 32 write with stride 1, lane y reads with stride 33: conflict-free, and no lane-half swaps
         constexpr int Q = M + 1;
-        static_assert(WS * Q <= G::LDS_FLOATS, "half-spectrum plane fits the tile");
+        static_assert(WS * Q * (PLANAR ? 1 : 2) <= G::LDS_FLOATS, "half-spectrum plane fits the tile");
         // (the values are pinned in front of the conditional stores: left alone, the compiler sinks the end of the
         //  column transform into the branch and keeps its inputs alive across it -- 32 spills at the register cap)
         cf b[WS];
@@ -396,6 +396,18 @@ __device__ __forceinline__ void transpose_half(const cf (&a)[WS], cf (&g)[WS / 2
             asm volatile("" : "+v"(b[k].x), "+v"(b[k].y));
         });
         wave_sync();
+        if constexpr (!PLANAR) {              // complex elements (two wavefronts per SIMD: 16.9 KB tile)
+            cf* t = reinterpret_cast<cf*>(lds);
+            if (i <= M) {
+                static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    t[k * Q + i] = b[k];
+                });
+            }
+            wave_sync();
+#pragma unroll
+            for (int r = 0; r <= M; ++r) g[r] = t[i * Q + r];
+        } else {
         if (i <= M) {
             static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int k = decltype(kc)::value;
@@ -415,6 +427,7 @@ __device__ __forceinline__ void transpose_half(const cf (&a)[WS], cf (&g)[WS / 2
         wave_sync();
 #pragma unroll
         for (int r = 0; r <= M; ++r) g[r].y = lds[i * Q + r];
+        }
     } else if constexpr (PLANAR) {
         float* t = lds + (lane / WS) * G::HTILE;
         wave_sync();
@@ -1414,7 +1427,7 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
 #ifndef TPIV_C2R64
 #define TPIV_C2R64 1
 #endif
-        if constexpr (TPIV_C2R && (WS <= 32 || (TPIV_C2R64 && WS == 64 && PLANAR))) {
+        if constexpr (TPIV_C2R && (WS <= 32 || (TPIV_C2R64 && WS == 64))) {
             // the map rows are real: only spectrum columns 0..WS/2 cross the LDS and a WS/2-point complex
             // transform yields the row as z[m] = corr(y, 2m) + i corr(y, 2m + 1)  (c2r_inreg)
             cf hs[WS / 2 + 1], z[WS / 2];
