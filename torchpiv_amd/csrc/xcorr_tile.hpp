@@ -10,10 +10,13 @@
 //   * lane = one image ROW of one window.  The row (WS bytes per frame) is fetched with
 //     16-byte loads straight into VGPRs; overlapping windows re-read through L2 (a per-XCD work
 //     queue keeps the wavefronts of an XCD on adjacent windows).  Both frames are packed as a + i*b.
+//     Bilinear (CWS) passes fetch the (WS+1)^2 source patch of a window with all its lanes together and
+//     hand the rows over through LDS (CoopGeo below).
 //   * all 1-D FFTs (WS points) run per lane, entirely in registers (fft_inreg.hpp).
 //   * LDS is used only to transpose between the row and the column transform, in 32x33 (or
 //     WSx(WS+1)) tiles; a 64x64 tile is transposed as four 32x32 blocks after a
-//     v_permlane32_swap of the off-diagonal blocks.  Kernels at three wavefronts per SIMD move one
+//     v_permlane32_swap of the off-diagonal blocks.  The last transform is a c2r one: only spectrum
+//     columns 0..WS/2 cross the LDS the second time (transpose_half).  Kernels at three wavefronts per SIMD move one
 //     float plane at a time (8.4 KB per wavefront), the others complex elements (16.9 KB).
 //   * the k <-> -k partner of the packed spectrum is fetched with ds_bpermute (no LDS memory).
 //   * peak search: plain max scans per lane, DPP / permlane reductions, one LDS row lookup for the
