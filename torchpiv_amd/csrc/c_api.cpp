@@ -211,7 +211,8 @@ struct tpiv_plan {
     std::vector<double*> Wy32, Ax32;
     std::vector<int*> k0y32, k0x32;
     std::vector<int> KY, KX;
-    double *u0 = nullptr, *v0 = nullptr, *u2 = nullptr, *v2 = nullptr, *T = nullptr;
+    double *u0 = nullptr, *v0 = nullptr, *T = nullptr;      // predictor hand-off: raw fields ...
+    uint8_t* pmask = nullptr;                               // ... and the thresholded mask (PassParams::pmask)
     float* peak_raw = nullptr;           // [max_batch, max N_p, 8] hand-off tile kernel -> finalize
     size_t peak_raw_bytes = 0;
     std::vector<void*> allocs;
@@ -435,13 +436,14 @@ int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf, const 
 static int run_iter(int mode, int precision, const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws,
                     int ov, const double* u0, const double* v0, const double* u2, const double* v2,
                     double val_ratio, int val_win, double* u, double* v, uint8_t* invalid, double* du,
-                    double* dv, float* dbg_win, float* dbg_corr, void* work, size_t work_bytes, void* stream) {
+                    double* dv, float* dbg_win, float* dbg_corr, void* work, size_t work_bytes, void* stream,
+                    const uint8_t* pmask = nullptr) {
     if (mode != TPIV_MODE_DWS && mode != TPIV_MODE_CWS && mode != TPIV_MODE_CWS_FAST)
         return fail(TPIV_EKEY, "unknown multipass mode");
     int rc = check_window(H, W, ws, ov, val_win);
     if (rc) return rc;
     if (mode == TPIV_MODE_CWS_FAST && ws < 2) return fail(TPIV_EINVAL, "window too small");
-    if (mode != TPIV_MODE_CWS_FAST && (!u2 || !v2)) return fail(TPIV_EINVAL, "tpiv_iter: u2 / v2 missing");
+    if (mode != TPIV_MODE_CWS_FAST && !pmask && (!u2 || !v2)) return fail(TPIV_EINVAL, "tpiv_iter: u2 / v2 missing");
     if (!u0 || !v0) return fail(TPIV_EINVAL, "tpiv_iter: u0 / v0 missing");
     if (precision != TPIV_PREC_FAST && precision != TPIV_PREC_REFERENCE)
         return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST or TPIV_PREC_REFERENCE");
@@ -460,6 +462,7 @@ static int run_iter(int mode, int precision, const uint8_t* a, const uint8_t* b,
     p.v0 = v0;
     p.u2 = u2;
     p.v2 = v2;
+    p.pmask = pmask;           // plan path: raw predictor in u0 / v0 + mask (piv_kernels.h)
     p.u = u;
     p.v = v;
     p.val = invalid;
@@ -621,8 +624,7 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
     if (rc == TPIV_OK && n_pass > 1) {
         rc = pl->alloc(&pl->u0, max_fine * max_batch);
         if (!rc) rc = pl->alloc(&pl->v0, max_fine * max_batch);
-        if (!rc) rc = pl->alloc(&pl->u2, max_fine * max_batch);
-        if (!rc) rc = pl->alloc(&pl->v2, max_fine * max_batch);
+        if (!rc) rc = pl->alloc(&pl->pmask, max_fine * max_batch);
         if (!rc) rc = pl->alloc(&pl->T, max_T * max_batch);
     }
     if (rc) {
@@ -668,7 +670,7 @@ int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u, double** 
 
 static int run_banded_predict(tpiv_plan* plan, int p, int batch, const double* u_c, const double* v_c,
                               const uint8_t* val_c, double* u0, double* v0, double* u2, double* v2,
-                              hipStream_t st) {
+                              hipStream_t st, uint8_t* mask_out = nullptr) {
     const PassGeo& g = plan->geo[p];
     const PassGeo& c = plan->geo[p - 1];
     tpiv::BandedPredictParams q{};
@@ -693,6 +695,7 @@ static int run_banded_predict(tpiv_plan* plan, int p, int batch, const double* u
     q.v0 = v0;
     q.u2 = u2;
     q.v2 = v2;
+    q.mask_out = mask_out;
     hipError_t he = tpiv::launch_predict_mfma(q, st);
     return he == hipSuccess ? TPIV_OK : hip_fail(he, "launch_predict_mfma");
 }
@@ -734,14 +737,15 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
         } else {
             const PassGeo& c = plan->geo[p - 1];
             mark(2 * p - 1, 0);
+            // compact hand-off: raw predictor (u0, v0) + mask byte; zeroing and half shift are formed by the readers
             rc = run_banded_predict(plan, p, batch, plan->u[p - 1], plan->v[p - 1], plan->val[p - 1], plan->u0,
-                                    plan->v0, plan->u2, plan->v2, st);
+                                    plan->v0, nullptr, nullptr, st, plan->pmask);
             mark(2 * p - 1, 1);
             mark(2 * p, 0);
             if (!rc)
                 rc = run_iter(plan->mode, plan->precision, a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->u0, plan->v0,
-                              plan->u2, plan->v2, plan->val_ratio, plan->val_win, pu, pv, pval, nullptr,
-                              nullptr, nullptr, nullptr, plan->peak_raw, plan->peak_raw_bytes, stream);
+                              nullptr, nullptr, plan->val_ratio, plan->val_win, pu, pv, pval, nullptr,
+                              nullptr, nullptr, nullptr, plan->peak_raw, plan->peak_raw_bytes, stream, plan->pmask);
             mark(2 * p, 1);
         }
         if (rc) return rc;

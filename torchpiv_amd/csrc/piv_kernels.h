@@ -20,6 +20,11 @@ struct PassParams {
     const double* v0;
     const double* u2;      // window half-shift: DWS rint(u0/2), CWS u0_prezero/2
     const double* v2;
+    // Compact hand-off from the plan's predictor (tpiv_plan_run): pmask != nullptr means u0 / v0 hold the RAW
+    // predictor (before the invalid-zeroing), pmask its thresholded mask, and u2 / v2 are not used -- the
+    // zeroing and the half shift are formed where they are read (pred_half_shift / pred_fallback below): two
+    // float64 fields and a byte per window cross HBM instead of four fields.
+    const uint8_t* pmask;
     // outputs [batch, n_rows, n_cols]
     double* u;
     double* v;
@@ -80,6 +85,7 @@ struct BandedPredictParams {
     double* v0;
     double* u2;
     double* v2;
+    uint8_t* mask_out;            // compact output (PassParams::pmask): u0 / v0 receive the RAW predictor, u2 / v2 nothing
 };
 
 // post-validation on the device (postval.hip)
@@ -111,6 +117,48 @@ constexpr int tile_occ_c(int ws, int mode) {
            : (ws == 16 ? 4 : ((ws == 32 || (ws == 64 && (mode != MODE_CWS || TPIV_OCC64C == 3))) ? 3 : 2));
 }
 inline int tile_occ(int ws, int mode) { return tile_occ_c(ws, mode); }
+#ifdef __HIPCC__
+// The predictor as the kernels of a shifted pass read it.  MODE is MODE_DWS or MODE_CWS.
+//   half shift (B:705-706 CWS: halves taken BEFORE the zeroing; B:782-785 DWS: rint(u0 / 2) AFTER it)
+// (The loads are unconditional -- the form is chosen by selecting POINTERS, wave-uniformly: the kernels fetch the
+//  next item's shift one iteration ahead, and a load under `if` makes the compiler wait right behind it.)
+template <int MODE>
+__device__ __forceinline__ void pred_half_shift(const PassParams& p, size_t i, double& sx, double& sy) {
+    const bool compact = p.pmask != nullptr;
+    const double* __restrict__ us = compact ? p.u0 : p.u2;
+    const double* __restrict__ vs = compact ? p.v0 : p.v2;
+    double u = us[i], v = vs[i];
+    if constexpr (MODE == MODE_DWS) {
+        const uint8_t* mp = compact ? p.pmask + i : reinterpret_cast<const uint8_t*>(us + i);    // (any readable byte)
+        const bool zero = *mp != 0 && compact;
+        const double uz = zero ? 0.0 : u, vz = zero ? 0.0 : v;
+        sx = compact ? rint(uz / 2) : u;
+        sy = compact ? rint(vz / 2) : v;
+    } else {
+        sx = compact ? u / 2 : u;
+        sy = compact ? v / 2 : v;
+    }
+}
+//   the CWS half shift as the float32 the staging uses (B:714-715 casts u2, v2 to float32): halving is exact in
+//   either precision, so float(u / 2) == float(u) * 0.5f -- one float32 multiply instead of float64 work
+__device__ __forceinline__ void pred_half_shift_cws_f32(const PassParams& p, size_t i, float& vx, float& vy) {
+    const bool compact = p.pmask != nullptr;
+    const double* __restrict__ us = compact ? p.u0 : p.u2;
+    const double* __restrict__ vs = compact ? p.v0 : p.v2;
+    const float k = compact ? 0.5f : 1.0f;
+    vx = (float)us[i] * k;
+    vy = (float)vs[i] * k;
+}
+//   fallback value: the predictor after the invalid-zeroing (B:711-713 / B:778-780)
+__device__ __forceinline__ void pred_fallback(const PassParams& p, size_t i, double& u0, double& v0) {
+    const bool compact = p.pmask != nullptr;
+    const uint8_t* mp = compact ? p.pmask + i : reinterpret_cast<const uint8_t*>(p.u0 + i);
+    const bool zero = *mp != 0 && compact;
+    u0 = zero ? 0.0 : p.u0[i];
+    v0 = zero ? 0.0 : p.v0[i];
+}
+#endif
+
 // symbol-like name of the kernel launch_xcorr picks for (ws, mode) -- for bench / profile labels
 const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len);
 // bytes of PassParams::peak_raw a pass needs (records, work-queue counters, generic-size DFT scratch)

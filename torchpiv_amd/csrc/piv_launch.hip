@@ -79,14 +79,18 @@ __global__ __launch_bounds__(256) void finalize_kernel(PassParams p, int mode) {
             p.v[i] = dv;
             p.val[i] = invalid ? 1 : 0;
         } else {                     // multipass combine (B:728-738 / B:800-810)
-            const double u0 = p.u0[i], v0 = p.v0[i];
+            double u0, v0;
+            pred_fallback(p, i, u0, v0);
             double u, v;
             if (mode == MODE_CWSF) {             // B:663-664: the windows were resampled by -/+ u0/2
                 u = u0 + du;
                 v = v0 + dv;
             } else {
-                u = 2 * p.u2[i] + du;
-                v = 2 * p.v2[i] + dv;
+                double sx, sy;
+                if (mode == MODE_DWS) pred_half_shift<MODE_DWS>(p, i, sx, sy);
+                else pred_half_shift<MODE_CWS>(p, i, sx, sy);
+                u = 2 * sx + du;
+                v = 2 * sy + dv;
             }
             const bool mask_u = ((du > u0) && (rint(u0) > 0)) || invalid;
             const bool mask_v = ((dv > v0) && (rint(v0) > 0)) || invalid;

@@ -191,6 +191,13 @@ __global__ __launch_bounds__(256, 2) void predict_cols_mfma_kernel(BandedPredict
                     if (rf >= q.nrf) continue;
                     double u0 = c.a[0][hi][hj][r], v0 = c.a[1][hi][hj][r];
                     const bool val = c.a[2][hi][hj][r] >= 0.5;      // B:711 / B:778
+                    if (q.mask_out != nullptr) {                    // compact hand-off: raw predictor + mask byte
+                        const size_t o = ((size_t)b * q.nrf + rf) * q.ncf + cf;
+                        q.u0[o] = u0;
+                        q.v0[o] = v0;
+                        q.mask_out[o] = val ? 1 : 0;
+                        continue;
+                    }
                     double u2 = 0.0, v2 = 0.0;
                     if (q.mode == MODE_CWS) {                   // B:705-706: halves taken BEFORE the zeroing
                         u2 = u0 / 2;

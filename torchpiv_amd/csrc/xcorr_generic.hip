@@ -192,11 +192,12 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
         const size_t fidx = (size_t)item;
         float vx = 0.f, vy = 0.f;     // (shifted passes exist in float only)
         long long sh = 0;
-        if constexpr (MODE == MODE_DWS) sh = (long long)p.v2[fidx] * p.W + (long long)p.u2[fidx];
-        if constexpr (MODE == MODE_CWS) {
-            vx = (float)p.u2[fidx];
-            vy = (float)p.v2[fidx];
+        if constexpr (MODE == MODE_DWS) {
+            double sx, sy;
+            pred_half_shift<MODE_DWS>(p, fidx, sx, sy);
+            sh = (long long)sy * p.W + (long long)sx;
         }
+        if constexpr (MODE == MODE_CWS) pred_half_shift_cws_f32(p, fidx, vx, vy);
         if constexpr (MODE == MODE_CWSF) {      // B:644-645: theta[:, 0, 2] = -u0 / wind_size (float64, stored as float32)
             vx = (float)(p.u0[fidx] / (double)n);
             vy = (float)(p.v0[fidx] / (double)n);

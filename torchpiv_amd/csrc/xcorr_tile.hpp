@@ -1245,8 +1245,14 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             vx = 0.f;
             vy = 0.f;
         } else {      // DWS: exact small integers; CWS: the float32 cast of B:714-715
-            vx = (float)p.u2[g.fidx];
-            vy = (float)p.v2[g.fidx];
+            if constexpr (MODE == MODE_CWS) {
+                pred_half_shift_cws_f32(p, g.fidx, vx, vy);
+            } else {
+                double sx, sy;
+                pred_half_shift<MODE>(p, g.fidx, sx, sy);
+                vx = (float)sx;
+                vy = (float)sy;
+            }
         }
     };
 

@@ -221,7 +221,9 @@ __global__ __launch_bounds__(64, 2) void xcorr_w8_kernel(PassParams p) {
             });
         } else if constexpr (MODE == MODE_DWS) {
             // integer shift on the FLAT index (B:213-215): a at idx - (vy W + vx), b at idx + (...), clamped per pixel
-            const long long sh = (long long)p.v2[fidx] * p.W + (long long)p.u2[fidx];
+            double sx, sy;
+            pred_half_shift<MODE_DWS>(p, fidx, sx, sy);
+            const long long sh = (long long)sy * p.W + (long long)sx;
             const long long qa = (long long)base - sh, qb = (long long)base + sh;
             const long long last = (long long)7 * p.W + 7;
             const bool fast = qa >= 0 && qb >= 0 && qa + last <= (long long)HW - 1 && qb + last <= (long long)HW - 1;
@@ -242,7 +244,8 @@ __global__ __launch_bounds__(64, 2) void xcorr_w8_kernel(PassParams p) {
                 stage_slow<MODE_DWS, true>(p, fb, x0, y0, 0.f, 0.f, sh, lds, lane, x);
             }
         } else {
-            const float vx = (float)p.u2[fidx], vy = (float)p.v2[fidx];          // the float32 cast of B:714-715
+            float vx, vy;                                                        // the float32 cast of B:714-715
+            pred_half_shift_cws_f32(p, fidx, vx, vy);
             // Fast path: floor(float(g) + v) == g + floor(v) and no exactly integral coordinate (the "nearest
             // sample" quirk, B:170/193) for every column and row of the window -- checked coordinate by coordinate
             // with the reference's own float32 sums (a threshold on frac(v) wide enough for float32 rounding at
