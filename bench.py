@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the PIV cross-correlation hot path (driver contract).
 
-    python bench.py --gpus N --steps K --warmup W [--config 1|2] [--precision fast|reference]
+    python bench.py --gpus N --steps K --warmup W [--config 1|2] [--precision f64|fast|reference]
 
 Metric (BASELINE.json): image-pairs/sec at 4 MP, wind=64 ov=32, 2-pass CWS x2.0.
 
@@ -19,11 +19,17 @@ N > 1 without a launcher: `python bench.py --gpus N` starts the N ranks itself (
 touches the GPU runs `python -m torch.distributed.run --nproc-per-node N bench.py ...`); under
 torchrun (WORLD_SIZE set) it is a rank.  The line is refused unless n_gpus == --gpus.
 
+Precision.  `value` is measured at --precision f64 (the default): the reference's own arithmetic types -- pass 1 in
+float64 (PIVbackend.py:513-514), shifted passes float32 with the float64 epilogue (B:249-257, B:382) -- `dtype
+"f64/f32"`.  At N = 1 the same process then times the all-float32 mode as well and reports it BESIDE the headline as
+`fast: {value, ms_per_step, kernel_ms, roofline}` (never as `value`), followed by `end_to_end` (the generator through
+post-validation and yield, tools/e2e_generator.py) and `cpu_baseline`.
+
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel: HIP-event durations on the
 launch stream during the timed steps, bound = "valu" (the path sits ~10x above the
 HBM ridge), frac = max(B_alg / 8 TB/s, F_alg / 157.3 TFLOP/s) / t, the HBM view beside it, and --
 at N = 1 -- PMC counters of THIS build collected live by rocprofv3 child runs of this script
-(FETCH_SIZE, WRITE_SIZE, SQ_* in separate passes; --pmc file reads profiles/r02/pmc_counters.json
+(FETCH_SIZE, WRITE_SIZE, SQ_* in separate passes; --pmc file reads profiles/r03/pmc_counters.json
 instead, --pmc off skips).  `cpu_baseline` (N = 1): the CPU oracle on the host cores.
 """
 import argparse
@@ -47,7 +53,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_VALU_PEAK_TFLOPS = 157.3   # vector fp32 peak, same guide
 FP64_VALU_PEAK_TFLOPS = 78.6    # vector fp64 peak (half rate)
 ISSUE_PEAK_G = 256 * 4 * 2.4 / 2.0      # wave-instructions/s: one per SIMD every 2 cycles at 2.4 GHz
-PMC_FILE = os.path.join(ROOT, "profiles", "r02", "pmc_counters.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03", "pmc_counters.json")
 
 
 def alg_bytes(H, W, n_windows, first_pass):
@@ -69,8 +75,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for config 1, 10 for config 2)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=1, choices=(1, 2))
-    ap.add_argument("--precision", default="fast", choices=("fast", "reference"),
-                    help="arithmetic of pass 1: float32 (fast) or float64 like the reference (PIVbackend.py:513-514)")
+    ap.add_argument("--precision", default="f64",
+                    help="f64 (default): pass 1 in float64 like the reference (PIVbackend.py:513-514), shifted passes float32; "
+                         "reference: the same with the reference's operation order in the CWS sampling; fast: pass 1 in float32 too")
+    ap.add_argument("--no-fast", action="store_true", help="N = 1: skip the all-float32 run reported beside the headline")
+    ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end_to_end block (generator rates)")
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per launch (config 1: 256; config 2: shard 500)")
     ap.add_argument("--stream", type=int, default=4000, help="config 2: pairs in the stream (all ranks together)")
     ap.add_argument("--size", type=int, default=2048)
@@ -84,9 +93,12 @@ def parse_args():
                     help="end-to-end generator mode instead of the kernel-path bench: ResidentPIV / OfflinePIV.batched incl. "
                          "device post-validation, counted host fallbacks, BMP ingest (one JSON line, N = 1)")
     ap.add_argument("--e2e-pairs", type=int, default=256)
+    ap.add_argument("--e2e-block-pairs", type=int, default=128, help="pairs per case of the end_to_end block of the default run")
     ap.add_argument("--fill-workers", type=int, default=8)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if not all(p_ in ("f64", "fast", "reference") for p_ in a.precision.split(",")):
+        ap.error("--precision must be f64, fast or reference")
     if a.mode is None:
         a.mode = "CWS" if a.config == 1 else "DWS"
     if a.batch is None:
@@ -120,13 +132,21 @@ def spawn_ranks(args):
 # ---------------------------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1): the oracle (a port of the reference's algorithm) on the host cores
 # ---------------------------------------------------------------------------------------------
-def cpu_baseline(H, W, ws, ov, n_pass, mode, budget_s=20.0):
+def cpu_baseline(H, W, ws, ov, n_pass, mode, n_kernels=8, n_e2e=4):
+    """Bounded sample of the SAME workload through oracle/piv_oracle.py (numpy + torch-CPU FFT: pass 1 in float64,
+    shifted passes float32 like the reference): `n_kernels` pairs through the passes alone (the scope of `value`),
+    `n_e2e` pairs end to end like OfflinePIV.__call__ incl. post-validation -- about 25 s on the box's host cores."""
     import torch
     from oracle import piv_oracle as O
     from torchpiv_amd import synth
     threads = torch.get_num_threads()
-    pairs = [synth.make_pair(H, W, 900 + i, noise=2.0) for i in range(2)]
-    pairs = [(a.numpy(), b.numpy()) for a, b in pairs]
+    pairs = [synth.make_pair(H, W, 900 + i, noise=2.0) for i in range(4)]
+    pairs = [(a.numpy().copy(), b.numpy().copy()) for a, b in pairs]
+    for a, b in pairs:                     # a few dead windows: the pair has invalid vectors, so the hole fill runs
+        a[300:340, 500:540] = 0            # (a clean pair is DROPPED by the reference's quirk before any fill, B:300-304)
+        b[300:340, 500:540] = 0
+        a[1200:1240, 900:940] = 0
+        b[1200:1240, 900:940] = 0
 
     def kernels_only(a, b):
         u, v, x, y, val = O.pass1(a, b, ws, ov, validate=True)
@@ -137,28 +157,23 @@ def cpu_baseline(H, W, ws, ov, n_pass, mode, budget_s=20.0):
         return u, v, val
 
     kernels_only(*pairs[0])                      # warm-up (MKL plans, page faults)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        kernels_only(*pairs[n % len(pairs)])
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s * 0.7 or n >= 8:
-            break
+    t0 = time.perf_counter()
+    for k in range(n_kernels):
+        kernels_only(*pairs[k % len(pairs)])
+    dt = time.perf_counter() - t0
     # end to end like OfflinePIV.__call__ (B:873-901): the passes plus NaN-out, border interpolation,
     # Delaunay hole fill, flip and scaling (frames already decoded, as for the GPU figure)
     t1 = time.perf_counter()
-    n2 = 0
-    for _ in O.offline_piv(pairs[:1], ws, ov, multipass=n_pass, mode=mode):
-        pass
-    n2 += 1
+    n_yield = sum(1 for _ in O.offline_piv([pairs[k % len(pairs)] for k in range(n_e2e)], ws, ov, multipass=n_pass, mode=mode))
     dt2 = time.perf_counter() - t1
-    return {"value": n / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "end_to_end": {"value": n2 / dt2, "unit": "pairs/s",
+    return {"value": n_kernels / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "end_to_end": {"value": n_e2e / dt2, "unit": "pairs/s", "pairs": n_e2e, "yielded": n_yield,
                            "what": "oracle offline_piv on resident frames: passes + NaN-out + border interpolation + "
-                                   "Delaunay hole fill + flip/scale (PIVbackend.py:873-901), 1 pair"},
-            "sample": f"{n} pairs of the same {H}x{W} {n_pass}-pass {mode} workload (noise 2), oracle/piv_oracle.py "
-                      f"(numpy + torch-CPU FFT), no file I/O; survey-container figure for the reference itself: "
-                      f"0.24 pairs/s on 8 threads (BASELINE.md)"}
+                                   "Delaunay hole fill + flip/scale (PIVbackend.py:873-901)"},
+            "sample": f"{n_kernels} pairs (kernels only) + {n_e2e} pairs (end to end) of the same {H}x{W} {n_pass}-pass {mode} "
+                      f"workload (noise 2, two dead spots per frame), oracle/piv_oracle.py (numpy + torch-CPU FFT, pass 1 in "
+                      f"float64), no file I/O; survey-container figure for the reference itself: 0.24 pairs/s on 8 threads "
+                      f"(BASELINE.md)"}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -168,10 +183,11 @@ PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"],
               ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES"]]
 
 
-def collect_pmc_live(args, timeout_s=170):
-    """{kernel name substring: {counter: mean per launch}} or None.  One rocprofv3 child per counter
-    group (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots');
-    the program itself follows `--` (no env/bash hop: the profiler's library initialises the GPU)."""
+def collect_pmc_live(args, precisions, timeout_s=170):
+    """{kernel name: {counter: mean per launch}} or None.  One rocprofv3 child per counter group (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots'); the program itself follows `--`
+    (no env/bash hop: the profiler's library initialises the GPU).  The child runs 2 plain steps at every
+    precision in `precisions`, so one set of passes covers the kernels of the headline AND of the fast run."""
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not on PATH"
@@ -184,7 +200,7 @@ def collect_pmc_live(args, timeout_s=170):
             d = os.path.join(tmp, f"p{i}")
             cmd = [exe, "--pmc", *ctrs, "--kernel-include-regex", "xcorr", "--output-format", "csv", "-d", d, "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--pmc", "off", "--no-cpu-baseline",
-                   "--config", str(args.config), "--precision", args.precision, "--steps", "2", "--warmup", "1",
+                   "--config", str(args.config), "--precision", ",".join(precisions), "--steps", "2", "--warmup", "1",
                    "--batch", str(args.batch), "--size", str(args.size), "--ws", str(args.ws),
                    "--passes", str(args.passes), "--mode", args.mode, "--distinct", "8", "--stream", str(args.batch)]
             left = t_end - time.time()
@@ -210,7 +226,7 @@ def collect_pmc_live(args, timeout_s=170):
         return (out or None), f"{type(exc).__name__}: {exc}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return out, "live: rocprofv3 --pmc child runs of this bench.py (2 timed steps each)"
+    return out, "live: rocprofv3 --pmc child runs of this bench.py (2 timed steps per precision each)"
 
 
 def pmc_for(pmc, kernel_name):
@@ -222,24 +238,47 @@ def pmc_for(pmc, kernel_name):
     return None
 
 
-def e2e_mode(args):
-    """Generator rates end to end (tools/e2e_generator.py): not the BASELINE.json metric -- `value` is the
-    resident-frame rate on frames that all need the host triangulation, the other cases ride along."""
+def e2e_cases(n, workers, files=True, budget_s=150.0):
+    """Generator rates end to end (tools/e2e_generator.py) at the default precision of the drop-in ("f64")."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import contextlib
     import io as _io
     import e2e_generator
     log = _io.StringIO()
     with contextlib.redirect_stdout(log):
-        r = e2e_generator.main(n=args.e2e_pairs, workers=args.fill_workers)
+        r = e2e_generator.main(n=n, workers=workers, files=files, budget_s=budget_s)
+    return r, log.getvalue().strip().splitlines()
+
+
+def e2e_block(r, log, n, workers):
+    return {"unit": "pairs/s", "pairs_per_case": n, "batch": 32, "fill_workers": workers, "precision": r.get("precision", "f64"),
+            "what": "generator end to end at 4 MP, wind=64 ov=32 2-pass CWS: passes + device post-validation + counted host "
+                    "fallbacks + flip/scale + yield (ResidentPIV / OfflinePIV.batched)",
+            "resident_clean_all_dropped": r.get("clean"), "resident_straight_runs": r.get("runs"),
+            "resident_isolated_spots": r.get("spots"), "bmp_files_isolated_spots": r.get("files"),
+            "bmp_files_generator_call": r.get("files_call"), "post_validation": r.get("stats"), "log": log}
+
+
+def e2e_mode(args):
+    """`--e2e`: the generator rates as the line's own metric (not the BASELINE.json metric) -- `value` is the
+    resident-frame rate on frames that all hold isolated invalid vectors, the other cases ride along."""
+    r, log = e2e_cases(args.e2e_pairs, args.fill_workers)
     rec = {"metric": "generator pairs/s end to end at 4 MP, wind=64 ov=32 2-pass CWS (passes + post-validation + flip/scale + yield)",
            "value": r["spots"], "unit": "pairs/s", "n_gpus": 1, "higher_is_better": True, "data": "synthetic",
            "config": {"workload": f"{args.e2e_pairs} synthetic 2048x2048 pairs, batch 32, {args.fill_workers} Qhull worker processes",
-                      "cases": {"resident_clean_all_dropped": r["clean"], "resident_straight_runs": r["runs"],
-                                "resident_isolated_spots": r["spots"], "bmp_files_isolated_spots": r.get("files"),
-                                "bmp_files_generator_call": r.get("files_call")}},
-           "log": log.getvalue().strip().splitlines()}
+                      "cases": e2e_block(r, [], args.e2e_pairs, args.fill_workers)},
+           "log": log}
     print(json.dumps(rec), flush=True)
+
+
+DTYPE = {"fast": "f32", "f64": "f64/f32", "reference": "f64/f32"}
+PREC_NOTE = {
+    "fast": "fast (pass 1 float32; passes >= 2 float32 + float64 epilogue as in the reference)",
+    "f64": "f64 (pass 1 float64 as in the reference, B:513-514; passes >= 2 float32 + float64 epilogue as in the reference, "
+           "B:249-257 / B:382, CWS sample formed as row lerps + column lerp)",
+    "reference": "reference (pass 1 float64, B:513-514; passes >= 2 float32 + float64 epilogue with the reference's "
+                 "operation order in the CWS sampling, B:187-193: bit-identical staged windows)",
+}
 
 
 def main():
@@ -282,10 +321,6 @@ def main():
     B = B0.repeat(reps, 1, 1)[:batch].contiguous()
     del A0, B0
 
-    plan = engine.Plan(H, W, ws, ov, n_pass=args.passes, mode=args.mode, max_batch=batch, device=dev,
-                       precision=args.precision)
-    nr, nc = plan.out_shape
-
     if args.config == 1:
         n_local = batch                                  # pairs this rank processes per step
         shards = [(0, batch)]
@@ -299,107 +334,178 @@ def main():
         pair_ids = torch.tensor(mine, dtype=torch.int64, device=dev)
         total_per_step = args.stream
         scaling = "strong"
-    u_all = torch.empty(max(n_local, 1), nr, nc, dtype=torch.float64, device=dev)
-    v_all = torch.empty_like(u_all)
-    i_all = torch.empty(max(n_local, 1), nr, nc, dtype=torch.uint8, device=dev)
-
-    def one_step(gather):
-        for s, n in shards:
-            # (every shard reads the same resident synthetic frames; its fields land in its own slice)
-            plan.run(A[:n], B[:n], out=(u_all[s:s + n], v_all[s:s + n], i_all[s:s + n]))
-        if gather and world > 1:
-            # the single collective: (u, v) of every rank's pairs onto rank 0, float64 as yielded
-            uv = torch.stack([u_all[:n_local], v_all[:n_local]], dim=1)
-            pdist.gather_fields(pair_ids, uv)
-
     gather_every_step = args.config == 2
-    for _ in range(args.warmup):
-        one_step(True)       # (also rehearses the gather: communicator / buffer setup of the first call)
-    torch.cuda.synchronize()
-    if args.pmc_child:       # profiled child: a couple of plain steps are all the counters need
-        for _ in range(args.steps):
-            one_step(False)
+
+    def measure(precision, steps, warmup, timed=True):
+        """W warm-up steps, then exactly `steps` timed steps between barrier + synchronize pairs; returns the
+        elapsed wall time (max over ranks), the per-step event times, the per-kernel event times and the plan's
+        geometry / kernel names."""
+        plan = engine.Plan(H, W, ws, ov, n_pass=args.passes, mode=args.mode, max_batch=batch, device=dev,
+                           precision=precision)
+        nr, nc = plan.out_shape
+        u_all = torch.empty(max(n_local, 1), nr, nc, dtype=torch.float64, device=dev)
+        v_all = torch.empty_like(u_all)
+        i_all = torch.empty(max(n_local, 1), nr, nc, dtype=torch.uint8, device=dev)
+
+        def one_step(gather):
+            for s_, n_ in shards:
+                # (every shard reads the same resident synthetic frames; its fields land in its own slice)
+                plan.run(A[:n_], B[:n_], out=(u_all[s_:s_ + n_], v_all[s_:s_ + n_], i_all[s_:s_ + n_]))
+            if gather and world > 1:
+                # the single collective: (u, v) of every rank's pairs onto rank 0, float64 as yielded
+                uv = torch.stack([u_all[:n_local], v_all[:n_local]], dim=1)
+                pdist.gather_fields(pair_ids, uv)
+
+        for _ in range(warmup):
+            one_step(True)       # (also rehearses the gather: communicator / buffer setup of the first call)
         torch.cuda.synchronize()
+        if not timed:            # profiled child: a couple of plain steps are all the counters need
+            for _ in range(steps):
+                one_step(False)
+            torch.cuda.synchronize()
+            plan.close()
+            return None
+        plan.set_timing(True)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev[0].record()
+        for k in range(steps):
+            one_step(gather_every_step or k == steps - 1)
+            ev[k + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        step_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(steps)]
+        timing, n_runs = plan.get_timing()
+        plan.set_timing(False)
+        res = {"precision": precision, "elapsed": elapsed, "step_ms": step_ms, "timing": timing, "n_runs": n_runs,
+               "geometry": list(plan.geometry), "names": [plan.kernel_name(p_) for p_ in range(plan.n_pass)],
+               "n_pass": plan.n_pass}
         plan.close()
+        del u_all, v_all, i_all
+        return res
+
+    if args.pmc_child:
+        for prec in args.precision.split(","):
+            measure(prec, args.steps, args.warmup, timed=False)
         return
-    plan.set_timing(True)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    if "," in args.precision:
+        raise SystemExit("bench.py: one --precision (the comma form is the profiled child's)")
+
+    head = measure(args.precision, args.steps, args.warmup)
+    also_fast = world == 1 and args.config == 1 and not args.no_fast and args.precision != "fast"
+    fast = measure("fast", args.steps, args.warmup) if also_fast else None
+
+    # who ran: backend and devices as torch.distributed saw them (every rank reports, rank 0 prints)
+    me = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(dev), "device_index": dev.index}
+    ranks_info = [me]
     if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev[0].record()
-    for k in range(args.steps):
-        one_step(gather_every_step or k == args.steps - 1)
-        ev[k + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    step_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
-    timing, n_runs = plan.get_timing()
-    plan.set_timing(False)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        ranks_info = gathered
 
     if rank == 0:
-        value = total_per_step * args.steps / elapsed
-        # ---- per-kernel roofline entries, dominant = the xcorr slot with the largest mean duration
+        # ---- PMC counters (N = 1): one set of child passes covers both precisions
         pmc, pmc_src = None, "off"
         if world == 1 and args.pmc == "live":
-            pmc, pmc_src = collect_pmc_live(args)
+            pmc, pmc_src = collect_pmc_live(args, [args.precision] + (["fast"] if also_fast else []))
         if pmc is None and args.pmc in ("live", "file") and os.path.exists(PMC_FILE):
             try:
                 with open(PMC_FILE) as f:
                     blob = json.load(f)
-                key = f"config{args.config}_{args.precision}"
-                if key in blob and (args.batch, args.size, args.ws, args.passes) == (blob[key]["batch"], 2048, 64, 2):
-                    pmc = blob[key]["kernels"]
-                    pmc_src = f"file: profiles/r02/pmc_counters.json ({blob[key].get('source', '')}); live pass: {pmc_src}"
+                if (args.batch, args.size, args.ws, args.passes, args.config) == (blob.get("batch"), 2048, 64, 2, 1):
+                    pmc = blob["kernels"]
+                    pmc_src = f"file: {os.path.relpath(PMC_FILE, ROOT)} ({blob.get('source', '')}); live pass: {pmc_src}"
             except Exception as exc:
                 pmc_src = f"{pmc_src}; file unreadable: {exc}"
-        kernels = {}
-        for p_idx in range(plan.n_pass):
-            slot = "pass1_xcorr" if p_idx == 0 else f"pass{p_idx + 1}_xcorr"
-            g_ws, g_ov, g_nr, g_nc = plan.geometry[p_idx]
-            n_win = g_nr * g_nc
-            launch_pairs = shards[0][1]                   # pairs per launch (full shards)
-            f64 = p_idx == 0 and args.precision == "reference"
-            b_launch = alg_bytes(H, W, n_win, p_idx == 0) * launch_pairs
-            f_launch = alg_flops(g_ws, n_win, args.mode == "CWS" and p_idx > 0) * launch_pairs
-            t_k = timing[slot] * 1e-3
-            peak_tf = FP64_VALU_PEAK_TFLOPS if f64 else FP32_VALU_PEAK_TFLOPS
-            name = plan.kernel_name(p_idx)
-            ctr = pmc_for(pmc, name)
-            ent = {
-                "kernel": name, "launch_ms": timing[slot], "launches_timed": n_runs, "pairs_per_launch": launch_pairs,
-                "alg_flops_per_launch": f_launch, "alg_bytes_per_launch": b_launch,
-                "valu": {"achieved": f_launch / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
-                         "frac": f_launch / t_k / 1e12 / peak_tf},
-                "hbm": {"achieved": b_launch / t_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": b_launch / t_k / 1e9 / HBM_PEAK_GBS, "traffic": None},
+
+        def analyse(m):
+            """Per-kernel roofline entries of one measured run; dominant = the xcorr slot with the largest mean duration."""
+            kernels = {}
+            for p_idx in range(m["n_pass"]):
+                slot = "pass1_xcorr" if p_idx == 0 else f"pass{p_idx + 1}_xcorr"
+                g_ws, g_ov, g_nr, g_nc = m["geometry"][p_idx]
+                n_win = g_nr * g_nc
+                launch_pairs = shards[0][1]                   # pairs per launch (full shards)
+                f64 = p_idx == 0 and m["precision"] != "fast"
+                b_launch = alg_bytes(H, W, n_win, p_idx == 0) * launch_pairs
+                f_launch = alg_flops(g_ws, n_win, args.mode == "CWS" and p_idx > 0) * launch_pairs
+                t_k = m["timing"][slot] * 1e-3
+                peak_tf = FP64_VALU_PEAK_TFLOPS if f64 else FP32_VALU_PEAK_TFLOPS
+                name = m["names"][p_idx]
+                ctr = pmc_for(pmc, name)
+                ent = {
+                    "kernel": name, "arith": "f64" if f64 else "f32", "launch_ms": m["timing"][slot],
+                    "launches_timed": m["n_runs"], "pairs_per_launch": launch_pairs,
+                    "alg_flops_per_launch": f_launch, "alg_bytes_per_launch": b_launch,
+                    "valu": {"achieved": f_launch / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                             "frac": f_launch / t_k / 1e12 / peak_tf},
+                    "hbm": {"achieved": b_launch / t_k / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": b_launch / t_k / 1e9 / HBM_PEAK_GBS, "traffic": None},
+                }
+                if ctr:
+                    scale = launch_pairs / args.batch if args.config == 1 else 1.0      # child ran the same launch size
+                    if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
+                        # KiB units; on gfx950 FETCH_SIZE tallies 64 B per 128-B request of wide streaming reads
+                        ent["hbm"]["traffic"] = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0 * scale
+                        ent["hbm"]["traffic_over_alg"] = ent["hbm"]["traffic"] / b_launch
+                    if "SQ_INSTS_VALU" in ctr:
+                        insts = ctr["SQ_INSTS_VALU"] * scale
+                        # float64 VALU instructions issue at half rate: the wave-instruction peak is halved for them
+                        ipk = ISSUE_PEAK_G
+                        ent["valu_issue"] = {"insts_per_launch": insts, "achieved": insts / t_k / 1e9, "peak": ipk,
+                                             "unit": "G wave-instr/s", "frac": insts / t_k / 1e9 / ipk,
+                                             "alg_flops_per_wave_instr": f_launch / insts / 64.0}
+                    if "SQ_LDS_BANK_CONFLICT" in ctr and ctr.get("SQ_ACTIVE_INST_LDS"):
+                        ent["lds_conflict_share"] = ctr["SQ_LDS_BANK_CONFLICT"] / ctr["SQ_ACTIVE_INST_LDS"]
+                    ent["counters_per_launch"] = {k: v * scale for k, v in ctr.items()}
+                kernels[slot] = ent
+            dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])
+            d = kernels[dom]
+            roof = {
+                "bound": "valu",
+                "kernel": d["kernel"] + f" ({dom})",
+                "achieved": d["valu"]["achieved"],
+                "peak": d["valu"]["peak"],
+                "unit": "TFLOP/s",
+                "frac": max(d["valu"]["frac"], d["hbm"]["frac"]),
+                "traffic": d["hbm"]["traffic"],
+                "hbm": d["hbm"],
+                "valu_issue": d.get("valu_issue"),
+                "lds_conflict_share": d.get("lds_conflict_share"),
+                "alg_flops_per_launch": d["alg_flops_per_launch"],
+                "alg_bytes_per_launch": d["alg_bytes_per_launch"],
+                "launch_ms": d["launch_ms"],
+                "launches_timed": d["launches_timed"],
+                "counters": pmc_src,
+                "note": "frac = max(B_alg / 8 TB/s, F_alg / vector peak of the kernel's arithmetic type: 78.6 TFLOP/s "
+                        "float64, 157.3 float32) / t (SURVEY.md 8d): the path is VALU-bound (~190 flop/B against a ridge "
+                        "of ~20), `hbm` is the same launch seen from the HBM side; traffic = (2 FETCH_SIZE + WRITE_SIZE) "
+                        "KiB per launch from the PMC passes",
             }
-            if ctr:
-                scale = launch_pairs / args.batch if args.config == 1 else 1.0      # child ran the same launch size
-                if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:
-                    # KiB units; on gfx950 FETCH_SIZE tallies 64 B per 128-B request of wide streaming reads
-                    ent["hbm"]["traffic"] = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0 * scale
-                    ent["hbm"]["traffic_over_alg"] = ent["hbm"]["traffic"] / b_launch
-                if "SQ_INSTS_VALU" in ctr:
-                    insts = ctr["SQ_INSTS_VALU"] * scale
-                    ent["valu_issue"] = {"insts_per_launch": insts, "achieved": insts / t_k / 1e9, "peak": ISSUE_PEAK_G,
-                                         "unit": "G wave-instr/s", "frac": insts / t_k / 1e9 / ISSUE_PEAK_G,
-                                         "alg_flops_per_wave_instr": f_launch / insts / 64.0}
-                ent["counters_per_launch"] = {k: v * scale for k, v in ctr.items()}
-            kernels[slot] = ent
-        dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])
-        d = kernels[dom]
-        frac = max(d["valu"]["frac"], d["hbm"]["frac"])
-        b_pair = sum(alg_bytes(H, W, g[2] * g[3], i == 0) for i, g in enumerate(plan.geometry))
-        f_pair = sum(alg_flops(g[0], g[2] * g[3], args.mode == "CWS" and i > 0) for i, g in enumerate(plan.geometry))
-        srt = sorted(step_ms)
+            return kernels, roof
+
+        def stats(m):
+            st = sorted(m["step_ms"])
+            return {"median": statistics.median(st), "min": st[0], "max": st[-1],
+                    "p05": st[int(0.05 * (len(st) - 1))], "p95": st[int(math.ceil(0.95 * (len(st) - 1)))],
+                    "pairs_per_s_at_median": total_per_step / (statistics.median(st) * 1e-3),
+                    "note": "per-step HIP-event times on rank 0's launch stream; `value` uses the wall clock "
+                            "around all steps (max over ranks)"}
+
+        kernels, roof = analyse(head)
+        value = total_per_step * args.steps / head["elapsed"]
+        geo = head["geometry"]
+        b_pair = sum(alg_bytes(H, W, g[2] * g[3], i == 0) for i, g in enumerate(geo))
+        f_pair = sum(alg_flops(g[0], g[2] * g[3], args.mode == "CWS" and i > 0) for i, g in enumerate(geo))
         rec = {
             "metric": "image-pairs/sec at 4 MP, wind=64 ov=32 2-pass CWS; % HBM roofline",
             "value": value,
@@ -407,62 +513,57 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fast" else "f64/f32",
+            "dtype": DTYPE[args.precision],
             "data": "synthetic",
             "config": {
                 "workload": (f"synthetic {H}x{W} pair batch={batch} per GPU, wind={ws} overlap={ov}, {args.passes}-pass "
                              f"{args.mode} x2.0 (BASELINE.json configs[1])") if args.config == 1 else
                             (f"synthetic {H}x{W} pair stream={args.stream} in {batch}-pair shards, wind={ws} overlap={ov}, "
                              f"{args.passes}-pass {args.mode}, sharded over {world} GPU(s) (BASELINE.json configs[2])"),
-                "precision": args.precision + (" (pass 1 float32; passes >= 2 float32 + float64 epilogue as in the reference)"
-                                               if args.precision == "fast" else
-                                               " (pass 1 float64 as in the reference, B:513-514; passes >= 2 float32 + float64 epilogue)"),
+                "precision": PREC_NOTE[args.precision],
                 "batch_per_gpu": batch, "distinct_pairs": distinct, "pairs_per_step": total_per_step,
                 "parallelism": (f"pair-sharded x{world}, one RCCL gather of (u,v) onto rank 0 "
                                 + ("at the end of the timed region" if args.config == 1 else "inside every step")),
             },
-            "step_ms": {"median": statistics.median(step_ms), "min": srt[0], "max": srt[-1],
-                        "p05": srt[int(0.05 * (len(srt) - 1))], "p95": srt[int(math.ceil(0.95 * (len(srt) - 1)))],
-                        "pairs_per_s_at_median": total_per_step / world / (statistics.median(step_ms) * 1e-3) * world,
-                        "note": "per-step HIP-event times on rank 0's launch stream; `value` uses the wall clock "
-                                "around all steps (max over ranks)"},
-            "roofline": {
-                "bound": "valu",
-                "kernel": d["kernel"] + f" ({dom})",
-                "achieved": d["valu"]["achieved"],
-                "peak": d["valu"]["peak"],
-                "unit": "TFLOP/s",
-                "frac": frac,
-                "traffic": d["hbm"]["traffic"],
-                "hbm": d["hbm"],
-                "valu_issue": d.get("valu_issue"),
-                "alg_flops_per_launch": d["alg_flops_per_launch"],
-                "alg_bytes_per_launch": d["alg_bytes_per_launch"],
-                "launch_ms": d["launch_ms"],
-                "launches_timed": d["launches_timed"],
-                "counters": pmc_src,
-                "note": "frac = max(B_alg / 8 TB/s, F_alg / vector peak) / t (SURVEY.md 8d): the path is VALU-bound "
-                        "(~190 flop/B against a ridge of ~20), `hbm` is the same launch seen from the HBM side; "
-                        "traffic = (2 FETCH_SIZE + WRITE_SIZE) KiB per launch from the PMC passes",
-            },
+            "step_ms": stats(head),
+            "roofline": roof,
             "kernels": kernels,
-            "kernel_ms": timing,
+            "kernel_ms": head["timing"],
             "whole_path": {"alg_bytes_per_pair": b_pair, "hbm_frac": b_pair * value / world / 1e9 / HBM_PEAK_GBS,
                            "alg_flops_per_pair": f_pair,
-                           "valu_frac": f_pair * value / world / 1e12 / FP32_VALU_PEAK_TFLOPS},
+                           "valu_frac_of_f32_peak": f_pair * value / world / 1e12 / FP32_VALU_PEAK_TFLOPS},
+            "distributed": {"world_size": dist.get_world_size() if world > 1 else 1,
+                            "backend": dist.get_backend() if world > 1 else None,
+                            "collectives_per_gather": 2 if world > 1 else 0, "ranks": ranks_info},
             "published_ref": {"value": 6.7, "unit": "pairs/s",
                               "note": "'>6.7 pairs/s' incl. file I/O, GPU unnamed (GTX 1660 Ti era), "
                                       "reference README.md:58; not this exact metric, so vs_baseline is null"},
         }
+        if fast is not None:
+            fk, froof = analyse(fast)
+            rec["fast"] = {"dtype": DTYPE["fast"], "precision": PREC_NOTE["fast"],
+                           "value": total_per_step * args.steps / fast["elapsed"], "unit": "pairs/s",
+                           "steps": args.steps, "warmup": args.warmup,
+                           "ms_per_step": fast["elapsed"] / args.steps * 1e3, "step_ms": stats(fast),
+                           "kernel_ms": fast["timing"], "roofline": froof, "kernels": fk,
+                           "note": "the same workload, same process, timed right after the headline with pass 1 in float32 "
+                                   "(narrower than the reference's float64 pass 1: reported beside `value`, never as it)"}
+        if world == 1 and args.config == 1 and not args.no_e2e:
+            del A, B
+            torch.cuda.empty_cache()
+            try:
+                r, log = e2e_cases(args.e2e_block_pairs, args.fill_workers, files=True, budget_s=100.0)
+                rec["end_to_end"] = e2e_block(r, log, args.e2e_block_pairs, args.fill_workers)
+            except Exception as exc:                      # never let the side block break the bench line
+                rec["end_to_end"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(H, W, ws, ov, args.passes, args.mode)
         assert rec["n_gpus"] == args.gpus
         print(json.dumps(rec), flush=True)
-    plan.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

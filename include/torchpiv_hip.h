@@ -54,11 +54,16 @@ enum tpiv_precision {
     TPIV_PREC_FAST = 0,      /* pass 1 in float32 (observed deviation ~1e-6 px); shifted passes form the CWS
                                 sample as row lerps + a column lerp with the reference's float32 weights
                                 (float32 rounding differences against B:187-193) */
-    TPIV_PREC_REFERENCE = 1  /* pass 1 in float64 like the reference (B:513-514 promotes the windows to
+    TPIV_PREC_REFERENCE = 1, /* pass 1 in float64 like the reference (B:513-514 promotes the windows to
                                 float64 before the FFT); shifted passes evaluate B:187-193 operation by
                                 operation, so the staged windows are bit-identical to the reference's
                                 (the transforms of passes >= 2 are float32 in the reference itself,
                                 B:249-257, with a float64 epilogue, B:382) */
+    TPIV_PREC_F64 = 2        /* the reference's ARITHMETIC TYPES in every pass -- pass 1 in float64 (as
+                                TPIV_PREC_REFERENCE), shifted passes in float32 with the float64 epilogue -- with
+                                the cheaper operation order of TPIV_PREC_FAST in the shifted passes (row lerps +
+                                column lerp of the CWS sample: float32 rounding differences, <= 1e-4 grey levels,
+                                against B:187-193).  The default of the Python drop-in (OfflinePIV). */
 };
 
 typedef struct tpiv_plan tpiv_plan;

@@ -74,6 +74,56 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker4(rank, world, port, q):
+    """Four ranks; rank 2 drops EVERY pair of its shard (an all-dropped rank), rank 3's shard is cut short; then
+    the all-empty stream.  Counts the collectives a gather issues: one meta all-gather + one payload gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from torchpiv_amd import dist as pdist
+    pdist.init_from_env(backend="gloo")
+    calls = []
+    real_ag, real_g = dist.all_gather_into_tensor, dist.gather
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append("all_gather"), real_ag(*a, **k))[1]
+    dist.gather = lambda *a, **k: (calls.append("gather"), real_g(*a, **k))[1]
+    n_pairs = 13
+    mine = pdist.shard_indices(n_pairs, rank, world, "block")            # 4, 3, 3, 3
+    kept = [] if rank == 2 else (mine[:-1] if rank == 3 else mine)
+    fields = torch.stack([torch.full((2, 5, 3), float(i), dtype=torch.float64) for i in kept]) \
+        if kept else torch.zeros(0, 2, 0, 0, dtype=torch.float64)
+    ids, allf = pdist.gather_fields(torch.tensor(kept, dtype=torch.int64), fields)
+    assert calls == ["all_gather", "gather"], calls
+    if rank == 0:
+        assert tuple(allf.shape[1:]) == (2, 5, 3)
+        q.put((ids.tolist(), allf[:, 1, 4, 2].tolist()))
+    else:
+        assert ids is None and allf is None
+    # nothing anywhere: every rank learns it from the counts, no payload collective
+    del calls[:]
+    ids0, f0 = pdist.gather_fields(torch.zeros(0, dtype=torch.int64), torch.zeros(0, 2, 0, 0, dtype=torch.float64))
+    assert calls == ["all_gather"], calls
+    if rank == 0:
+        assert ids0.numel() == 0 and f0.shape[0] == 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_gather_four_ranks_one_all_dropped():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    ids, vals = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # 13 pairs: rank 0 owns 0..3, rank 1 4..6, rank 2 7..9 (all dropped), rank 3 10..12 (12 dropped)
+    assert ids == [0, 1, 2, 3, 4, 5, 6, 10, 11]
+    assert vals == [float(i) for i in ids]
+
+
 @pytest.mark.timeout(180)
 def test_gather_two_ranks():
     port = _free_port()

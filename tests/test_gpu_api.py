@@ -41,6 +41,7 @@ def explained_region(a, b, ws, ov, n_pass, mode):
     H, W = a.shape
     u, v, x, y, val = O.pass1(a, b, ws, ov, validate=True)
     E = near_tie_windows(a, b, ws, ov) | pass1_constant(a, b, ws, ov)
+    n_const = int(pass1_constant(a, b, ws, ov).sum())
     w, o = ws, ov
     for p in range(1, n_pass):
         xc, yc = x[0, :].copy(), y[:, 0].copy()
@@ -58,7 +59,8 @@ def explained_region(a, b, ws, ov, n_pass, mode):
             aa = O.shift_dws(a, idx, -f(u2, np.int64), -f(v2, np.int64))
             bb = O.shift_dws(b, idx, f(u2, np.int64), f(v2, np.int64))
         nr, nc = u.shape
-        E = D | fp32_noise_excuse(aa, bb, nr, nc, ulps=4096.0, fit_tol=0.5e-3) | constant_windows(aa, bb, nr, nc)
+        E = D | fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5e-3) | constant_windows(aa, bb, nr, nc)
+        n_const += int(constant_windows(aa, bb, nr, nc).sum())
     patch, n = ndimage.label(val | E)
     hit = np.unique(patch[E])
     region = np.isin(patch, hit[hit > 0]) | E
@@ -66,7 +68,37 @@ def explained_region(a, b, ws, ov, n_pass, mode):
     for sl in ((0, slice(None)), (-1, slice(None)), (slice(None), 0), (slice(None), -1)):
         if region[sl].any():
             region[sl] = True
-    return np.flip(region, axis=0)
+    return np.flip(region, axis=0), n_const
+
+
+REGION_CAP = 0.25       # a comparison whose explained region covers more of the field than this checks nothing
+
+
+def strict_chain(a, b, ws, ov, n_pass, mode, precision, unit, got_u, got_v, name, check_drift=True):
+    """What the explained-region comparison cannot see (frames with black / saturated blocks explain most of
+    their small grids) is covered by a chain without a region: (i) the generator's tuple equals the REFERENCE's
+    post-processing (oracle restatement of B:884-898: NaN-out, border interpolation, Delaunay fill, flip, scale)
+    applied to the plan's own last-pass fields, everywhere, to 1e-9 px; (ii) those fields, and every pass before
+    them, pass the three gates of cascade_check against the oracle's chain on the same frames."""
+    from oracle import piv_oracle as O
+    from test_gpu_fullsize import _oracle_fields
+    from test_gpu_parity import cascade_check
+    from torchpiv_amd import engine
+    H, W = a.shape
+    plan = engine.Plan(H, W, ws, ov, n_pass=n_pass, mode=mode, max_batch=1, precision=precision)
+    geo = [tuple(t[:2]) for t in plan.geometry]
+    u, v, inv = plan.run(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    u, v, val = u[0].cpu().numpy(), v[0].cpu().numpy(), inv[0].cpu().numpy().astype(bool)
+    plan.close()
+    u[val] = np.nan
+    v[val] = np.nan
+    u, v = O.fill_missing(O.interp_borders(u)), O.fill_missing(O.interp_borders(v))
+    assert u is not None and v is not None, name
+    wu, wv = np.flip(u, axis=0) * unit, -np.flip(v, axis=0) * unit
+    assert np.allclose(got_u, wu, rtol=0, atol=1e-9 * unit, equal_nan=True), name
+    assert np.allclose(got_v, wv, rtol=0, atol=1e-9 * unit, equal_nan=True), name
+    g = _oracle_fields(a, b, geo, mode, name)
+    cascade_check(engine, g, name, mode, precision, geo, check_drift=check_drift)
 
 
 # Pair 3 of the fixture is frame_b == frame_a without noise: its predictor is ~ +-1e-8 px and the
@@ -97,16 +129,25 @@ def test_offline_piv_generator(folder, golden, run, precision):
         assert u.dtype == np.float64 and x.dtype == np.float64
         assert np.array_equal(x, g[f"{run}_{j}_x"]) and np.array_equal(y, g[f"{run}_{j}_y"])
         assert u.shape == g[f"{run}_{j}_u"].shape
-        if precision == "fast" and (run, yielded[j]) in DEGENERATE:
-            continue
         unit = 1000 * scale / dt
+        if precision == "fast" and (run, yielded[j]) in DEGENERATE:
+            # (the region-free chain still applies: isolation feeds the oracle the GPU's own predictor signs)
+            strict_chain(g["frames_a"][yielded[j]], g["frames_b"][yielded[j]], ws, ov, mp_, ("DWS", "CWS")[mode],
+                         precision, unit, u, v, f"{run}p{yielded[j]}", check_drift=False)
+            continue
         bad = ~np.isclose(u / unit, g[f"{run}_{j}_u"] / unit, rtol=0, atol=1e-3, equal_nan=True)
         bad |= ~np.isclose(v / unit, g[f"{run}_{j}_v"] / unit, rtol=0, atol=1e-3, equal_nan=True)
         i = yielded[j]
-        region = explained_region(g["frames_a"][i], g["frames_b"][i], ws, ov, mp_, ("DWS", "CWS")[mode])
+        region, n_const = explained_region(g["frames_a"][i], g["frames_b"][i], ws, ov, mp_, ("DWS", "CWS")[mode])
         print(f"{run} {precision} pair {i}: {int(bad.sum())} of {bad.size} cells beyond 1e-3 px, "
-              f"{int((bad & ~region).sum())} unexplained; explained region covers {region.mean():.2f} of the field")
+              f"{int((bad & ~region).sum())} unexplained; explained region covers {region.mean():.2f} of the field "
+              f"({n_const} constant-input windows)")
         assert not (bad & ~region).any(), (run, j, np.argwhere(bad & ~region)[:6].tolist())
+        # the region must leave something to compare -- unless the frames hold black / saturated blocks, whose
+        # coin-toss windows reach most of these small grids through predictor and hole fill
+        assert region.mean() <= REGION_CAP or n_const > 0, (run, i, float(region.mean()))
+        strict_chain(g["frames_a"][i], g["frames_b"][i], ws, ov, mp_, ("DWS", "CWS")[mode], precision, unit, u, v,
+                     f"{run}p{i}")
     # the batched extension gives the same tuples, tagged with the pair index
     res_b = list(piv.batched(batch_size=3))
     assert len(res_b) == len(res)
@@ -134,10 +175,12 @@ def test_generator_config0_geometry(tmp_path, golden):
             bad = ~np.isclose(u / 1000, g[f"r5_{j}_u"] / 1000, rtol=0, atol=1e-3, equal_nan=True)
             bad |= ~np.isclose(v / 1000, g[f"r5_{j}_v"] / 1000, rtol=0, atol=1e-3, equal_nan=True)
             i = yielded[j]
-            region = explained_region(g["r5_frames_a"][i], g["r5_frames_b"][i], 64, 32, 1, "DWS")
+            region, n_const = explained_region(g["r5_frames_a"][i], g["r5_frames_b"][i], 64, 32, 1, "DWS")
             print(f"r5 {precision} pair {i}: {int(bad.sum())} of {bad.size} cells beyond 1e-3 px, "
-                  f"{int((bad & ~region).sum())} unexplained; explained region {region.mean():.2f}")
+                  f"{int((bad & ~region).sum())} unexplained; explained region {region.mean():.2f} ({n_const} constant-input windows)")
             assert not (bad & ~region).any()
+            assert region.mean() <= REGION_CAP or n_const > 0, (i, float(region.mean()))
+            strict_chain(g["r5_frames_a"][i], g["r5_frames_b"][i], 64, 32, 1, "DWS", precision, 1000.0, u, v, f"r5p{i}")
 
 
 def test_function_seam_signatures(golden):

@@ -40,7 +40,7 @@ def test_cfg2_against_oracle(pair, mode, precision):
     a, b = pair
     geo = [(64, 32), (32, 16)]
     g = _oracle_fields(a.cpu().numpy(), b.cpu().numpy(), geo, mode, "cfg2")
-    counts = cascade_check(engine, g, "cfg2", mode, precision, geo, noise_ulps=16.0 if precision == "reference" else 4096.0)
+    counts = cascade_check(engine, g, "cfg2", mode, precision, geo)
     assert counts[-1][-1] == 127 * 127 and counts[-1][0] <= 0.005 * counts[-1][-1]      # (and they stay few)
 
 
@@ -53,7 +53,7 @@ def test_cfg4_large_windows_against_oracle(pair, precision):
     a, b = pair
     geo = [(128, 64), (64, 32)]
     g = _oracle_fields(a.cpu().numpy(), b.cpu().numpy(), geo, "CWS", "cfg4")
-    counts = cascade_check(engine, g, "cfg4", "CWS", precision, geo, noise_ulps=16.0 if precision == "reference" else 4096.0)
+    counts = cascade_check(engine, g, "cfg4", "CWS", precision, geo)
     assert counts[0][-1] == 31 * 31 and counts[-1][-1] == 63 * 63 and counts[-1][0] <= 0.01 * counts[-1][-1]
 
 
@@ -68,7 +68,7 @@ def test_cfg3_geometry_against_oracle(mode):
     geo = [(32, 16), (16, 8), (8, 4)]
     g = _oracle_fields(a.numpy(), b.numpy(), geo, mode, "cfg3")
     for precision in ("reference", "fast"):
-        counts = cascade_check(engine, g, "cfg3", mode, precision, geo, noise_ulps=16.0 if precision == "reference" else 4096.0)
+        counts = cascade_check(engine, g, "cfg3", mode, precision, geo)
         assert counts[-1][-1] == 255 * 383
 
 

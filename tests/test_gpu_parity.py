@@ -293,16 +293,55 @@ def staged_windows(a, b, H, W, w, o, mode, u2, v2):
             O.shift_dws(b, idx, sh(u2).astype(np.int64), sh(v2).astype(np.int64)))
 
 
-def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, noise_ulps=16.0):
-    """The whole plan (all passes on the device, batch of 2) against the reference's fields of EVERY
-    pass, without a fraction threshold: a cell may differ from the reference (value beyond 1e-3 px or
-    other validity) only if
-      (a) its own discrete decisions lie in the reference's float32 noise band (fp32_noise_excuse on
-          the windows the reference staged; pass 1: near-tie windows), or
-      (b) it is downstream of a differing cell of the previous pass: the spline predictor weight
-          |Ay| M |Ax|^T that connects them is >= 1e-4 (a changed coarse vector moves the fine
-          predictor by weight x a few px).
-    Returns the per-pass counts."""
+DRIFT_PX = 1e-4         # bound on |GPU field - reference field| where no discrete decision changed (observed ~1e-6)
+ISO_Q99_PX = 2e-5       # isolation gate: 99 % of the windows outside the band agree with the oracle to this (observed ~1e-6;
+                        # a 1e-3 error in one lerp weight moves the fields by ~1e-4 px: tests/test_gpu_gates.py)
+
+
+def spline_ops(eng, H, W, geo_prev, geo):
+    xc, yc = eng.coordinates_1d(H, W, geo_prev[0], geo_prev[1])
+    xf, yf = eng.coordinates_1d(H, W, geo[0], geo[1])
+    return eng.spline_matrix(yc, yf), eng.spline_matrix(xc, xf)
+
+
+def oracle_pass_from(a, b, geo_prev, geo, mode, u_prev, v_prev, inv_prev):
+    """The oracle's pass (B:690-740 / B:757-812) fed with GIVEN fields of the pass before (numpy; e.g. the
+    GPU's own): returns its u, v, validity and the windows it staged (for the noise band)."""
+    x0, y0 = O.coordinates(a.shape, geo_prev[0], geo_prev[1])
+    it = O.ITER[mode](a.shape, geo[0], geo[1])
+    ru, rv, _, _, rval, _, _, _, _, u2, v2 = it(a, b, x0, y0, u_prev.copy(), v_prev.copy(), inv_prev.copy(), debug=True)
+    f = (lambda t, dt: t.reshape(-1)[:, None, None].astype(dt))
+    if mode == "CWS":
+        aa = O.shift_cws(a, it.idx, -f(u2, np.float32), -f(v2, np.float32))
+        bb = O.shift_cws(b, it.idx, f(u2, np.float32), f(v2, np.float32))
+    else:
+        aa = O.shift_dws(a, it.idx, -f(u2, np.int64), -f(v2, np.int64))
+        bb = O.shift_dws(b, it.idx, f(u2, np.int64), f(v2, np.int64))
+    return ru, rv, rval, aa, bb
+
+
+def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP, max_differing=None,
+                  drift_frac=0.002, drift_min=2, check_drift=True):
+    """The whole plan (all passes on the device, batch of 2) against the reference's fields of EVERY pass.
+    Three gates per pass p; every excuse set is SIZE-CAPPED (constant-input windows aside) and printed:
+
+    (A) reference chain -- GPU field of pass p against the REFERENCE's field of pass p.  A cell may differ
+        (value beyond 1e-3 px or other validity) only if (a) its own discrete decisions lie in the reference's
+        float32 noise band at 16 ulp (fp32_noise_excuse on the windows the reference staged, incl. ill-conditioned
+        fits; pass 0: near-tie windows) or (b) it is downstream of a differing cell of pass p-1 (spline weight
+        |Ay| M |Ax|^T >= 1e-4).  STRICT (no unexplained cell) at precision="reference" and for pass 0.
+    (B) isolation, p >= 1, both precisions -- the ORACLE's pass p fed with the GPU's OWN fields of pass p-1
+        against the plan's pass p under the 16-ulp band of the windows THAT chain staged, no fit clause: isolates
+        every shifted-pass kernel and the plan's predictor hand-off at the size of the test, whatever happened
+        upstream.  STRICT.
+    (C) drift, precision="fast" / "f64", p >= 1 -- the float32 pass 1 sits ~1e-6 px from the float64 reference (and
+        the fast CWS sampling order <= 1e-4 grey levels from the reference's), which can tip a later decision that
+        lies within ~1e-5 (relative) of a threshold; no meaningful band describes that
+        (round 2's 4096-ulp band covered 100 % of the windows), so it is COUNTED instead: cells beyond 1e-4 px
+        (or with other validity) that are neither in the 16-ulp band of (A) nor downstream of such a cell of
+        pass p-1 must stay <= max(drift_min, drift_frac * cells).
+    max_differing: optional per-pass absolute cap on the cells that differ from the reference at all (1e-3 px /
+    validity).  Returns the per-pass counts (differing, in band, downstream, unexplained, cells)."""
     a, b = g[name + "_a"], g[name + "_b"]
     H, W = a.shape
     n_pass = len(geo)
@@ -311,54 +350,87 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, noise_ulps=16.0
     assert [list(t[:2]) for t in plan.geometry] == [list(t) for t in geo]
     u, v, inv = plan.run(dev(np.stack([a, a])), dev(np.stack([b, b])))
     assert torch.equal(u[0], u[1]) and torch.equal(inv[0], inv[1])       # batch items independent
-    prev_M = None
+    fields = [plan.pass_fields(p, 2) if p < n_pass - 1 else (u, v, inv) for p in range(n_pass)]
+    fields = [(t[0][0].cpu().numpy(), t[1][0].cpu().numpy(), t[2][0].cpu().numpy().astype(bool)) for t in fields]
+    plan.close()
+    prev_M = prev_drift = None
     counts = []
+    tag = f"{name} {mode} {precision}"
     for p in range(n_pass):
         w, o = geo[p]
-        pu, pv, pi = plan.pass_fields(p, 2) if p < n_pass - 1 else (u, v, inv)
+        pu, pv, pi = fields[p]
         ru, rv, rval = (g[f"{name}_{mode}_p{p}_{k}"] for k in ("u", "v", "val"))
-        err = np.maximum(np.abs(pu[0].cpu().numpy() - ru), np.abs(pv[0].cpu().numpy() - rv))
-        M = (err > TOL_PX) | (pi[0].cpu().numpy().astype(bool) != rval)
+        err = np.maximum(np.abs(pu - ru), np.abs(pv - rv))
+        flip = pi != rval
+        M = (err > TOL_PX) | flip
         nr, nc = O.field_shape((H, W), w, o)
+        cap_p = 0.05 if w <= 8 else cap
         if p == 0:
-            E = near_tie_windows(a, b, w, o) | pass1_constant(a, b, w, o)
-            D = np.zeros_like(M)
+            const = pass1_constant(a, b, w, o)
+            E = near_tie_windows(a, b, w, o) | const
+            D = Dd = np.zeros_like(M)
         else:
-            wc, oc = geo[p - 1]
-            xc, yc = eng.coordinates_1d(H, W, wc, oc)
-            xf, yf = eng.coordinates_1d(H, W, w, o)
-            Ay_, Ax_ = eng.spline_matrix(yc, yf), eng.spline_matrix(xc, xf)
+            Ay_, Ax_ = spline_ops(eng, H, W, geo[p - 1], geo[p])
             pre = [dev(g[f"{name}_{mode}_p{p-1}_{k}"])[None] for k in ("u", "v")]
             _, _, u2, v2 = eng.predict(mode, dev(Ay_), dev(Ax_), pre[0], pre[1],
                                        dev(g[f"{name}_{mode}_p{p-1}_val"].astype(np.uint8))[None])
             aa, bb = staged_windows(a, b, H, W, w, o, mode, u2, v2)
-            E = fp32_noise_excuse(aa, bb, nr, nc, ulps=noise_ulps, fit_tol=0.5e-3) | constant_windows(aa, bb, nr, nc)
+            const = constant_windows(aa, bb, nr, nc)
+            E = fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5e-3) | const
             D = (np.abs(Ay_) @ prev_M.astype(np.float64) @ np.abs(Ax_).T) >= 1e-4
+            Dd = (np.abs(Ay_) @ prev_drift.astype(np.float64) @ np.abs(Ax_).T) >= 1e-4
+        free = E & ~const
         unexplained = M & ~E & ~D
         counts.append((int(M.sum()), int((M & E).sum()), int((M & ~E & D).sum()), int(unexplained.sum()), M.size))
-        print(f"  {name} {mode} {precision} pass {p} (ws {w}): differing {int(M.sum())} of {M.size}: "
-              f"{int((M & E).sum())} in the noise band, {int((M & ~E & D).sum())} downstream of pass {p - 1}, "
-              f"{int(unexplained.sum())} unexplained; downstream region covers {float(D.mean()):.2f} of the grid")
-        assert not unexplained.any(), (name, mode, precision, p, np.argwhere(unexplained)[:6].tolist(),
-                                       err[unexplained][:6].tolist())
-        prev_M = M
-    plan.close()
+        print(f"  {tag} pass {p} (ws {w}): (A) differing from the reference {int(M.sum())} of {M.size}: "
+              f"{int((M & E).sum())} in the 16-ulp band, {int((M & ~E & D).sum())} downstream of pass {p - 1}, "
+              f"{int(unexplained.sum())} unexplained; band holds {int(free.sum())} non-constant windows "
+              f"({free.mean():.4f}, cap {cap_p}), downstream region {float(D.mean()):.3f} of the grid")
+        assert free.mean() <= cap_p, (tag, p, "excuse set too large", int(free.sum()), M.size)
+        if max_differing is not None:
+            assert M.sum() <= max_differing[p], (tag, p, "differing cells", int(M.sum()), "cap", max_differing[p])
+        if precision == "reference" or p == 0:
+            assert not unexplained.any(), (tag, p, np.argwhere(unexplained)[:6].tolist(), err[unexplained][:6].tolist())
+        drift = (err > DRIFT_PX) | flip
+        if p >= 1:
+            # (B) isolation: oracle pass p from the GPU's own pass p-1
+            gu, gv, gi = fields[p - 1]
+            ou, ov_, oval, aa2, bb2 = oracle_pass_from(a, b, geo[p - 1], geo[p], mode, gu, gv, gi)
+            const2 = constant_windows(aa2, bb2, nr, nc)
+            E2 = fp32_noise_excuse(aa2, bb2, nr, nc, ulps=16.0) | const2
+            err2 = np.maximum(np.abs(pu - ou), np.abs(pv - ov_))
+            M2 = (err2 > TOL_PX) | (pi != oval)
+            free2 = E2 & ~const2
+            clean = ~M2 & ~E2
+            q50, q99, qmax = (np.quantile(err2[clean], [0.5, 0.99, 1.0]) if clean.any() else (0.0, 0.0, 0.0))
+            print(f"  {tag} pass {p} (ws {w}): (B) isolation vs the oracle fed with the GPU's pass {p - 1}: differing "
+                  f"{int(M2.sum())} ({int((M2 & ~E2).sum())} outside the band), band holds {int(free2.sum())} non-constant "
+                  f"windows ({free2.mean():.4f}); |d| elsewhere: median {q50:.2e}, 99 % {q99:.2e}, max {qmax:.2e} px")
+            assert free2.mean() <= cap_p, (tag, p, "isolation excuse set too large", int(free2.sum()))
+            assert not (M2 & ~E2).any(), (tag, p, "isolation", np.argwhere(M2 & ~E2)[:6].tolist(),
+                                          err2[M2 & ~E2][:6].tolist())
+            assert q99 <= ISO_Q99_PX, (tag, p, "isolation: systematic deviation", float(q50), float(q99))
+            if precision != "reference" and check_drift:
+                # (C) drift against the reference chain
+                loose = drift & ~E & ~Dd
+                lim = max(drift_min, int(drift_frac * M.size))
+                print(f"  {tag} pass {p} (ws {w}): (C) drift beyond {DRIFT_PX} px / other validity: {int(drift.sum())}, "
+                      f"of which outside the band and not downstream: {int(loose.sum())} (cap {lim})")
+                assert loose.sum() <= lim, (tag, p, "drift", int(loose.sum()), lim, np.argwhere(loose)[:6].tolist())
+        prev_M, prev_drift = M, drift
     return counts
 
 
 @pytest.mark.parametrize("precision", ["reference", "fast"])
 @pytest.mark.parametrize("mode", ["DWS", "CWS"])
 def test_multipass_plan_end_to_end(eng, golden, mode, precision):
-    """Whole-plan cascade on every multipass golden; see cascade_check for the (threshold-free) rule.
-    precision="reference" runs pass 1 in float64 like the reference, so that no pass-1 rounding leaks
-    into the later passes; "fast" is the float32 pass 1, whose ~1e-6 px deviations may tip decisions
-    that sit within 1e-4 (relative) of a threshold in later passes (wider noise band)."""
+    """Whole-plan cascade on every multipass golden; see cascade_check for the three gates (reference chain,
+    per-pass isolation against the oracle fed with the GPU's own fields, counted drift at fast precision)."""
     g = golden("g4_multipass")
     for name in g["names"]:
         ws, ov, n_pass = (int(t) for t in g[name + "_cfg"])
         geo = [(ws >> p, ov >> p) for p in range(n_pass)]
-        counts = cascade_check(eng, g, name, mode, precision, geo,
-                               noise_ulps=16.0 if precision == "reference" else 4096.0)
+        counts = cascade_check(eng, g, name, mode, precision, geo)
         # sanity on top of the rule: differing cells stay a small minority unless the fixture has
         # constant-input blocks ("special")
         if "special" not in name:
@@ -474,8 +546,7 @@ def test_generic_sizes_multipass(eng, golden, mode):
                                 constant=constant_windows(aa, bb, nr, nc))
             print(f"generic {name} {mode} pass {p} (ws {w}/{o}): max err {e:.2e} px, mask flips {f}")
         for precision in ("reference", "fast"):
-            cascade_check(eng, g, name, mode, precision, [(int(t[0]), int(t[1])) for t in geo], scale=scale,
-                          noise_ulps=16.0 if precision == "reference" else 4096.0)
+            cascade_check(eng, g, name, mode, precision, [(int(t[0]), int(t[1])) for t in geo], scale=scale)
 
 
 @pytest.mark.parametrize("ws,planar", [(8, False), (8, True), (8, 2), (16, False), (16, True), (32, False), (32, True),

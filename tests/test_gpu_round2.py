@@ -124,8 +124,7 @@ def test_shifted_128_windows(eng, golden, mode):
     assert np.array_equal(win[0, :, 0].cpu().numpy(), aa.astype(np.float32))
     assert np.array_equal(win[0, :, 1].cpu().numpy(), bb.astype(np.float32))
     for precision in ("reference", "fast"):
-        cascade_check(eng, g, name, mode, precision, [(ws, ov), (w, o)],
-                      noise_ulps=16.0 if precision == "reference" else 4096.0)
+        cascade_check(eng, g, name, mode, precision, [(ws, ov), (w, o)])
 
 
 def test_function_seam_two_streams(eng):
@@ -273,6 +272,26 @@ def test_postval_device_vs_host(eng, golden):
     assert np.array_equal(got[~hole], g["pv_borders"][~hole])
 
 
+def test_postval_single_row_or_column_grid(eng):
+    """A final grid with ONE row or column (a short frame under a large window): tpiv_postval accepts it and the
+    census drops the pair like the reference does (its interpolator has no usable ring: Qhull refuses collinear
+    points / no points at all) -- the old check raised EINVAL here."""
+    rng = np.random.default_rng(8)
+    for shape in ((1, 9), (7, 1)):
+        u = torch.from_numpy(rng.standard_normal((2,) + shape)).cuda()
+        v = torch.from_numpy(rng.standard_normal((2,) + shape)).cuda()
+        m = np.zeros((2,) + shape, np.uint8)
+        m[0].flat[3] = 1
+        cls, counts = eng.postval(u, v, torch.from_numpy(m).cuda())
+        counts = counts.cpu().numpy()
+        # the border interpolation fills the hole (every cell is a border cell), so no ring is left: dropped,
+        # exactly as the host path decides (post_validate -> None)
+        assert counts[:, 1].tolist() == [0, 0], counts
+        for k in range(2):
+            hu, hv = _host_postval(u[k].cpu().numpy(), v[k].cpu().numpy(), m[k].astype(bool))
+            assert hu is None and hv is None
+
+
 def test_resident_generator_equals_host_post_validation(eng):
     """ResidentPIV (device post-validation + counted host fallbacks) against the same kernels' raw fields
     pushed through the host-only reference path: identical drops, values to 1e-12."""
@@ -412,8 +431,7 @@ def test_odd_window_in_a_shifted_pass(eng, golden, mode):
                         excused=fp32_noise_excuse(aa, bb, nr, nc), constant=constant_windows(aa, bb, nr, nc))
     print(f"odd window 33 {mode}: max err {e:.2e} px, mask flips {f}")
     for precision in ("reference", "fast"):
-        cascade_check(eng, g, name, mode, precision, [(ws, ov), (w, o)],
-                      noise_ulps=16.0 if precision == "reference" else 4096.0)
+        cascade_check(eng, g, name, mode, precision, [(ws, ov), (w, o)])
 
 
 @pytest.mark.parametrize("precision", ["reference", "fast"])
@@ -425,8 +443,7 @@ def test_other_scales_and_zero_overlap(eng, golden, mode, precision):
     g = golden("g11_scales")
     for name in g["names"]:
         geo = [tuple(int(t) for t in row) for row in g[name + "_geo"]]
-        cascade_check(eng, g, str(name), mode, precision, geo, scale=float(g[name + "_scale"][0]),
-                      noise_ulps=16.0 if precision == "reference" else 4096.0)
+        cascade_check(eng, g, str(name), mode, precision, geo, scale=float(g[name + "_scale"][0]))
 
 
 def test_cws_fast_iteration_golden(eng, golden):

@@ -23,6 +23,17 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(_lib.lib, name), name
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert _lib.lib.tpiv_version() == _lib.ABI_VERSION == 2
+    # the production library keeps no state: the stamp setter of the diagnostic build is not in it
+    assert not hasattr(_lib.lib, "tpiv_debug_set_stamps")
+    assert _lib.PRECISIONS == {"fast": 0, "reference": 1, "f64": 2}
+
+
+def test_reference_helper_names():
+    """atoi / natural_keys of PlotterFunctions.py:27-37 (the reference's own behaviour on the same inputs)."""
+    from torchpiv_amd import io as pio
+    assert pio.atoi("123") == 123 and pio.atoi("abc") == "abc" and pio.atoi("") == ""
+    assert pio.natural_keys("image10_a.bmp") == ["image", 10, "_a.bmp"]
+    assert sorted(["im10", "im9", "im1"], key=pio.natural_keys) == ["im1", "im9", "im10"]
 
 
 def test_geometry_matches_reference(golden):

@@ -116,7 +116,10 @@ def test_run_folder_matches_generator(tmp_path, golden):
     from test_gpu_api import explained_region
     region = np.zeros(close.shape, bool)
     for a, b in zip(g["frames_a"], g["frames_b"]):
-        region |= explained_region(a, b, ws, ov, mp_, ("DWS", "CWS")[mode])
+        region |= explained_region(a, b, ws, ov, mp_, ("DWS", "CWS")[mode])[0]
     print(f"  mean field within 1e-3 px of the reference's: {close.mean():.4f}; unexplained cells "
           f"{int((~close & ~region).sum())}; explained region {region.mean():.2f}")
+    # (the ensemble holds pairs with black / saturated blocks, whose coin-toss windows explain much of this small
+    #  grid; the region-free statement is the bit-equality with the generator's own tuples above, and the
+    #  generator's parity is tests/test_gpu_api.py::test_offline_piv_generator's strict chain)
     assert not (~close & ~region).any()

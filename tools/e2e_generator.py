@@ -48,24 +48,28 @@ def rate(gen, n):
     return n / dt, k
 
 
-def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0):
-    out = {}
+def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True, budget_s=None, precision="f64"):
+    """Rates in pairs/s per case; `files` adds the BMP cases (skipped once `budget_s` seconds are spent)."""
+    out = {"precision": precision}
+    t_start = time.perf_counter()
     for kind in ("clean", "runs", "spots"):
         A, B = make_frames(n, H, W, kind)
-        piv = T.ResidentPIV(A, B, 64, 32, multipass=2, multipass_mode="CWS")
+        piv = T.ResidentPIV(A, B, 64, 32, multipass=2, multipass_mode="CWS", precision=precision)
         piv.fill_workers = workers
         rate(piv.batched(batch), n)                      # warm-up: plan creation
         piv.reset_stats()
         r, k = rate(piv.batched(batch), n)
         out[kind] = r
+        out.setdefault("stats", {})[kind] = dict(piv.stats, yielded=k)
         print(f"resident {kind:6s}: {r:8.1f} pairs/s ({k} of {n} yielded)  {piv.stats}")
-        if kind == "spots":
+        over = budget_s is not None and time.perf_counter() - t_start > budget_s
+        if kind == "spots" and files and not over:
             from PIL import Image
             d = tempfile.mkdtemp()
             for i in range(n):
                 Image.fromarray(A[i].cpu().numpy(), "L").save(os.path.join(d, f"img{i:04d}_a.bmp"))
                 Image.fromarray(B[i].cpu().numpy(), "L").save(os.path.join(d, f"img{i:04d}_b.bmp"))
-            fp = T.OfflinePIV(d, "cuda:0", "bmp", 64, 32, multipass=2, multipass_mode="CWS")
+            fp = T.OfflinePIV(d, "cuda:0", "bmp", 64, 32, multipass=2, multipass_mode="CWS", precision=precision)
             fp.fill_workers = workers
             if read_threads:
                 fp.read_threads = read_threads
@@ -77,9 +81,13 @@ def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0):
             r, k = rate(fp(), n)
             out["files_call"] = r
             print(f"files    __call__ (the reference's generator API; reads ahead {fp.call_batch} pairs per launch): {r:8.1f} pairs/s")
-            fp.call_batch = 1
-            r, k = rate(fp(), n)
-            print(f"files    __call__ with call_batch = 1 (one pair per launch, host decode): {r:8.1f} pairs/s")
+            if budget_s is None:
+                fp.call_batch = 1
+                r, k = rate(fp(), n)
+                print(f"files    __call__ with call_batch = 1 (one pair per launch, host decode): {r:8.1f} pairs/s")
+            fp.close()
+            import shutil
+            shutil.rmtree(d, ignore_errors=True)
         piv.close()
         del A, B
     return out
@@ -87,4 +95,5 @@ def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0):
 
 if __name__ == "__main__":
     main(int(sys.argv[1]) if len(sys.argv) > 1 else 128, workers=int(sys.argv[2]) if len(sys.argv) > 2 else 0,
-         read_threads=int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+         read_threads=int(sys.argv[3]) if len(sys.argv) > 3 else 0,
+         precision=sys.argv[4] if len(sys.argv) > 4 else "f64")

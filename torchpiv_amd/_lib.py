@@ -16,8 +16,8 @@ OK, EINVAL, EKEY, EHIP, ENOMEM, EUNSUPPORTED = 0, 1, 2, 3, 4, 5
 MODE_DWS, MODE_CWS, MODE_CWS_FAST = 1, 2, 3
 MODES = {"DWS": MODE_DWS, "CWS": MODE_CWS}           # the multipass modes of OfflinePIV (IterModMap, B:814-818)
 ITER_MODES = dict(MODES, CWS_Fast=MODE_CWS_FAST)     # + piv_iteration_CWS_Fast (function-level seam only)
-PREC_FAST, PREC_REFERENCE = 0, 1
-PRECISIONS = {"fast": PREC_FAST, "reference": PREC_REFERENCE}
+PREC_FAST, PREC_REFERENCE, PREC_F64 = 0, 1, 2
+PRECISIONS = {"fast": PREC_FAST, "reference": PREC_REFERENCE, "f64": PREC_F64}
 ABI_VERSION = 2
 
 

@@ -25,6 +25,8 @@ import numpy as np
 import torch
 
 from . import engine
+from ._lib import PRECISIONS
+from ._qhull import qhull_fill      # numpy/scipy-only module: the fill worker processes import nothing else
 from .io import PIVDataset, ToTensor, natural_keys  # noqa: F401  (re-exported like the reference)
 
 
@@ -122,11 +124,11 @@ def moving_window_array(array: torch.Tensor, window_size, overlap) -> torch.Tens
 # pass 1 (B:459-520)
 # ----------------------------------------------------------------------------------------
 def extended_search_area_piv(frame_a, frame_b, window_size=32, overlap=0, validate: bool = False,
-                             validation_ratio: float = 1.2, precision: str = "fast"):
+                             validation_ratio: float = 1.2, precision: str = "f64"):
     """First-pass PIV of one pair.  frame_a / frame_b: uint8 tensors [H, W] on a ROCm device.
     Returns (u, v, x, y, mask) as numpy arrays like the reference (mask None if not validate).
     Raises ValueError for overlap >= window_size or a window larger than the image.
-    precision (extension): "fast" = float32 transforms, "reference" = float64 like B:513-514."""
+    precision (extension): "f64" / "reference" = float64 like B:513-514 (the default), "fast" = float32 transforms."""
     H, W = frame_a.shape[-2], frame_a.shape[-1]
     u, v, inv = engine.pass1(frame_a, frame_b, int(window_size), int(overlap),
                              val_ratio=float(validation_ratio), precision=precision)
@@ -211,7 +213,12 @@ class IterModMap:
 # post-validation on the host (B:266-344, B:884-892)
 # ----------------------------------------------------------------------------------------
 def nan_helper(y):
-    return np.isnan(y), lambda z: z.nonzero()[0]
+    """(NaN mask, index helper) of a 1-D array -- the reference's helper of the same name (B:311-326)."""
+    mask = np.isnan(y)
+
+    def indices(selector):
+        return np.flatnonzero(selector)
+    return mask, indices
 
 
 def interpolate_boarders(vec: np.ndarray) -> np.ndarray:
@@ -239,26 +246,32 @@ def getPixelsForInterp(img):
     return dil & ~invalid, invalid
 
 
+TOO_MANY_MSG = "Warning! to many false vectors"      # the reference's stdout line (B:306), spelling included
+
+
 def fillMissingValues(target_for_interp, interpolator=None):
-    """Fill NaN holes by Delaunay-linear interpolation from the ring of valid neighbours.
-    Returns None when that fails -- including, as in the reference, when there is no invalid
-    vector at all (no points -> the interpolator raises -> bare except, B:300-304) -- or when
-    at least a quarter of the cells would be ring points ('too many false vectors')."""
-    if interpolator is None:
-        from scipy import interpolate
-        interpolator = interpolate.LinearNDInterpolator
-    ring, invalid = getPixelsForInterp(target_for_interp)
-    points = np.argwhere(ring)
-    values = target_for_interp[ring]
-    if points.size < ring.size / 2:
-        try:
-            interp = interpolator(points, values)
-            target_for_interp[invalid] = interp(np.argwhere(invalid))
-        except Exception:
-            return None
-    else:
-        print("Warning! to many false vectors")
+    """Fill NaN holes by Delaunay-linear interpolation from the ring of valid neighbours (B:284-308), in place.
+    None -- the pair is to be dropped -- when the ring holds a quarter of the cells or more (the reference's
+    size test on the flattened point list, with its warning line), when there is nothing to interpolate from
+    (no invalid vector at all: the reference's interpolator raises on zero points and its bare `except`
+    swallows that, B:300-304) or when Qhull refuses the ring.  `interpolator`: optional stand-in for scipy's
+    LinearNDInterpolator class."""
+    ring, holes = getPixelsForInterp(target_for_interp)
+    n_ring = int(np.count_nonzero(ring))
+    if 4 * n_ring >= ring.size:                       # 2 coordinates per ring point against size / 2
+        print(TOO_MANY_MSG)
         return None
+    where_ring, where_holes = np.argwhere(ring), np.argwhere(holes)
+    if interpolator is None:
+        vals = qhull_fill(where_ring, target_for_interp[ring], where_holes)
+    else:
+        try:
+            vals = interpolator(where_ring, target_for_interp[ring])(where_holes)
+        except Exception:
+            vals = None
+    if vals is None:
+        return None
+    target_for_interp[holes] = vals
     return target_for_interp
 
 
@@ -286,18 +299,6 @@ def _ring_of(hole: np.ndarray) -> np.ndarray:
     ring[:, :-1] |= hole[:, 1:]
     ring &= ~hole
     return ring
-
-
-def qhull_fill(points: np.ndarray, values: np.ndarray, targets: np.ndarray):
-    """The triangulation step of fillMissingValues (B:300-302) on plain arrays: Delaunay-linear
-    interpolation of `values` [n, k] given at integer `points` [n, 2], evaluated at `targets` [m, 2].
-    None when Qhull refuses the points (the reference's bare `except` then drops the pair).  A pure
-    function of small arrays, so that it can run in worker processes (OfflinePIV.fill_workers)."""
-    from scipy.interpolate import LinearNDInterpolator
-    try:
-        return LinearNDInterpolator(points, values)(targets)
-    except Exception:
-        return None
 
 
 def fill_holes_host(u: np.ndarray, v: np.ndarray, hole: np.ndarray, solve=qhull_fill):
@@ -335,10 +336,12 @@ class OfflinePIV:
 
     def __init__(self, folder: str, device: str, file_fmt: str, wind_size: int, overlap: int,
                  multipass: int = 1, multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.,
-                 multipass_scale: float = 2., folder_mode: str = "pairs", precision: str = "fast") -> None:
-        # precision (extension, keyword after the reference's arguments): "fast" runs pass 1 in float32,
-        # "reference" in float64 like the reference (B:513-514); later passes are float32 in both.
-        if precision not in ("fast", "reference"):
+                 multipass_scale: float = 2., folder_mode: str = "pairs", precision: str = "f64") -> None:
+        # precision (extension, keyword after the reference's arguments).  "f64" (default): the reference's own
+        # arithmetic types -- pass 1 in float64 (B:513-514), later passes float32 with a float64 epilogue.
+        # "reference": the same plus the reference's operation order in the CWS sampling (bit-identical staged
+        # windows).  "fast": pass 1 in float32 too (~1e-6 px from the float64 pass 1, about 1.9x the rate).
+        if precision not in PRECISIONS:
             raise KeyError(precision)
         self._precision = precision
         self._wind_size = wind_size
@@ -448,7 +451,7 @@ class OfflinePIV:
         st["dropped_no_invalid"] += int(no_ring.sum())
         st["dropped_too_many"] += int(too_many.sum())
         for _ in range(2 * int(too_many.sum())):                  # once for u, once for v (B:306, B:889-890)
-            print("Warning! to many false vectors")
+            print(TOO_MANY_MSG)
         out = [None] * n
         jobs = []
         for i in np.flatnonzero(keep):
@@ -560,7 +563,7 @@ class OfflinePIV:
         cap = (max(sizes) + 4095) // 4096 * 4096
         # (page-locking half a gigabyte takes a tenth of a second: the staging buffers are kept for the next call)
         key = (batch_size, cap)
-        prev = getattr(self, "_loader", None)            # (an abandoned generator may have left its loader running)
+        prev = getattr(self, "_loader", None)            # (a loader that outlived its generator still owns the buffers)
         if getattr(self, "_stage_key", None) != key or (prev is not None and prev.is_alive()):
             self._stage = [torch.empty(2 * batch_size, cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
             self._stage_key = key
@@ -569,6 +572,16 @@ class OfflinePIV:
         for e in free:
             e.set()
         q = queue.Queue(maxsize=2)
+        stop = threading.Event()         # set when the consumer is done or gone: the loader must not block for ever
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return True
+                except queue.Full:
+                    continue
+            return False
 
         def loader():
             from concurrent.futures import ThreadPoolExecutor
@@ -578,7 +591,11 @@ class OfflinePIV:
                 with ThreadPoolExecutor(max_workers=self.read_threads) as ex:
                     for n, s0 in enumerate(range(0, len(idx), batch_size)):
                         buf = n % 2
-                        free[buf].wait()
+                        while not free[buf].wait(0.2):
+                            if stop.is_set():
+                                return
+                        if stop.is_set():
+                            return
                         free[buf].clear()
                         raw = stage[buf].numpy()
                         ids = idx[s0:s0 + batch_size]
@@ -602,9 +619,10 @@ class OfflinePIV:
                             lut_b.append(lb[4])
                             chunk.append(i)
                         # unpacked frame order: every a of the batch, then every b (two contiguous stacks)
-                        q.put((buf, len(ids), chunk, desc_a + desc_b, lut_a + lut_b, order))
+                        if not put((buf, len(ids), chunk, desc_a + desc_b, lut_a + lut_b, order)):
+                            return
             finally:
-                q.put(None)
+                put(None)
 
         th = threading.Thread(target=loader, daemon=True)
         th.start()
@@ -623,32 +641,44 @@ class OfflinePIV:
                 if out is not None:
                     yield (i,) + out
 
-        while True:
-            item = q.get()
-            if item is None:
-                break
-            buf, n_slots, chunk, desc, luts, order = item
-            ticket = None
-            if chunk:
-                n = len(chunk)
-                raw_d = stage[buf][:2 * n_slots].to(dev, non_blocking=True)
-                up = torch.cuda.Event()
-                up.record()
-                desc_d = torch.tensor(desc, dtype=torch.int64).to(dev, non_blocking=True)
-                lut_d = torch.from_numpy(np.stack(luts)).to(dev, non_blocking=True)
-                frames = engine.bmp_unpack(raw_d.view(-1), desc_d, lut_d, H, W)      # [2n, H, W]: a_0..a_n-1, b_0..b_n-1
-                u, v, inv = plan.run(frames[:n], frames[n:])
-                ticket = self._post_submit(u, v, inv)
-            # the host work of the PREVIOUS batch runs while the GPU works on this one
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                buf, n_slots, chunk, desc, luts, order = item
+                ticket = None
+                if chunk:
+                    n = len(chunk)
+                    raw_d = stage[buf][:2 * n_slots].to(dev, non_blocking=True)
+                    up = torch.cuda.Event()
+                    up.record()
+                    desc_d = torch.tensor(desc, dtype=torch.int64).to(dev, non_blocking=True)
+                    lut_d = torch.from_numpy(np.stack(luts)).to(dev, non_blocking=True)
+                    frames = engine.bmp_unpack(raw_d.view(-1), desc_d, lut_d, H, W)      # [2n, H, W]: a_0..a_n-1, b_0..b_n-1
+                    u, v, inv = plan.run(frames[:n], frames[n:])
+                    ticket = self._post_submit(u, v, inv)
+                # the host work of the PREVIOUS batch runs while the GPU works on this one
+                if pending is not None:
+                    yield from drain(pending)
+                pending = (order, chunk, ticket)
+                if chunk:
+                    up.synchronize()                  # staging buffer may be refilled now
+                free[buf].set()
             if pending is not None:
                 yield from drain(pending)
-            pending = (order, chunk, ticket)
-            if chunk:
-                up.synchronize()                  # staging buffer may be refilled now
-            free[buf].set()
-        if pending is not None:
-            yield from drain(pending)
-        th.join()
+        finally:
+            # consumer finished, raised, or abandoned the generator (GeneratorExit lands here): release the
+            # loader -- it may sit in a full queue or wait for a staging buffer -- and let it end
+            stop.set()
+            for e in free:
+                e.set()
+            try:
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=5.0)
 
 
 class ResidentPIV(OfflinePIV):
@@ -658,11 +688,11 @@ class ResidentPIV(OfflinePIV):
 
     def __init__(self, frames_a: torch.Tensor, frames_b: torch.Tensor, wind_size: int, overlap: int,
                  multipass: int = 1, multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.,
-                 multipass_scale: float = 2., precision: str = "fast") -> None:
+                 multipass_scale: float = 2., precision: str = "f64") -> None:
         if frames_a.shape != frames_b.shape or frames_a.dim() != 3 or frames_a.dtype != torch.uint8 \
                 or frames_b.dtype != torch.uint8:
             raise ValueError("ResidentPIV: two uint8 tensors [n, H, W] of one shape")
-        if precision not in ("fast", "reference"):
+        if precision not in PRECISIONS:
             raise KeyError(precision)
         self._precision = precision
         self._wind_size, self._overlap, self._dt = wind_size, overlap, dt

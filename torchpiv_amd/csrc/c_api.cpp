@@ -16,7 +16,11 @@
 namespace {
 
 thread_local std::string g_err;
-unsigned long long* g_stamps = nullptr;      // diagnostic builds: device buffer for phase stamps
+#ifdef TPIV_STAMPS
+unsigned long long* g_stamps = nullptr;      // diagnostic builds (make stamps) only: device buffer for phase stamps
+#else
+constexpr unsigned long long* g_stamps = nullptr;      // the production library keeps no state
+#endif
 
 int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -192,6 +196,8 @@ int spline_matrix(int nc, const double* xc, int nf, const double* xf, double* A)
     return TPIV_OK;
 }
 
+bool valid_precision(int p) { return p == TPIV_PREC_FAST || p == TPIV_PREC_REFERENCE || p == TPIV_PREC_F64; }
+
 struct PassGeo {
     int ws, ov, n_rows, n_cols;
     std::vector<double> x, y;
@@ -360,8 +366,7 @@ static int pass1_impl(const uint8_t* a, const uint8_t* b, int batch, int H, int 
                       void* work, size_t work_bytes, float* dbg_win, float* dbg_corr, void* stream) {
     int rc = check_window(H, W, ws, ov, val_win);
     if (rc) return rc;
-    if (precision != TPIV_PREC_FAST && precision != TPIV_PREC_REFERENCE)
-        return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST or TPIV_PREC_REFERENCE");
+    if (!valid_precision(precision)) return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST, TPIV_PREC_REFERENCE or TPIV_PREC_F64");
     if (batch <= 0) return TPIV_OK;
     tpiv::PassParams p{};
     p.dbg_win = dbg_win;
@@ -445,8 +450,7 @@ static int run_iter(int mode, int precision, const uint8_t* a, const uint8_t* b,
     if (mode == TPIV_MODE_CWS_FAST && ws < 2) return fail(TPIV_EINVAL, "window too small");
     if (mode != TPIV_MODE_CWS_FAST && !pmask && (!u2 || !v2)) return fail(TPIV_EINVAL, "tpiv_iter: u2 / v2 missing");
     if (!u0 || !v0) return fail(TPIV_EINVAL, "tpiv_iter: u0 / v0 missing");
-    if (precision != TPIV_PREC_FAST && precision != TPIV_PREC_REFERENCE)
-        return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST or TPIV_PREC_REFERENCE");
+    if (!valid_precision(precision)) return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST, TPIV_PREC_REFERENCE or TPIV_PREC_F64");
     if (batch <= 0) return TPIV_OK;
     tpiv::PassParams p{};
     p.A = a;
@@ -534,8 +538,7 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
         return fail(TPIV_EKEY, "unknown multipass mode");
     if (max_batch < 1) return fail(TPIV_EINVAL, "max_batch must be >= 1");
     if (!(pass_scale > 0)) return fail(TPIV_EINVAL, "multipass_scale must be positive");
-    if (precision != TPIV_PREC_FAST && precision != TPIV_PREC_REFERENCE)
-        return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST or TPIV_PREC_REFERENCE");
+    if (!valid_precision(precision)) return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST, TPIV_PREC_REFERENCE or TPIV_PREC_F64");
     tpiv_plan* pl = new tpiv_plan();
     pl->precision = precision;
     pl->H = H;
@@ -756,7 +759,7 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
 
 int tpiv_postval(double* u, double* v, const uint8_t* invalid, int batch, int n_rows, int n_cols, uint8_t* cls,
                  int32_t* counts, void* stream) {
-    if (batch < 0 || n_rows < 2 || n_cols < 2) return fail(TPIV_EINVAL, "tpiv_postval: needs a grid of at least 2 x 2");
+    if (batch < 0 || n_rows < 1 || n_cols < 1) return fail(TPIV_EINVAL, "tpiv_postval: empty grid");
     if ((long long)n_rows * n_cols >= (1LL << 31)) return fail(TPIV_EUNSUPPORTED, "field too large");
     if (batch == 0) return TPIV_OK;
     if (!u || !v || !invalid || !cls || !counts) return fail(TPIV_EINVAL, "tpiv_postval: null pointer");
@@ -790,13 +793,14 @@ int tpiv_bmp_unpack(const uint8_t* raw, const int64_t* desc, const uint8_t* lut,
     return TPIV_OK;
 }
 
-// Diagnostic builds (make stamps): device buffer of 32 uint64 that the tile kernels add their
-// per-phase s_memtime deltas to.  Not declared in the public header: the production library
-// ignores it (the stamp code is compiled out).
+#ifdef TPIV_STAMPS
+// Diagnostic builds only (make stamps): device buffer of 32 uint64 that the tile kernels add their
+// per-phase s_memtime deltas to.  The production library has neither this setter nor any other state.
 int tpiv_debug_set_stamps(void* dev_buffer) {
     g_stamps = static_cast<unsigned long long*>(dev_buffer);
     return TPIV_OK;
 }
+#endif
 
 int tpiv_plan_set_timing(tpiv_plan* plan, int enable) {
     if (!plan) return fail(TPIV_EINVAL, "null plan");

@@ -147,7 +147,14 @@ size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool forc
 
 // (in the demangled form rocprofv3 prints, so that profile rows can be matched by substring; the MODE
 //  template argument is the tpiv::MODE_* value: 0 pass 1, 1 DWS, 2 CWS)
+// TPIV_PREC_F64 (2): float64 pass 1, fast operation order in the shifted passes
+static int pass_precision(int precision, int mode) {
+    if (precision == 2) return mode == MODE_PASS1 ? 1 : 0;
+    return precision;
+}
+
 const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len) {
+    precision = pass_precision(precision, mode);
     if (precision && mode == MODE_PASS1) {
         if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_kernel<%d>", ws);
         else snprintf(buf, len, "xcorr_generic_kernel<0, double>");
@@ -168,6 +175,7 @@ const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int le
 hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t stream) {
     hipError_t e;
     PassParams p = p_in;
+    p.precision = pass_precision(p.precision, mode);
     // float64 exists for pass 1 only (the reference's later passes are float32, B:249-257); for shifted
     // passes precision != 0 selects the tile kernel's reference-order arithmetic (xcorr_tile.hpp)
     const bool f64 = p.precision != 0 && mode == MODE_PASS1;

@@ -965,7 +965,13 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                     const float4 wx = wbuf[k];
                     const float na = fmaf(byte_f<k + 1, NB>(ra1), c.wya_dn, byte_f<k + 1, NB>(ra0) * c.wya_up);
                     const float nb = fmaf(byte_f<k + 1, NB>(rb1), c.wyb_dn, byte_f<k + 1, NB>(rb0) * c.wyb_up);
+#ifdef TPIV_MUTANT_LERP
+                    // tests only (tools/diag/libtorchpiv_hip_mutant.so, never shipped): one weight of the column
+                    // lerp off by 1e-3 -- the parity gates must notice (tests/test_gpu_gates.py)
+                    x[k].x = fmaf(na, wx.y * 1.001f, va * wx.x);
+#else
                     x[k].x = fmaf(na, wx.y, va * wx.x);
+#endif
                     x[k].y = fmaf(nb, wx.w, vb * wx.z);
                     va = na;
                     vb = nb;

@@ -49,6 +49,13 @@ def shard_indices(n_pairs: int, rank: int, world: int, policy: str = "block"):
     return list(range(lo, lo + q + (1 if rank < r else 0)))
 
 
+def _numel(shape) -> int:
+    n = 1
+    for d in shape:
+        n *= int(d)
+    return n
+
+
 def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=None):
     """Gather variable-length shards onto rank `dst`.
 
@@ -57,9 +64,10 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
     Returns (ids_all, fields_all) sorted by dataset index on `dst`, (None, None) elsewhere.
     Ranks with nothing to send pass fields of shape [0, ...]; their tail shape is taken from the ranks
     that have data (exchanged with the counts), so an empty shard needs no plan.
-    One count all-gather (8 + 8*6 bytes per rank) + one padded payload gather onto `dst`: on xGMI's full
-    mesh the seven shards arrive over seven different links at once, and no other rank has to hold
-    the whole result (an all-gather would move and store world x more).
+    TWO collectives: one count / shape all-gather (56 bytes per rank) + one payload gather onto `dst` whose
+    byte buffer carries the fields AND their ids: on xGMI's full mesh the seven shards arrive over seven
+    different links at once, and no other rank has to hold the whole result (an all-gather would move and
+    store world x more).
     """
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         order = torch.argsort(ids)
@@ -96,24 +104,34 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
                 raise ValueError(f"gather_fields: rank {r_} holds fields of shape {t_r}, rank {int(have[0])} {tail}")
     if ids.numel() == 0:
         fields = fields.new_zeros((0,) + tail)
-    pad_f = torch.zeros((n_max,) + tail, dtype=fields.dtype, device=dev)
+    if n_max == 0:          # nothing anywhere (every rank knows it from the counts: no second collective)
+        if rank != dst:
+            return None, None
+        return ids.new_zeros(0).to(out_dev), fields.new_zeros((0,) + tail).to(out_dev)
+    # ONE payload collective: the ids ride behind the fields in the same byte buffer (fields padded to the
+    # largest shard -- dist.gather needs equal sizes; block shards differ by at most one pair unless pairs
+    # were dropped)
+    fields = fields.contiguous()
+    f_bytes = n_max * _numel(tail) * fields.element_size()
+    buf = torch.zeros(f_bytes + n_max * 8, dtype=torch.uint8, device=dev)
     pad_i = torch.full((n_max,), -1, dtype=torch.int64, device=dev)
-    pad_f[: ids.numel()] = fields
     pad_i[: ids.numel()] = ids.to(dev)
+    if ids.numel():
+        buf[: fields.numel() * fields.element_size()] = fields.reshape(-1).view(torch.uint8)
+    buf[f_bytes:] = pad_i.view(torch.uint8)
     if rank == dst:
-        all_f = torch.empty((world * n_max,) + tail, dtype=fields.dtype, device=dev)
-        all_i = torch.empty(world * n_max, dtype=torch.int64, device=dev)
-        lst_f = list(all_f.view((world, n_max) + tail).unbind(0))
-        lst_i = list(all_i.view(world, n_max).unbind(0))
+        all_b = torch.empty(world, buf.numel(), dtype=torch.uint8, device=dev)
+        lst = list(all_b.unbind(0))
     else:
-        lst_f = lst_i = None
+        lst = None
     dst_global = dist.get_global_rank(group, dst) if group is not None else dst
     # (gather is implemented by both backends this package runs on -- RCCL and gloo; any error here is a
     #  real one and propagates: a fallback decided per rank could leave the ranks in different collectives)
-    dist.gather(pad_f, gather_list=lst_f, dst=dst_global, group=group)
-    dist.gather(pad_i, gather_list=lst_i, dst=dst_global, group=group)
+    dist.gather(buf, gather_list=lst, dst=dst_global, group=group)
     if rank != dst:
         return None, None
+    all_f = all_b[:, :f_bytes].contiguous().view(fields.dtype).view((world * n_max,) + tail)
+    all_i = all_b[:, f_bytes:].contiguous().view(torch.int64).reshape(-1)
     keep = all_i >= 0
     all_i, all_f = all_i[keep], all_f[keep]
     order = torch.argsort(all_i)

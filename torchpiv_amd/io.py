@@ -26,8 +26,8 @@ def natural_keys(text):
     return [int(part) if part.isdigit() else part for part in _DIGIT_RUNS.split(text)]
 
 
-def atoi(text):          # kept for callers of the reference's helper name
-    return natural_keys(text)[0] if text.isdigit() else text
+def atoi(text):          # PlotterFunctions.py:27-28, kept for callers of the reference's helper name
+    return int(text) if text.isdigit() else text
 
 
 def _bgr_to_gray(b, g, r):

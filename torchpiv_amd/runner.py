@@ -71,9 +71,10 @@ class EnsembleStats:
     with the reference's arithmetic: it stacks every field and takes TWO-PASS means with numpy, which
     accumulates along the stack axis in order, so `mean = ((f0 + f1) + f2 ...) / n` and
     `uu = sum_k (f_k - mean)^2 / n` in that order are reproduced bit for bit (a streaming
-    E[x^2] - E[x]^2 would cancel where the two-pass form does not).  The fields are kept as a stack --
-    4000 fields of 127 x 127 are 1 GB -- and the moments come from one kernel on the GPU
-    (tpiv_ensemble_moments: one thread per grid cell walks the stack in order) or from numpy."""
+    E[x^2] - E[x]^2 would cancel where the two-pass form does not).  The fields are kept on the host until
+    the end of the run (O(n) memory, see moments()) and the moments come from a kernel on the GPU
+    (tpiv_ensemble_moments: one thread per grid cell walks the stack in order), chunk of cells by chunk of
+    cells, or from numpy."""
 
     def __init__(self):
         self.ids, self.u, self.v = [], [], []
@@ -107,21 +108,50 @@ class EnsembleStats:
         self.u = [fields[k, 0] for k in range(fields.shape[0])]
         self.v = [fields[k, 1] for k in range(fields.shape[0])]
 
+    # cells per chunk of moments(): bounds the stacked copy (host) and its upload (device) to
+    # 2 fields x n x CHUNK_BYTES-worth of cells, whatever the length of the run
+    CHUNK_BYTES = 256 << 20
+
     def moments(self, device=None):
-        """(avg_u, avg_v, uu, vv, uv) in dataset order of the fields."""
+        """(avg_u, avg_v, uu, vv, uv) in dataset order of the fields.
+
+        The per-pair fields themselves stay in host memory until the end of the run (the reference's
+        arithmetic is two-pass over the whole stack: 16 bytes per vector and pair, e.g. 4000 pairs of 127 x 127
+        = 1 GB, of 1023 x 1023 = 67 GB).  Everything on top of that is bounded: the stack is cut into chunks of
+        grid cells (CHUNK_BYTES per field component), each chunk is stacked, uploaded and reduced on its own
+        (tpiv_ensemble_moments walks a cell's stack in order, so cutting along the cells changes no bit), and
+        a chunk that does not fit the GPU is reduced by numpy instead."""
         order = np.argsort(np.asarray(self.ids), kind="stable")
-        U = np.stack([self.u[k] for k in order])
-        V = np.stack([self.v[k] for k in order])
-        if device is not None:
-            import torch
-            from . import engine
-            out = engine.ensemble_moments(torch.from_numpy(U).to(device), torch.from_numpy(V).to(device))
-            return tuple(o.cpu().numpy() for o in out)
-        avg_u = np.mean(U, axis=0, dtype=np.float64)
-        avg_v = np.mean(V, axis=0, dtype=np.float64)
-        du, dv = U - avg_u, V - avg_v
-        return (avg_u, avg_v, np.mean(du ** 2, axis=0, dtype=np.float64), np.mean(dv ** 2, axis=0, dtype=np.float64),
-                np.mean(du * dv, axis=0, dtype=np.float64))
+        n = len(order)
+        shape = self.u[order[0]].shape
+        cells = int(np.prod(shape))
+        step = max(1, min(cells, self.CHUNK_BYTES // (8 * n)))
+        out = np.empty((5, cells), dtype=np.float64)
+        flat_u = [self.u[k].reshape(-1) for k in order]
+        flat_v = [self.v[k].reshape(-1) for k in order]
+        for c0 in range(0, cells, step):
+            c1 = min(cells, c0 + step)
+            U = np.stack([f[c0:c1] for f in flat_u])
+            V = np.stack([f[c0:c1] for f in flat_v])
+            res = None
+            if device is not None:
+                import torch
+                from . import engine
+                try:
+                    res = [o.cpu().numpy() for o in engine.ensemble_moments(torch.from_numpy(U).to(device),
+                                                                            torch.from_numpy(V).to(device))]
+                except torch.OutOfMemoryError:
+                    torch.cuda.empty_cache()
+                    res = None
+            if res is None:
+                avg_u = np.mean(U, axis=0, dtype=np.float64)
+                avg_v = np.mean(V, axis=0, dtype=np.float64)
+                du, dv = U - avg_u, V - avg_v
+                res = [avg_u, avg_v, np.mean(du ** 2, axis=0, dtype=np.float64), np.mean(dv ** 2, axis=0, dtype=np.float64),
+                       np.mean(du * dv, axis=0, dtype=np.float64)]
+            for q in range(5):
+                out[q, c0:c1] = res[q]
+        return tuple(out[q].reshape(shape) for q in range(5))
 
     def table(self, x: np.ndarray, y: np.ndarray, device=None) -> dict:
         """The statistics table of workers.py:85-118: same keys, same order.  The gradients are
@@ -143,14 +173,15 @@ class EnsembleStats:
 def run_folder(folder: str, device: str, file_fmt: str, wind_size: int, overlap: int, multipass: int = 1,
                multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.0, multipass_scale: float = 2.0,
                folder_mode: str = "pairs", save_opt: str = "Dont save", save_dir: str = "Out",
-               batch_size: int = 32, on_pair=None, distributed: bool = False, stats_on_device: bool = True):
+               batch_size: int = 32, on_pair=None, distributed: bool = False, stats_on_device: bool = True,
+               precision: str = "f64"):
     """Process a folder like PIVWorker.run.  save_opt: "Dont save" | "Save all binary" |
     "Save all text" | "Save statistics" (anything but "Dont save" also writes the statistics table).
     Returns (table, n_pairs_done); with distributed=True every rank processes its shard of the
     pairs and rank 0 returns the table of the whole ensemble (other ranks: (None, n_local))."""
     piv = OfflinePIV(folder, device, file_fmt, wind_size, overlap, multipass=multipass,
                      multipass_mode=multipass_mode, dt=dt, scale=scale, multipass_scale=multipass_scale,
-                     folder_mode=folder_mode)
+                     folder_mode=folder_mode, precision=precision)
     if len(piv) == 0:
         return None, 0
     rank, world = 0, 1
