@@ -108,7 +108,7 @@ def strict_chain(a, b, ws, ov, n_pass, mode, precision, unit, got_u, got_v, name
 DEGENERATE = {("r2", 3), ("r4", 3)}
 
 
-@pytest.mark.parametrize("precision", ["fast", "reference"])
+@pytest.mark.parametrize("precision", ["fast", "f64", "reference"])
 @pytest.mark.parametrize("run", ["r1", "r2", "r3", "r4"])
 def test_offline_piv_generator(folder, golden, run, precision):
     """The generator against the reference's own OfflinePIV runs: same pairs dropped, same coordinates,
@@ -165,7 +165,7 @@ def test_generator_config0_geometry(tmp_path, golden):
     for i, (a, b) in enumerate(zip(g["r5_frames_a"], g["r5_frames_b"])):
         Image.fromarray(a, "L").save(tmp_path / f"image{8 + i}_a.bmp")
         Image.fromarray(b, "L").save(tmp_path / f"image{8 + i}_b.bmp")
-    for precision in ("fast", "reference"):
+    for precision in ("fast", "f64", "reference"):
         piv = T.OfflinePIV(str(tmp_path), "cuda:0", "bmp", 64, 32, multipass=1, multipass_mode="DWS", precision=precision)
         res = list(piv())
         assert len(piv) == int(g["r5_count"][0]) and len(res) == int(g["r5_count"][1]) > 0

@@ -28,23 +28,22 @@ def _oracle_fields(an, bn, geo, mode, name):
     return g
 
 
-@pytest.mark.parametrize("precision", ["reference", "fast"])
+@pytest.mark.parametrize("precision", ["reference", "f64", "fast"])
 @pytest.mark.parametrize("mode", ["CWS", "DWS"])
 def test_cfg2_against_oracle(pair, mode, precision):
-    """configs[1]/[2] geometry at full size (2048^2, 64/32 -> 32/16, 16 129 vectors) against the oracle by the
-    threshold-free rule of the golden tests (cascade_check): a vector of either pass may differ (beyond
-    1e-3 px, or in validity) only inside the float32 noise band of its own decisions or downstream of a
-    differing vector of the pass before."""
+    """configs[1]/[2] geometry at full size (2048^2, 64/32 -> 32/16, 16 129 vectors) against the oracle by the three
+    gates of the golden tests (cascade_check): reference chain with a capped 16-ulp band, per-pass isolation
+    against the oracle fed with the GPU's own fields, counted drift at the float32 / fast-order precisions."""
     from torchpiv_amd import engine
     from test_gpu_parity import cascade_check
     a, b = pair
     geo = [(64, 32), (32, 16)]
     g = _oracle_fields(a.cpu().numpy(), b.cpu().numpy(), geo, mode, "cfg2")
-    counts = cascade_check(engine, g, "cfg2", mode, precision, geo)
-    assert counts[-1][-1] == 127 * 127 and counts[-1][0] <= 0.005 * counts[-1][-1]      # (and they stay few)
+    counts = cascade_check(engine, g, "cfg2", mode, precision, geo, max_differing=[2, 8])     # observed: 0, 0
+    assert counts[-1][-1] == 127 * 127
 
 
-@pytest.mark.parametrize("precision", ["reference", "fast"])
+@pytest.mark.parametrize("precision", ["reference", "f64", "fast"])
 def test_cfg4_large_windows_against_oracle(pair, precision):
     """configs[4] geometry (2048^2, 128/64 -> 64/32, 2-pass CWS; pass 1 runs the two-threads-per-line 128x128
     kernel, or its float64 form at reference precision) against the oracle, same rule."""
@@ -53,8 +52,8 @@ def test_cfg4_large_windows_against_oracle(pair, precision):
     a, b = pair
     geo = [(128, 64), (64, 32)]
     g = _oracle_fields(a.cpu().numpy(), b.cpu().numpy(), geo, "CWS", "cfg4")
-    counts = cascade_check(engine, g, "cfg4", "CWS", precision, geo)
-    assert counts[0][-1] == 31 * 31 and counts[-1][-1] == 63 * 63 and counts[-1][0] <= 0.01 * counts[-1][-1]
+    counts = cascade_check(engine, g, "cfg4", "CWS", precision, geo, max_differing=[2, 4])        # observed: 0, 0
+    assert counts[0][-1] == 31 * 31 and counts[-1][-1] == 63 * 63
 
 
 @pytest.mark.parametrize("mode", ["CWS", "DWS"])
@@ -67,8 +66,10 @@ def test_cfg3_geometry_against_oracle(mode):
     a, b = synth.make_pair(1024, 1536, 654, kind="vortex", noise=2.0)
     geo = [(32, 16), (16, 8), (8, 4)]
     g = _oracle_fields(a.numpy(), b.numpy(), geo, mode, "cfg3")
-    for precision in ("reference", "fast"):
-        counts = cascade_check(engine, g, "cfg3", mode, precision, geo)
+    for precision in ("reference", "f64", "fast"):
+        # absolute caps on the vectors that differ from the oracle's chain at all (observed: 0, 0 and -- DWS, 8x8 pass --
+        # 5 of 97 665, every one inside the 16-ulp band)
+        counts = cascade_check(engine, g, "cfg3", mode, precision, geo, max_differing=[2, 4, 16])
         assert counts[-1][-1] == 255 * 383
 
 

@@ -331,8 +331,9 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
         fits; pass 0: near-tie windows) or (b) it is downstream of a differing cell of pass p-1 (spline weight
         |Ay| M |Ax|^T >= 1e-4).  STRICT (no unexplained cell) at precision="reference" and for pass 0.
     (B) isolation, p >= 1, both precisions -- the ORACLE's pass p fed with the GPU's OWN fields of pass p-1
-        against the plan's pass p under the 16-ulp band of the windows THAT chain staged, no fit clause: isolates
-        every shifted-pass kernel and the plan's predictor hand-off at the size of the test, whatever happened
+        against the plan's pass p under the 16-ulp band of the windows THAT chain staged (incl. ill-conditioned
+        fits: sparse 8x8 windows whose peak neighbours sit at the map minimum move by 0.1 px under any rounding):
+        isolates every shifted-pass kernel and the plan's predictor hand-off at the size of the test, whatever happened
         upstream.  STRICT.
     (C) drift, precision="fast" / "f64", p >= 1 -- the float32 pass 1 sits ~1e-6 px from the float64 reference (and
         the fast CWS sampling order <= 1e-4 grey levels from the reference's), which can tip a later decision that
@@ -364,7 +365,10 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
         flip = pi != rval
         M = (err > TOL_PX) | flip
         nr, nc = O.field_shape((H, W), w, o)
-        cap_p = 0.05 if w <= 8 else cap
+        # size caps of the excuse sets: 1 % of a pass (5 % for 8x8 passes, whose windows hold ~2 particles and often
+        # an ill-conditioned fit); the small golden fixtures (< 2000 windows, some with half-black windows next to
+        # their black blocks) get 10 % -- eight windows are 5 % of an 11 x 15 grid
+        cap_p = 0.10 if M.size < 2000 else (0.05 if w <= 8 else cap)
         if p == 0:
             const = pass1_constant(a, b, w, o)
             E = near_tie_windows(a, b, w, o) | const
@@ -397,7 +401,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
             gu, gv, gi = fields[p - 1]
             ou, ov_, oval, aa2, bb2 = oracle_pass_from(a, b, geo[p - 1], geo[p], mode, gu, gv, gi)
             const2 = constant_windows(aa2, bb2, nr, nc)
-            E2 = fp32_noise_excuse(aa2, bb2, nr, nc, ulps=16.0) | const2
+            E2 = fp32_noise_excuse(aa2, bb2, nr, nc, ulps=16.0, fit_tol=0.5e-3) | const2
             err2 = np.maximum(np.abs(pu - ou), np.abs(pv - ov_))
             M2 = (err2 > TOL_PX) | (pi != oval)
             free2 = E2 & ~const2
@@ -421,7 +425,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
     return counts
 
 
-@pytest.mark.parametrize("precision", ["reference", "fast"])
+@pytest.mark.parametrize("precision", ["reference", "f64", "fast"])
 @pytest.mark.parametrize("mode", ["DWS", "CWS"])
 def test_multipass_plan_end_to_end(eng, golden, mode, precision):
     """Whole-plan cascade on every multipass golden; see cascade_check for the three gates (reference chain,
@@ -545,8 +549,10 @@ def test_generic_sizes_multipass(eng, golden, mode):
                                 max_flip_frac=0.0, max_bad_frac=0.0, excused=fp32_noise_excuse(aa, bb, nr, nc),
                                 constant=constant_windows(aa, bb, nr, nc))
             print(f"generic {name} {mode} pass {p} (ws {w}/{o}): max err {e:.2e} px, mask flips {f}")
-        for precision in ("reference", "fast"):
-            cascade_check(eng, g, name, mode, precision, [(int(t[0]), int(t[1])) for t in geo], scale=scale)
+        for precision in ("reference", "f64", "fast"):
+            # (absolute cap on the cells that differ from the reference at all: observed 0 in every pass)
+            cascade_check(eng, g, name, mode, precision, [(int(t[0]), int(t[1])) for t in geo], scale=scale,
+                          max_differing=[2] * len(geo))
 
 
 @pytest.mark.parametrize("ws,planar", [(8, False), (8, True), (8, 2), (16, False), (16, True), (32, False), (32, True),
