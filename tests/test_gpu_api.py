@@ -36,7 +36,7 @@ def explained_region(a, b, ws, ov, n_pass, mode):
     tests/test_oracle_golden.py::test_generator)."""
     from scipy import ndimage
     from oracle import piv_oracle as O
-    from test_gpu_parity import constant_windows, fp32_noise_excuse, near_tie_windows, pass1_constant
+    from test_gpu_parity import constant_windows, fp32_noise_excuse, mask_ties, near_tie_windows, pass1_constant
     from torchpiv_amd import engine
     H, W = a.shape
     u, v, x, y, val = O.pass1(a, b, ws, ov, validate=True)
@@ -45,6 +45,7 @@ def explained_region(a, b, ws, ov, n_pass, mode):
     w, o = ws, ov
     for p in range(1, n_pass):
         xc, yc = x[0, :].copy(), y[:, 0].copy()
+        ties = mask_ties(a.shape, (w, o), (w // 2, o // 2), val)       # predictor mask ON the 0.5 threshold
         w, o = w // 2, o // 2
         it = O.ITER[mode](a.shape, w, o)
         u, v, x, y, val, _, _, _, _, u2, v2 = it(a, b, x, y, u.copy(), v.copy(), val.copy(), debug=True)
@@ -60,6 +61,7 @@ def explained_region(a, b, ws, ov, n_pass, mode):
             bb = O.shift_dws(b, idx, f(u2, np.int64), f(v2, np.int64))
         nr, nc = u.shape
         E = D | fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5e-3) | constant_windows(aa, bb, nr, nc)
+        E |= ties
         n_const += int(constant_windows(aa, bb, nr, nc).sum())
     patch, n = ndimage.label(val | E)
     hit = np.unique(patch[E])

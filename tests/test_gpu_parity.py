@@ -304,6 +304,18 @@ def spline_ops(eng, H, W, geo_prev, geo):
     return eng.spline_matrix(yc, yf), eng.spline_matrix(xc, xf)
 
 
+def mask_ties(shape, geo_prev, geo, inv_prev):
+    """Cells whose spline-interpolated validity mask (B:710-711 / B:777-778: RectBivariateSpline of the 0/1 mask,
+    thresholded at >= 0.5) lies within 1e-9 of the threshold.  Midway between an invalid and a valid coarse vector
+    FITPACK returns 0.5 -+ 1 ulp (observed: 0.49999999999999994 at six cells of one golden pair): which side it
+    falls on is decided by the last bit of the spline evaluation, i.e. a coin toss for any other implementation
+    of the same spline -- and it switches the cell's predictor between its value and zero."""
+    x0, y0 = O.coordinates(shape, geo_prev[0], geo_prev[1])
+    x1, y1 = O.coordinates(shape, geo[0], geo[1])
+    m = O.spline_predict(y0, x0, inv_prev.astype(np.float64), y1[:, 0], x1[0, :])
+    return np.abs(m - 0.5) < 1e-9
+
+
 def oracle_pass_from(a, b, geo_prev, geo, mode, u_prev, v_prev, inv_prev):
     """The oracle's pass (B:690-740 / B:757-812) fed with GIVEN fields of the pass before (numpy; e.g. the
     GPU's own): returns its u, v, validity and the windows it staged (for the noise band)."""
@@ -328,7 +340,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
     (A) reference chain -- GPU field of pass p against the REFERENCE's field of pass p.  A cell may differ
         (value beyond 1e-3 px or other validity) only if (a) its own discrete decisions lie in the reference's
         float32 noise band at 16 ulp (fp32_noise_excuse on the windows the reference staged, incl. ill-conditioned
-        fits; pass 0: near-tie windows) or (b) it is downstream of a differing cell of pass p-1 (spline weight
+        fits; pass 0: near-tie windows), or its interpolated predictor mask sits ON the 0.5 threshold (mask_ties), or (b) it is downstream of a differing cell of pass p-1 (spline weight
         |Ay| M |Ax|^T >= 1e-4).  STRICT (no unexplained cell) at precision="reference" and for pass 0.
     (B) isolation, p >= 1, both precisions -- the ORACLE's pass p fed with the GPU's OWN fields of pass p-1
         against the plan's pass p under the 16-ulp band of the windows THAT chain staged (incl. ill-conditioned
@@ -381,6 +393,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
             aa, bb = staged_windows(a, b, H, W, w, o, mode, u2, v2)
             const = constant_windows(aa, bb, nr, nc)
             E = fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5e-3) | const
+            E |= mask_ties((H, W), geo[p - 1], geo[p], g[f"{name}_{mode}_p{p-1}_val"])
             D = (np.abs(Ay_) @ prev_M.astype(np.float64) @ np.abs(Ax_).T) >= 1e-4
             Dd = (np.abs(Ay_) @ prev_drift.astype(np.float64) @ np.abs(Ax_).T) >= 1e-4
         free = E & ~const
@@ -402,6 +415,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
             ou, ov_, oval, aa2, bb2 = oracle_pass_from(a, b, geo[p - 1], geo[p], mode, gu, gv, gi)
             const2 = constant_windows(aa2, bb2, nr, nc)
             E2 = fp32_noise_excuse(aa2, bb2, nr, nc, ulps=16.0, fit_tol=0.5e-3) | const2
+            E2 |= mask_ties((H, W), geo[p - 1], geo[p], gi)
             err2 = np.maximum(np.abs(pu - ou), np.abs(pv - ov_))
             M2 = (err2 > TOL_PX) | (pi != oval)
             free2 = E2 & ~const2
