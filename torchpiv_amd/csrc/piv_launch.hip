@@ -156,7 +156,8 @@ static int pass_precision(int precision, int mode) {
 const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len) {
     precision = pass_precision(precision, mode);
     if (precision && mode == MODE_PASS1) {
-        if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_kernel<%d>", ws);
+        if (ws == 64) snprintf(buf, len, "xcorr_f64_split64_kernel");
+        else if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_kernel<%d>", ws);
         else snprintf(buf, len, "xcorr_generic_kernel<0, double>");
     } else if (ws == 8) {
         snprintf(buf, len, "xcorr_w8_kernel<%d, %s>", mode, (precision && mode != MODE_PASS1) ? "false" : "true");

@@ -25,21 +25,23 @@
 
 #include "piv_kernels.h"
 #include "xcorr_tile.hpp"      // grp_reduce: wavefront reductions in the VALU (DPP / permlane swaps)
+#include "xcorr_f64_split.hpp" // 64x64: lines split over two lanes, 32-point in-register codelets (second generation)
 
 namespace tpiv {
 
 namespace {
 
-struct alignas(16) cd {       // 16-byte alignment: ds_read_b128 / ds_write_b128 instead of ds_read2_b64 / ds_write2_b64
+// (the LDS-resident scheme below -- 8x8 ... 32x32 windows -- has its own 16-byte complex type)
+struct alignas(16) cz {       // 16-byte alignment: ds_read_b128 / ds_write_b128 instead of ds_read2_b64 / ds_write2_b64
     double x, y;
 };
-__device__ __forceinline__ cd cmul(cd a, cd w) { return cd{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
-__device__ __forceinline__ cd cmulc(cd a, cd w) { return cd{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }   // a * conj(w)
-__device__ __forceinline__ cd cadd_(cd a, cd b) { return cd{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cd csub_(cd a, cd b) { return cd{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cz cmul(cz a, cz w) { return cz{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
+__device__ __forceinline__ cz cmulc(cz a, cz w) { return cz{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }   // a * conj(w)
+__device__ __forceinline__ cz cadd_(cz a, cz b) { return cz{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cz csub_(cz a, cz b) { return cz{a.x - b.x, a.y - b.y}; }
 // a * (-i) for the forward transform, a * (+i) for the inverse
 template <bool FWD>
-__device__ __forceinline__ cd rot90(cd a) { return FWD ? cd{a.y, -a.x} : cd{-a.y, a.x}; }
+__device__ __forceinline__ cz rot90(cz a) { return FWD ? cz{a.y, -a.x} : cz{-a.y, a.x}; }
 
 // radix of the stage that works on blocks of length L: 8 while it fits, then what is left (4 or 2)
 constexpr int radix_of(int L) { return L >= 8 ? 8 : L; }
@@ -72,8 +74,8 @@ struct F64Geo {
 
 template <int WS>
 struct F64Shared {
-    cd z[WS * (WS + 1)];              // the packed tile a/mean(a) + i b/mean(b): 16-byte elements (ds_*_b128)
-    cd tw[WS];                        // exp(-2 pi i k / WS)
+    cz z[WS * (WS + 1)];              // the packed tile a/mean(a) + i b/mean(b): 16-byte elements (ds_*_b128)
+    cz tw[WS];                        // exp(-2 pi i k / WS)
     double redd[16];
     int redi[8];
     unsigned long long redu[8];
@@ -101,14 +103,14 @@ __device__ __forceinline__ T wg_reduce(T v, OP op, T* red) {
 
 // R-point DFT of x[0..R) in registers, natural order in and out; FWD: exp(-2 pi i pq/R), else the conjugate kernel
 template <int R, bool FWD>
-__device__ __forceinline__ void dft_small(cd (&x)[R]) {
+__device__ __forceinline__ void dft_small(cz (&x)[R]) {
     if constexpr (R == 2) {
-        const cd a = x[0], b = x[1];
+        const cz a = x[0], b = x[1];
         x[0] = cadd_(a, b);
         x[1] = csub_(a, b);
     } else if constexpr (R == 4) {
-        const cd t0 = cadd_(x[0], x[2]), t1 = csub_(x[0], x[2]), t2 = cadd_(x[1], x[3]);
-        const cd t3 = rot90<FWD>(csub_(x[1], x[3]));
+        const cz t0 = cadd_(x[0], x[2]), t1 = csub_(x[0], x[2]), t2 = cadd_(x[1], x[3]);
+        const cz t3 = rot90<FWD>(csub_(x[1], x[3]));
         x[0] = cadd_(t0, t2);
         x[1] = cadd_(t1, t3);
         x[2] = csub_(t0, t2);
@@ -117,16 +119,16 @@ __device__ __forceinline__ void dft_small(cd (&x)[R]) {
         static_assert(R == 8, "radix 2, 4 or 8");
         constexpr double H = 0.70710678118654752440;
         // first layer: a_p = x_p + x_{p+4} (even outputs), b_p = (x_p - x_{p+4}) w8^p (odd outputs)
-        cd a[4], b[4];
+        cz a[4], b[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             a[p] = cadd_(x[p], x[p + 4]);
             b[p] = csub_(x[p], x[p + 4]);
         }
         // w8^1 = (1 -+ i)/sqrt2, w8^2 = -+i, w8^3 = (-1 -+ i)/sqrt2   (upper sign: forward)
-        b[1] = FWD ? cd{(b[1].x + b[1].y) * H, (b[1].y - b[1].x) * H} : cd{(b[1].x - b[1].y) * H, (b[1].y + b[1].x) * H};
+        b[1] = FWD ? cz{(b[1].x + b[1].y) * H, (b[1].y - b[1].x) * H} : cz{(b[1].x - b[1].y) * H, (b[1].y + b[1].x) * H};
         b[2] = rot90<FWD>(b[2]);
-        b[3] = FWD ? cd{(b[3].y - b[3].x) * H, -(b[3].x + b[3].y) * H} : cd{-(b[3].x + b[3].y) * H, (b[3].x - b[3].y) * H};
+        b[3] = FWD ? cz{(b[3].y - b[3].x) * H, -(b[3].x + b[3].y) * H} : cz{-(b[3].x + b[3].y) * H, (b[3].x - b[3].y) * H};
         dft_small<4, FWD>(a);
         dft_small<4, FWD>(b);
 #pragma unroll
@@ -162,7 +164,7 @@ __device__ __forceinline__ void stage(F64Shared<WS>& sm) {
     for (int t = t0; t < BPL; t += TPP) {                          // (one iteration unless NT / LW < WS / R)
         const int blk = t / Q, j = t % Q;
         const int e0 = blk * L + j;
-        cd w[R];
+        cz w[R];
         if constexpr (Q > 1) {
 #pragma unroll
             for (int q = 1; q < R; ++q) w[q] = sm.tw[(q * j * TWS) % WS];
@@ -173,7 +175,7 @@ __device__ __forceinline__ void stage(F64Shared<WS>& sm) {
             const int line = line0 + it * LSTEP;
             if (LSTEP * NIT != WS && line >= WS) break;
             if (WS < LSTEP && line >= WS) break;
-            cd x[R];
+            cz x[R];
 #pragma unroll
             for (int q = 0; q < R; ++q) x[q] = ALONG_Y ? sm.z[(e0 + q * Q) * P + line] : sm.z[line * P + e0 + q * Q];
             if constexpr (FWD) {
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
     for (int k = tid; k < WS; k += NT) {
         double s, c;
         sincospi(2.0 * (double)k / (double)WS, &s, &c);
-        sm.tw[k] = cd{c, -s};
+        sm.tw[k] = cz{c, -s};
     }
     lds_barrier();
 
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const double a = (double)((da[q] >> (8 * k)) & 0xffu), b = (double)((db[q] >> (8 * k)) & 0xffu);
-                    sm.z[y * P + x4 + k] = cd{quot(a, ma, ra), quot(b, mb, rb)};
+                    sm.z[y * P + x4 + k] = cz{quot(a, ma, ra), quot(b, mb, rb)};
                 }
             }
         }
@@ -320,13 +322,13 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
                 const int e2 = qy * WS + qx;
                 if (e2 < e) continue;                      // the partner's thread writes both cells
                 const int a1 = py * P + px, a2 = qy * P + qx;
-                const cd zk = sm.z[a1], zm = sm.z[a2];
+                const cz zk = sm.z[a1], zm = sm.z[a2];
                 const double a_ = zk.x, b_ = zk.y, c_ = zm.x, d_ = zm.y;
                 // Z(k) = a + ib, Z(-k) = c + id:  4 P(k) = 2 (a d + b c) + i ((c^2 - a^2) + (d^2 - b^2))
                 const double pr = (a_ * d_ + b_ * c_) * (2.0 * SC);
                 const double pi = ((c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_)) * SC;
-                sm.z[a1] = cd{pr, pi};
-                if (e2 != e) sm.z[a2] = cd{pr, -pi};       // P(-k) = conj P(k)
+                sm.z[a1] = cz{pr, pi};
+                if (e2 != e) sm.z[a2] = cz{pr, -pi};       // P(-k) = conj P(k)
             }
             lds_barrier();
         }
@@ -416,6 +418,175 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
     }
 }
 
+
+// =====================================================================================================
+// 64x64 windows, second generation: every 64-point line split over two lanes, 32-point in-register codelets,
+// the radix-2 steps folded into planar LDS transposes (scheme and per-thread arithmetic: xcorr_f64_split.hpp,
+// which the CPU suite runs thread by thread against numpy).  One window per 128-thread workgroup, one 33 KB
+// float64 plane, four workgroups per CU (two wavefronts per SIMD, <= 256 VGPRs).  The first generation above
+// kept the 16-byte elements in LDS and walked radix-8 stages over them: 35 ms per 256 pairs at 43 % LDS bank
+// conflicts and ~25 barriers per window (profiles/r02); it still serves 8 ... 32 pixel windows.
+// =====================================================================================================
+struct F64SplitShared {
+    double plane[f64s::WS * f64s::PL];
+    double redd[8];
+    int redi[4];
+};
+
+__global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p) {
+    using namespace f64s;
+    __shared__ F64SplitShared sm;
+    double* const plane = sm.plane;
+    const int tid = threadIdx.x;
+
+    const int N = p.n_rows * p.n_cols;
+    const long long items = (long long)p.batch * N;
+    const int st = p.ws - p.ov;
+    const int HW = p.H * p.W;
+    // XCD-aware static order: workgroups b, b+8, ... share an XCD and walk one contiguous run of windows
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const long long chunk = (items + 7) / 8;
+    const long long lo = (long long)xcd * chunk;
+    const long long hi = lo + chunk < items ? lo + chunk : items;
+
+    // both threads of a line load the whole image row (64 bytes per frame); the next window's rows are fetched
+    // while the peak analysis of the current one runs
+    uint32_t da[NDW], db[NDW];
+    auto fetch = [&](long long it) TPIV_LAMBDA_INLINE {
+        const int pair_ = (int)(it / N), win_ = (int)(it % N);
+        const int yy0 = (win_ / p.n_cols) * st, xx0 = (win_ % p.n_cols) * st;
+        const size_t off = (size_t)pair_ * HW + (size_t)(yy0 + (tid & 63)) * p.W + xx0;
+        load_dwords<NDW>(p.A + off, da);
+        load_dwords<NDW>(p.B + off, db);
+    };
+    auto wg2 = [&](auto v, auto op, auto* red) TPIV_LAMBDA_INLINE {      // reduction over the two wavefronts
+        v = grp_reduce<64>(v, op);
+        lds_barrier();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        lds_barrier();
+        return op(red[0], red[1]);
+    };
+    if (lo + slot < hi) fetch(lo + slot);
+    for (long long item = lo + slot; item < hi; item += per_xcd) {
+        // (lane-derived values are re-made from an opaque copy of the thread index at every phase, so that the
+        //  32 + 32 + 66 loop-invariant LDS addresses are not hoisted out of the item loop into registers)
+#define TPIV_F64_TID() [&]() TPIV_LAMBDA_INLINE { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; }()
+        // ---- window sums: every wavefront holds all 64 rows -> no cross-wave exchange; exact integers
+        unsigned ia = 0, ib = 0;
+#pragma unroll
+        for (int q = 0; q < NDW; ++q) {
+            ia = __builtin_amdgcn_sad_u8(da[q], 0u, ia);
+            ib = __builtin_amdgcn_sad_u8(db[q], 0u, ib);
+        }
+        {
+            auto uadd = [](unsigned long long a, unsigned long long b) TPIV_LAMBDA_INLINE { return a + b; };
+            const unsigned long long s2 = grp_reduce<64>((unsigned long long)ia | ((unsigned long long)ib << 32), uadd);
+            ia = (unsigned)s2;
+            ib = (unsigned)(s2 >> 32);
+        }
+        const bool dead = ia == 0u || ib == 0u;          // zero-mean window: 0/0 = NaN map in the reference
+        // a / mean(a) (B:513-514) as (a[j] +- a[j+32]) * (n^2 / sum): one division per window; 0.5/64 on both inputs
+        // is the 1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra (exact power of two)
+        constexpr double PRE = 0.5 / (double)WS;
+        const double ra = dead ? 0.0 : ((double)(WS * WS) / (double)ia) * PRE;
+        const double rb = dead ? 0.0 : ((double)(WS * WS) / (double)ib) * PRE;
+
+        // ---- R: rows forward
+        cd x[M];
+        rows_forward(da, db, TPIV_F64_TID() >> 6, ra, rb, x);
+
+        // ---- T1 + C: transposition with the DIF step of the column transform, columns forward
+        cd u[M];
+        lds_barrier();                               // plane free (the previous window's record reads)
+        {
+            const int t_ = TPIV_F64_TID();
+            t1_write<0>(x, t_ & 63, t_ >> 6, plane);
+        }
+        lds_barrier();
+        {
+            const int t_ = TPIV_F64_TID();
+            t1_read<0>(u, t_ & 63, 1 - (t_ >> 6), plane);
+        }
+        lds_barrier();
+        {
+            const int t_ = TPIV_F64_TID();
+            t1_write<1>(x, t_ & 63, t_ >> 6, plane);
+        }
+        lds_barrier();
+        {
+            const int t_ = TPIV_F64_TID();
+            t1_read<1>(u, t_ & 63, 1 - (t_ >> 6), plane);
+        }
+        const int g = 1 - (TPIV_F64_TID() >> 6);     // parity of the column bins this thread owns (wave-uniform)
+        cols_forward(u, g);
+
+        // ---- X: cross-spectrum; the mirrored bin sits in lane (64 - k) % 64 of the same wavefront
+        {
+            const int partner = (64 - (TPIV_F64_TID() & 63)) & 63;
+            auto sh = [](double v, int, int, int pt) TPIV_LAMBDA_INLINE { return __shfl(v, pt, 64); };
+            if (g == 0) cross_spectrum_g<0>(u, partner, sh);
+            else cross_spectrum_g<1>(u, partner, sh);
+        }
+
+        // ---- Ci + T2: columns inverse, transposition with the DIT step
+        cd t[M];
+        cols_inverse(u, g, t);
+        cd Y[M + 1];
+        lds_barrier();                               // every thread has read its T1 column
+        {
+            const int t_ = TPIV_F64_TID();
+            t2_write<0>(t, t_ & 63, 1 - (t_ >> 6), plane);
+        }
+        lds_barrier();
+        t2_read<0>(Y, TPIV_F64_TID() & 63, plane);
+        lds_barrier();
+        {
+            const int t_ = TPIV_F64_TID();
+            t2_write<1>(t, t_ & 63, 1 - (t_ >> 6), plane);
+        }
+        lds_barrier();
+        t2_read<1>(Y, TPIV_F64_TID() & 63, plane);
+
+        // ---- Ri: rows inverse (c2r over the thread pair)
+        double c[M];
+        rows_inverse(Y, TPIV_F64_TID() >> 6, c);
+
+        // ---- P: peak analysis on the float64 map
+        auto dmin = [](double a, double b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
+        auto dmax = [](double a, double b) TPIV_LAMBDA_INLINE { return a > b ? a : b; };
+        auto imin = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
+        double cmin = peak_local_min(c);
+        // prefetch: the last iteration re-loads its own window (no branch around the loads)
+        fetch(item + per_xcd < hi ? item + per_xcd : item);
+        cmin = wg2(cmin, dmin, sm.redd);             // (its barriers also order the T2 reads before the map writes)
+        double bv;
+        int bf;
+        {
+            const int t_ = TPIV_F64_TID();
+            peak_shift_and_best(c, cmin, t_ & 63, t_ >> 6, plane, bv, bf);
+        }
+        const double gmax = wg2(bv, dmax, sm.redd + 2);
+        const int m = wg2(bv == gmax ? bf : WS * WS, imin, sm.redi);           // first flat index (B:383)
+        double sv;
+        {
+            const int t_ = TPIV_F64_TID();
+            sv = peak_second_local(c, t_ & 63, t_ >> 6, m, p.val_win);
+        }
+        sv = wg2(sv, dmax, sm.redd + 4);             // (the reductions also order the map writes before the reads below)
+        if (tid < 8) reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + tid] = peak_record_slot(tid, m, sv, dead, plane);
+#undef TPIV_F64_TID
+    }
+}
+
+static hipError_t launch_f64_split64(const PassParams& p, int n_cu, hipStream_t stream) {
+    const long long items = (long long)p.batch * p.n_rows * p.n_cols;
+    if (items <= 0) return hipErrorInvalidValue;
+    long long blocks = items < (long long)n_cu * 4 ? items : (long long)n_cu * 4;       // LDS: 33.4 KB per workgroup
+    blocks = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL(xcorr_f64_split64_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <int WS>
 hipError_t launch_f64(const PassParams& p, int n_cu, hipStream_t stream) {
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
@@ -434,7 +605,14 @@ hipError_t launch_xcorr_f64(const PassParams& p, int n_cu, hipStream_t stream) {
         case 8: return launch_f64<8>(p, n_cu, stream);
         case 16: return launch_f64<16>(p, n_cu, stream);
         case 32: return launch_f64<32>(p, n_cu, stream);
-        case 64: return launch_f64<64>(p, n_cu, stream);
+        case 64: {
+            // TPIV_F64_GEN1=1: the first-generation LDS-resident kernel (A/B runs)
+            static const bool gen1 = [] {
+                const char* e = getenv("TPIV_F64_GEN1");
+                return e && e[0] == '1';
+            }();
+            return gen1 ? launch_f64<64>(p, n_cu, stream) : launch_f64_split64(p, n_cu, stream);
+        }
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,0 +1,368 @@
+// Per-thread arithmetic of the float64 first pass for 64x64 windows (xcorr_f64.hip), written as host/device
+// functions so that the CPU suite can run the WHOLE scheme -- index maps, splits, partner bins, combines --
+// thread by thread against numpy (tests/host/f64_split_harness.cpp, tests/test_host_logic.py).
+//
+// A 64-point complex float64 line does not fit one lane (256 VGPRs), so every line is split over TWO threads
+// and every 64-point transform is a 32-point in-register codelet (fft_inreg_f64.hpp) plus one radix-2 step
+// that is folded into the LDS transposition in front of (decimation in frequency) or behind (decimation in
+// time) the codelet -- adds and subtractions of two plane cells while reading, plane by plane:
+//
+//   workgroup = 128 threads = one window; thread t: lane = t & 63, wave wv = t >> 6
+//   R   rows forward     thread (y = lane, h = wv) loads the whole image row y of both frames, forms the DIF halves
+//                        u[j] = x[j] + x[j+32]  (h = 0)   /   (x[j] - x[j+32]) w64^j  (h = 1),  j = 0..31
+//                        (integer sums / differences of the bytes, exact), scales by 1/mean (B:513-514) and
+//                        transforms: X[y][2m + h] at x[fft_pos(m, 32)]
+//   T1  transposition    plane[y][kx] <- X, one float64 component at a time (64 x 65 doubles = 33 KB: four
+//                        workgroups per CU); thread (k = lane, g = 1 - wv) reads column k as the DIF halves over
+//                        the rows: u[i] = X[i][k] +- X[i+32][k], the odd half times w64^i
+//   C   columns forward  32-point codelet: Z[2m + g][k] at u[fft_pos(m, 32)]
+//   X   cross-spectrum   P = conj(A) B of the packed transform Z = FFT2(a + i b); the mirrored bin Z(-ky, -k) has the
+//                        parity of ky, i.e. it lives in the same wavefront, lane (64 - k) % 64: ds_bpermute, no LDS memory
+//   Ci  columns inverse  the thread's own-parity bins through a 32-point inverse codelet: G_g[y1]; decimation in time:
+//                        Y[y1 + 32 c][k] = G_0[y1] +- w64^-y1 G_1[y1]; the g = 1 threads multiply by w64^-y1
+//   T2  transposition    plane[32 g + y1][k] <- G; thread (y = lane, q = wv) reads spectrum columns 0..32 of its row
+//                        (the row is real: Hermitian spectrum) as G_0 +- G_1
+//   Ri  rows inverse     real 64-point row from a 32-point complex transform (c2r), itself split over the thread pair:
+//                        DIF halves of the 32 packed values, 16-point codelet: thread q holds corr[y][4n + 2q + {0, 1}]
+//   P   peak analysis    on the float64 map (B:346-358, B:381-392, B:518), 8-double record for finalize_kernel<true>
+//
+// The odd halves carry 30 twiddle products per stage; the parities are assigned so that wave 0 takes them in the
+// column stages and wave 1 in the row stages.
+#pragma once
+#include <stdint.h>
+
+#include "fft_inreg_f64.hpp"
+
+namespace tpiv {
+namespace f64s {
+
+constexpr int WS = 64;          // window edge
+constexpr int M = 32;           // codelet length
+constexpr int PL = 65;          // plane pitch in doubles: conflict-free ds_read_b64 / ds_write_b64 along rows and columns
+constexpr int NDW = WS / 4;     // dwords per window row
+
+template <int K>
+TPIV_HD float byte_of(const uint32_t (&d)[NDW]) {
+    return (float)((d[K >> 2] >> (8 * (K & 3))) & 0xffu);
+}
+
+// ---- LDS reads of the transposes.  Device: explicit ds_read_b64 (the backend would merge neighbouring reads into
+// ds_read2_b64 pairs, which run at HALF the LDS rate: 8 cycles for 2 x 8 bytes per lane against 2 + 2), issued in
+// batches of eight with the next batch in flight while the current one is consumed (lgkmcnt counts at most 15).
+// Host: plain loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int OFF>
+__device__ __forceinline__ double lds_rd(unsigned addr) {
+    double v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// wait until at most LEFT LDS operations are outstanding; the eight values become usable only behind it
+template <int LEFT>
+__device__ __forceinline__ void lds_wait(double (&v)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 : "n"(LEFT));
+}
+__device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned)(uintptr_t)p; }     // low dword of a flat LDS address
+#endif
+
+// ---- R: thread (y, h).  da / db: row y of frame a / b (64 bytes each); ra, rb: 1/mean(a), 1/mean(b) times the
+// power of two 0.5/64 (1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra, exact).
+TPIV_HD void rows_forward(const uint32_t (&da)[NDW], const uint32_t (&db)[NDW], int h, double ra, double rb, cd (&x)[M]) {
+    const float sg = h ? -1.0f : 1.0f;
+    static_for<0, M>([&](auto jc) TPIV_LAMBDA_INLINE {
+        constexpr int j = decltype(jc)::value;
+        // sums / differences of two bytes: exact in float32, converted once
+        const float sa = byte_of<j>(da) + sg * byte_of<j + M>(da);
+        const float sb = byte_of<j>(db) + sg * byte_of<j + M>(db);
+        x[j] = cd{(double)sa * ra, (double)sb * rb};
+    });
+    if (h) {
+        static_for<1, M>([&](auto jc) TPIV_LAMBDA_INLINE {
+            constexpr int j = decltype(jc)::value;
+            x[j] = twmul_d<j, WS, 1>(x[j]);
+        });
+    }
+    fft_inreg_d<M, 1>(x);          // X[y][2m + h] at x[FFT_POS<m, M>]
+}
+
+// ---- T1 write: component COMP (0 = real, 1 = imaginary) of X[y][2m + h]
+template <int COMP>
+TPIV_HD void t1_write(const cd (&x)[M], int y, int h, double* plane) {
+    double* row = plane + y * PL + h;
+    static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
+        constexpr int m = decltype(mc)::value;
+        row[2 * m] = COMP ? x[FFT_POS<m, M>].y : x[FFT_POS<m, M>].x;
+    });
+}
+// ---- T1 read: thread (k, g): u[i] = X[i][k] +- X[i + 32][k]
+template <int COMP>
+TPIV_HD void t1_read(cd (&u)[M], int k, int g, const double* plane) {
+    const double sg = g ? -1.0 : 1.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned base = lds_addr(plane + k);
+    constexpr int NB = M / 4;                                   // batches of 4 rows i = 8 reads
+    double v[2][8];
+    auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
+        constexpr int b_ = decltype(bc)::value;
+        static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int i = 4 * b_ + decltype(ic)::value;
+            v[b_ & 1][2 * decltype(ic)::value] = lds_rd<i * PL * 8>(base);
+            v[b_ & 1][2 * decltype(ic)::value + 1] = lds_rd<(i + M) * PL * 8>(base);
+        });
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
+        constexpr int b_ = decltype(bc)::value;
+        if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
+        lds_wait<(b_ + 1 < NB) ? 8 : 0>(v[b_ & 1]);
+        static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int q = decltype(ic)::value, i = 4 * b_ + q;
+            const double r = v[b_ & 1][2 * q] + sg * v[b_ & 1][2 * q + 1];
+            if constexpr (COMP) u[i].y = r;
+            else u[i].x = r;
+        });
+    });
+#else
+    const double* col = plane + k;
+    for (int i = 0; i < M; ++i) {
+        const double r = col[i * PL] + sg * col[(i + M) * PL];
+        if (COMP) u[i].y = r;
+        else u[i].x = r;
+    }
+#endif
+}
+// ---- C: the odd half's twiddles, then the codelet: Z[2m + g][k] at u[FFT_POS<m, M>]
+TPIV_HD void cols_forward(cd (&u)[M], int g) {
+    if (g) {
+        static_for<1, M>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int i = decltype(ic)::value;
+            u[i] = twmul_d<i, WS, 1>(u[i]);
+        });
+    }
+    fft_inreg_d<M, 1>(u);
+}
+
+// ---- X: cross-spectrum in place.  With Z(k) = a + ib, Z(-k) = c + id:  4 P(k) = 2 (a d + b c) + i ((c^2 - a^2) + (d^2 - b^2))
+// (the factor 0.25 / n^2 is in the inputs).  sh(value, reg, partner) returns the PARTNER thread's value of register `reg`
+// (device: ds_bpermute of `value`; the host harness looks the register up).
+// (device: an empty asm on a value keeps computations that depend on it where they are written -- left alone, the
+//  compiler hoists the squares a^2, b^2 of ALL bins out of both parity branches and spills 48 of them)
+TPIV_HD void pin(cd& z) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(z.x), "+v"(z.y));
+#else
+    (void)z;
+#endif
+}
+TPIV_HD cd cross_bin(cd zk, cd zm) {
+    const double a_ = zk.x, b_ = zk.y, c_ = zm.x, d_ = zm.y;
+    return cd{(a_ * d_ + b_ * c_) * 2.0, (c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_)};
+}
+template <int G, typename SH>
+TPIV_HD void cross_spectrum_g(cd (&z)[M], int partner, SH&& sh) {
+    // bin ky = 2m + G sits at z[FFT_POS<m>]; its mirror -ky = 2 m' + G with m' = (32 - m) % 32 (G = 0), 31 - m (G = 1)
+    constexpr int NPAIR = G ? M / 2 : M / 2 + 1;
+    static_for<0, NPAIR>([&](auto mc) TPIV_LAMBDA_INLINE {
+        constexpr int m = decltype(mc)::value;
+        constexpr int m2 = G ? M - 1 - m : (M - m) % M;
+        constexpr int p1 = FFT_POS<m, M>, p2 = FFT_POS<m2, M>;
+        cd z1 = z[p1];
+        pin(z1);
+        if constexpr (m == m2) {
+            const cd m1{sh(z1.x, p1, 0, partner), sh(z1.y, p1, 1, partner)};
+            z[p1] = cross_bin(z1, m1);
+        } else {
+            cd z2 = z[p2];
+            pin(z2);
+            const cd m1{sh(z2.x, p2, 0, partner), sh(z2.y, p2, 1, partner)};      // Z(-ky, -k)
+            const cd m2v{sh(z1.x, p1, 0, partner), sh(z1.y, p1, 1, partner)};     // Z(+ky, -k): the mirror of bin -ky
+            z[p1] = cross_bin(z1, m1);
+            z[p2] = cross_bin(z2, m2v);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        // keep the exchange of a bin pair together: hoisted ahead, the 8 permutes of every pair hold their results
+        // in registers next to the 128 of the spectrum
+        if constexpr (m % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+    });
+}
+
+// ---- Ci: natural-order rename, inverse codelet, decimation-in-time twiddle of the odd half: G_g[y1] at t[FFT_POS<y1, M>]
+TPIV_HD void cols_inverse(const cd (&z)[M], int g, cd (&t)[M]) {
+    static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
+        constexpr int m = decltype(mc)::value;
+        t[m] = z[FFT_POS<m, M>];
+    });
+    fft_inreg_d<M, -1>(t);
+    if (g) {
+        static_for<1, M>([&](auto yc) TPIV_LAMBDA_INLINE {
+            constexpr int y1 = decltype(yc)::value;
+            t[FFT_POS<y1, M>] = twmul_d<y1, WS, -1>(t[FFT_POS<y1, M>]);
+        });
+    }
+}
+// ---- T2 write: thread (k, g): plane[32 g + y1][k] <- G_g[y1][k]
+template <int COMP>
+TPIV_HD void t2_write(const cd (&t)[M], int k, int g, double* plane) {
+    double* col = plane + (M * g) * PL + k;
+    static_for<0, M>([&](auto yc) TPIV_LAMBDA_INLINE {
+        constexpr int y1 = decltype(yc)::value;
+        col[y1 * PL] = COMP ? t[FFT_POS<y1, M>].y : t[FFT_POS<y1, M>].x;
+    });
+}
+// ---- T2 read: thread (y, q): Y[kx] = G_0[y % 32][kx] +- G_1[y % 32][kx], kx = 0..32
+template <int COMP>
+TPIV_HD void t2_read(cd (&Y)[M + 1], int y, const double* plane) {
+    const double sg = y < M ? 1.0 : -1.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned base = lds_addr(plane + (y & (M - 1)) * PL);
+    constexpr int NB = M / 4 + 1;                               // 8 batches of 4 columns + column 32
+    double v[2][8];
+    auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
+        constexpr int b_ = decltype(bc)::value;
+        static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int kx = 4 * b_ + decltype(ic)::value;
+            if constexpr (kx <= M) {
+                v[b_ & 1][2 * decltype(ic)::value] = lds_rd<kx * 8>(base);
+                v[b_ & 1][2 * decltype(ic)::value + 1] = lds_rd<(M * PL + kx) * 8>(base);
+            }
+        });
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
+        constexpr int b_ = decltype(bc)::value;
+        if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
+        // outstanding behind this batch: the next one (8 reads, the last batch holds 2)
+        lds_wait<(b_ + 1 < NB) ? (b_ + 2 == NB ? 2 : 8) : 0>(v[b_ & 1]);
+        static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int q = decltype(ic)::value, kx = 4 * b_ + q;
+            if constexpr (kx <= M) {
+                const double r = v[b_ & 1][2 * q] + sg * v[b_ & 1][2 * q + 1];
+                if constexpr (COMP) Y[kx].y = r;
+                else Y[kx].x = r;
+            }
+        });
+    });
+#else
+    const double* r0 = plane + (y & (M - 1)) * PL;
+    const double* r1 = r0 + M * PL;
+    for (int kx = 0; kx <= M; ++kx) {
+        const double r = r0[kx] + sg * r1[kx];
+        if (COMP) Y[kx].y = r;
+        else Y[kx].x = r;
+    }
+#endif
+}
+// ---- Ri: c2r pre-processing (both threads of the pair), DIF halves of the 32 packed values, 16-point inverse codelet.
+// Out: c[2n + e] = corr[y][4n + 2q + e], n = 0..15, e = 0, 1 (un-shifted column index).
+TPIV_HD void rows_inverse(cd (&Y)[M + 1], int q, double (&c)[M]) {
+    c2r_pre_d<WS>(Y);                       // h[0..32) in Y[0..32)
+    cd e[M / 2];
+    const double sq = q ? -1.0 : 1.0;
+    static_for<0, M / 2>([&](auto jc) TPIV_LAMBDA_INLINE {
+        constexpr int j = decltype(jc)::value;
+        e[j] = cd{Y[j].x + sq * Y[j + M / 2].x, Y[j].y + sq * Y[j + M / 2].y};
+    });
+    if (q) {
+        static_for<1, M / 2>([&](auto jc) TPIV_LAMBDA_INLINE {
+            constexpr int j = decltype(jc)::value;
+            e[j] = twmul_d<j, M, -1>(e[j]);
+        });
+    }
+    fft_inreg_d<M / 2, -1>(e);              // z[2n + q] at e[FFT_POS<n, 16>]
+    static_for<0, M / 2>([&](auto nc) TPIV_LAMBDA_INLINE {
+        constexpr int n = decltype(nc)::value;
+        c[2 * n] = e[FFT_POS<n, M / 2>].x;
+        c[2 * n + 1] = e[FFT_POS<n, M / 2>].y;
+    });
+}
+
+// ---- P: peak analysis in fftshift coordinates (y' = (y + 32) % 64, x' likewise).  Thread (y, q) holds
+// c[2n + e] = corr[y][x = 4n + 2q + e].
+TPIV_HD int col_of(int n, int e, int q) { return 4 * n + 2 * q + e; }
+
+TPIV_HD double peak_local_min(const double (&c)[M]) {
+    double m = c[0];
+#pragma unroll
+    for (int i = 1; i < M; ++i) m = c[i] < m ? c[i] : m;
+    return m;
+}
+// v = (c - min) + 1e-7 (B:518, B:381), written to the map (plane, shifted coordinates); the thread's best
+// (value, smallest shifted flat index)
+TPIV_HD void peak_shift_and_best(double (&c)[M], double cmin, int y, int q, double* plane, double& bv, int& bf) {
+    const int fy = (y + WS / 2) & (WS - 1);
+    bv = -1.0;
+    bf = WS * WS;
+    static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
+        constexpr int i = decltype(ic)::value;
+        const int fx = (col_of(i >> 1, i & 1, q) + WS / 2) & (WS - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double v = __dadd_rn(__dsub_rn(c[i], cmin), 1e-7);
+#else
+        const double v = (c[i] - cmin) + 1e-7;
+#endif
+        c[i] = v;
+        plane[fy * PL + fx] = v;
+        const int f = fy * WS + fx;
+        if (v > bv || (v == bv && f < bf)) {
+            bv = v;
+            bf = f;
+        }
+    });
+}
+// second peak: the thread's maximum outside the flat-index exclusion zone of m (B:346-358): f in {clamp(m + i + 64 j),
+// |i|, |j| <= wv}: in row fy the columns mx + i (j = fy - my), mx + i + 64 (the row wrap, j = fy - my - 1) and
+// mx + i - 64 (j = fy - my + 1), plus the two clamps.  -1 if every cell of the thread is excluded.
+TPIV_HD double peak_second_local(const double (&c)[M], int y, int q, int m, int wv) {
+    const int fy = (y + WS / 2) & (WS - 1);
+    const int my = m / WS, mx = m % WS;
+    const int dj = fy - my;
+    unsigned long long ex = 0ull;                  // bit fx set = excluded
+    auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
+        lo_ = lo_ < 0 ? 0 : lo_;
+        hi_ = hi_ > WS - 1 ? WS - 1 : hi_;
+        if (lo_ > hi_) return 0ull;
+        const int len = hi_ - lo_ + 1;
+        const unsigned long long ones = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+        return ones << lo_;
+    };
+    if (dj >= -wv && dj <= wv) ex |= span(mx - wv, mx + wv);
+    if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(mx - wv + WS, mx + wv + WS);
+    if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx - wv - WS, mx + wv - WS);
+    if (fy == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;
+    if (fy == WS - 1 && (m + wv + wv * WS) >= WS * WS - 1) ex |= 1ull << (WS - 1);
+    double sv = -1.0;
+    static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
+        constexpr int i = decltype(ic)::value;
+        const int fx = (col_of(i >> 1, i & 1, q) + WS / 2) & (WS - 1);
+        const bool excl = (ex >> fx) & 1ull;
+        if (!excl && c[i] > sv) sv = c[i];
+    });
+    return sv;
+}
+// record for finalize_kernel<true>: slot 0..7 = c[m], c[left], c[right], c[top], c[bot], c[m2], m, dead
+// (flat-index neighbours and fix-ups of B:385-392; `sv` < 0: nothing left outside the exclusion zone -- the
+// reference's second arg-max then runs over the zeroed map: c[m2] = 0, ratio = +inf)
+TPIV_HD double peak_record_slot(int slot, int m, double sv, bool dead, const double* plane) {
+    const int KD = WS * WS;
+    int left = m + 1, right = m - 1, top = m + WS, bot = m - WS;
+    if (left >= KD - 1) left = m;
+    if (right <= 0) right = m;
+    if (top >= KD - 1) top = m;
+    if (bot <= 0) bot = m;
+    int qi = m;
+    qi = slot == 1 ? left : qi;
+    qi = slot == 2 ? right : qi;
+    qi = slot == 3 ? top : qi;
+    qi = slot == 4 ? bot : qi;
+    double outv = plane[(qi / WS) * PL + (qi % WS)];
+    outv = slot == 5 ? (sv >= 0.0 ? sv : 0.0) : outv;
+    outv = slot == 6 ? (double)m : outv;
+    outv = slot == 7 ? (dead ? 1.0 : 0.0) : outv;
+    return outv;
+}
+
+}  // namespace f64s
+}  // namespace tpiv
