@@ -79,15 +79,20 @@ int main() {
             cmin = m < cmin ? m : cmin;
         }
         double gmax = -1.0;
-        std::vector<double> bv(128);
-        std::vector<int> bf(128);
+        std::vector<double> rmax(128);
         for (int t = 0; t < 128; ++t) {
-            peak_shift_and_best(T[t].c, cmin, t & 63, t >> 6, plane.data(), bv[t], bf[t]);
-            gmax = bv[t] > gmax ? bv[t] : gmax;
+            rmax[t] = peak_shift_and_rowmax(T[t].c, cmin, t & 63, t >> 6, plane.data());
+            gmax = rmax[t] > gmax ? rmax[t] : gmax;
         }
-        int m = WS * WS;
-        for (int t = 0; t < 128; ++t)
-            if (bv[t] == gmax && bf[t] < m) m = bf[t];
+        int ywin = WS - 1;
+        for (int t = 0; t < 128; ++t) {
+            const int fy = ((t & 63) + WS / 2) & (WS - 1);
+            if (rmax[t] == gmax && fy < ywin) ywin = fy;
+        }
+        int xwin = WS - 1;
+        for (int x = WS - 1; x >= 0; --x)
+            if (plane[ywin * PL + x] == gmax) xwin = x;
+        const int m = ywin * WS + xwin;
         double sv = -1.0;
         for (int t = 0; t < 128; ++t) {
             const double s = peak_second_local(T[t].c, t & 63, t >> 6, m, 3);

@@ -41,6 +41,8 @@ def explained_region(a, b, ws, ov, n_pass, mode):
     H, W = a.shape
     u, v, x, y, val = O.pass1(a, b, ws, ov, validate=True)
     E = near_tie_windows(a, b, ws, ov) | pass1_constant(a, b, ws, ov)
+    # rounding noise in place of an exactly-zero fit (identical windows): its sign is a coin toss for the next pass
+    E |= (np.maximum(np.abs(u), np.abs(v)) < 1e-9) & ((u != 0) | (v != 0))
     n_const = int(pass1_constant(a, b, ws, ov).sum())
     w, o = ws, ov
     for p in range(1, n_pass):
@@ -103,11 +105,11 @@ def strict_chain(a, b, ws, ov, n_pass, mode, precision, unit, got_u, got_v, name
     cascade_check(engine, g, name, mode, precision, geo, check_drift=check_drift)
 
 
-# Pair 3 of the fixture is frame_b == frame_a without noise: its predictor is ~ +-1e-8 px and the
-# reference's CWS "integral coordinate => nearest sample" quirk (PIVbackend.py:170,193) makes the
-# result depend on the SIGN of that rounding noise -- not reproducible by float32 arithmetic in pass 1
-# (precision="reference" reproduces the sign and is NOT exempted).
-DEGENERATE = {("r2", 3), ("r4", 3)}
+# Pair 3 of the fixture is frame_b == frame_a without noise: the exact first-pass fit is 0 and the reference returns 0.0
+# (in two cells its transform's rounding noise, 1.8e-15).  The sign / zero-ness of that value decides how the reference
+# shifts the next pass's windows (PIVbackend.py:170, 193 and the flat-index wrap): a +-1e-17 perturbation of pass 1 moves
+# 16 % of the final vectors by up to 3 px.  finalize_kernel returns the exact 0 for identical windows at every precision;
+# the cells where the reference holds its own noise instead are coin-toss cells for the comparison (explained_region).
 
 
 @pytest.mark.parametrize("precision", ["fast", "f64", "reference"])
@@ -132,11 +134,6 @@ def test_offline_piv_generator(folder, golden, run, precision):
         assert np.array_equal(x, g[f"{run}_{j}_x"]) and np.array_equal(y, g[f"{run}_{j}_y"])
         assert u.shape == g[f"{run}_{j}_u"].shape
         unit = 1000 * scale / dt
-        if precision == "fast" and (run, yielded[j]) in DEGENERATE:
-            # (the region-free chain still applies: isolation feeds the oracle the GPU's own predictor signs)
-            strict_chain(g["frames_a"][yielded[j]], g["frames_b"][yielded[j]], ws, ov, mp_, ("DWS", "CWS")[mode],
-                         precision, unit, u, v, f"{run}p{yielded[j]}", check_drift=False)
-            continue
         bad = ~np.isclose(u / unit, g[f"{run}_{j}_u"] / unit, rtol=0, atol=1e-3, equal_nan=True)
         bad |= ~np.isclose(v / unit, g[f"{run}_{j}_v"] / unit, rtol=0, atol=1e-3, equal_nan=True)
         i = yielded[j]

@@ -376,6 +376,13 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
         err = np.maximum(np.abs(pu - ru), np.abs(pv - rv))
         flip = pi != rval
         M = (err > TOL_PX) | flip
+        if p == 0:
+            # identical windows (frame b == frame a): the exact fit is 0 and the reference returns 0.0 or -- in a few cells --
+            # its transform's rounding noise (1e-15); the sign / zero-ness of such a value decides how the reference shifts
+            # the windows of the next pass (B:170, B:193 and the flat-index wrap), so a cell that is not bit-equal there
+            # counts as differing for the downstream rule
+            tiny = (np.maximum(np.abs(ru), np.abs(rv)) < 1e-9) & ((pu != ru) | (pv != rv))
+            M = M | tiny
         nr, nc = O.field_shape((H, W), w, o)
         # size caps of the excuse sets: 1 % of a pass (5 % for 8x8 passes, whose windows hold ~2 particles and often
         # an ill-conditioned fit); the small golden fixtures (< 2000 windows, some with half-black windows next to
@@ -383,7 +390,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
         cap_p = 0.10 if M.size < 2000 else (0.05 if w <= 8 else cap)
         if p == 0:
             const = pass1_constant(a, b, w, o)
-            E = near_tie_windows(a, b, w, o) | const
+            E = near_tie_windows(a, b, w, o) | const | tiny
             D = Dd = np.zeros_like(M)
         else:
             Ay_, Ax_ = spline_ops(eng, H, W, geo[p - 1], geo[p])
@@ -393,7 +400,10 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
             aa, bb = staged_windows(a, b, H, W, w, o, mode, u2, v2)
             const = constant_windows(aa, bb, nr, nc)
             E = fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5e-3) | const
-            E |= mask_ties((H, W), geo[p - 1], geo[p], g[f"{name}_{mode}_p{p-1}_val"])
+            ties = mask_ties((H, W), geo[p - 1], geo[p], g[f"{name}_{mode}_p{p-1}_val"])
+            E |= ties
+            # the band of the drift gate (C): the same, with the fit clause at half the drift threshold
+            Ed = fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5 * DRIFT_PX) | const | ties
             D = (np.abs(Ay_) @ prev_M.astype(np.float64) @ np.abs(Ax_).T) >= 1e-4
             Dd = (np.abs(Ay_) @ prev_drift.astype(np.float64) @ np.abs(Ax_).T) >= 1e-4
         free = E & ~const
@@ -430,7 +440,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
             assert q99 <= ISO_Q99_PX, (tag, p, "isolation: systematic deviation", float(q50), float(q99))
             if precision != "reference" and check_drift:
                 # (C) drift against the reference chain
-                loose = drift & ~E & ~Dd
+                loose = drift & ~Ed & ~Dd
                 lim = max(drift_min, int(drift_frac * M.size))
                 print(f"  {tag} pass {p} (ws {w}): (C) drift beyond {DRIFT_PX} px / other validity: {int(drift.sum())}, "
                       f"of which outside the band and not downstream: {int(loose.sum())} (cap {lim})")

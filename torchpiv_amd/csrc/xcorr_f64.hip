@@ -552,21 +552,26 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         rows_inverse(Y, TPIV_F64_TID() >> 6, c);
 
         // ---- P: peak analysis on the float64 map
-        auto dmin = [](double a, double b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
-        auto dmax = [](double a, double b) TPIV_LAMBDA_INLINE { return a > b ? a : b; };
+        auto dmin = [](double a, double b) TPIV_LAMBDA_INLINE { return fmin(a, b); };
+        auto dmax = [](double a, double b) TPIV_LAMBDA_INLINE { return fmax(a, b); };
         auto imin = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
         double cmin = peak_local_min(c);
         // prefetch: the last iteration re-loads its own window (no branch around the loads)
         fetch(item + per_xcd < hi ? item + per_xcd : item);
         cmin = wg2(cmin, dmin, sm.redd);             // (its barriers also order the T2 reads before the map writes)
-        double bv;
-        int bf;
+        double rmax;
         {
             const int t_ = TPIV_F64_TID();
-            peak_shift_and_best(c, cmin, t_ & 63, t_ >> 6, plane, bv, bf);
+            rmax = peak_shift_and_rowmax(c, cmin, t_ & 63, t_ >> 6, plane);
         }
-        const double gmax = wg2(bv, dmax, sm.redd + 2);
-        const int m = wg2(bv == gmax ? bf : WS * WS, imin, sm.redi);           // first flat index (B:383)
+        const double gmax = wg2(rmax, dmax, sm.redd + 2);
+        // arg-max = FIRST flat index holding the maximum (B:383): the smallest shifted row whose maximum is the global
+        // one, then the first column of that row -- lane = column, one LDS read and a ballot (both wavefronts do it: same
+        // row, same result, no exchange)
+        const int ywin = wg2(rmax == gmax ? (((TPIV_F64_TID() & 63) + WS / 2) & (WS - 1)) : WS - 1, imin, sm.redi);    // (map complete)
+        const unsigned long long hit = __ballot(plane[ywin * PL + (TPIV_F64_TID() & 63)] == gmax);
+        const int xwin = hit ? (int)__builtin_ctzll(hit) : WS - 1;
+        const int m = ywin * WS + xwin;
         double sv;
         {
             const int t_ = TPIV_F64_TID();

@@ -29,6 +29,7 @@
 // The odd halves carry 30 twiddle products per stage; the parities are assigned so that wave 0 takes them in the
 // column stages and wave 1 in the row stages.
 #pragma once
+#include <math.h>
 #include <stdint.h>
 
 #include "fft_inreg_f64.hpp"
@@ -286,35 +287,35 @@ TPIV_HD int col_of(int n, int e, int q) { return 4 * n + 2 * q + e; }
 TPIV_HD double peak_local_min(const double (&c)[M]) {
     double m = c[0];
 #pragma unroll
-    for (int i = 1; i < M; ++i) m = c[i] < m ? c[i] : m;
+    for (int i = 1; i < M; ++i) m = fmin(m, c[i]);
     return m;
 }
-// v = (c - min) + 1e-7 (B:518, B:381), written to the map (plane, shifted coordinates); the thread's best
-// (value, smallest shifted flat index)
-TPIV_HD void peak_shift_and_best(double (&c)[M], double cmin, int y, int q, double* plane, double& bv, int& bf) {
+// v = (c - min) + 1e-7 (B:518, B:381), written to the map (plane, shifted coordinates); returns the row maximum of the
+// thread's cells.  (No index is tracked here: the arg-max position comes from the map afterwards -- first the smallest
+// row whose maximum is the global one, then the first column of that row, peak_first_column -- which keeps the scan
+// free of compare / select chains.)
+TPIV_HD double peak_shift_and_rowmax(double (&c)[M], double cmin, int y, int q, double* plane) {
     const int fy = (y + WS / 2) & (WS - 1);
-    bv = -1.0;
-    bf = WS * WS;
+    double* row = plane + fy * PL + 2 * q;
+    double rmax = 0.0;
     static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
         constexpr int i = decltype(ic)::value;
-        const int fx = (col_of(i >> 1, i & 1, q) + WS / 2) & (WS - 1);
+        constexpr int fx0 = (4 * (i >> 1) + (i & 1) + WS / 2) & (WS - 1);       // + 2 q: stays inside its group of four
 #if defined(__HIP_DEVICE_COMPILE__)
         const double v = __dadd_rn(__dsub_rn(c[i], cmin), 1e-7);
 #else
         const double v = (c[i] - cmin) + 1e-7;
 #endif
         c[i] = v;
-        plane[fy * PL + fx] = v;
-        const int f = fy * WS + fx;
-        if (v > bv || (v == bv && f < bf)) {
-            bv = v;
-            bf = f;
-        }
+        row[fx0] = v;
+        rmax = fmax(rmax, v);
     });
+    return rmax;
 }
 // second peak: the thread's maximum outside the flat-index exclusion zone of m (B:346-358): f in {clamp(m + i + 64 j),
 // |i|, |j| <= wv}: in row fy the columns mx + i (j = fy - my), mx + i + 64 (the row wrap, j = fy - my - 1) and
-// mx + i - 64 (j = fy - my + 1), plus the two clamps.  -1 if every cell of the thread is excluded.
+// mx + i - 64 (j = fy - my + 1), plus the two clamps.  Negative if every cell of the thread is excluded (an excluded
+// cell takes part with its sign bit set: every map value is >= 1e-7).
 TPIV_HD double peak_second_local(const double (&c)[M], int y, int q, int m, int wv) {
     const int fy = (y + WS / 2) & (WS - 1);
     const int my = m / WS, mx = m % WS;
@@ -333,12 +334,21 @@ TPIV_HD double peak_second_local(const double (&c)[M], int y, int q, int m, int 
     if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx - wv - WS, mx + wv - WS);
     if (fy == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;
     if (fy == WS - 1 && (m + wv + wv * WS) >= WS * WS - 1) ex |= 1ull << (WS - 1);
+    ex >>= 2 * q;                                  // this thread's columns: bit positions become compile-time constants
+    const unsigned exl = (unsigned)ex, exh = (unsigned)(ex >> 32);
     double sv = -1.0;
     static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
         constexpr int i = decltype(ic)::value;
-        const int fx = (col_of(i >> 1, i & 1, q) + WS / 2) & (WS - 1);
-        const bool excl = (ex >> fx) & 1ull;
-        if (!excl && c[i] > sv) sv = c[i];
+        constexpr int fx0 = (4 * (i >> 1) + (i & 1) + WS / 2) & (WS - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // sign-extended exclusion bit (0 / -1) -> sign bit of the value: excluded cells lose every comparison
+        const int kill = __builtin_amdgcn_sbfe((int)(fx0 < 32 ? exl : exh), fx0 & 31, 1);
+        const double v = __hiloint2double(__double2hiint(c[i]) | (kill & (int)0x80000000), __double2loint(c[i]));
+#else
+        const bool excl = ((fx0 < 32 ? exl : exh) >> (fx0 & 31)) & 1u;
+        const double v = excl ? -c[i] : c[i];
+#endif
+        sv = fmax(sv, v);
     });
     return sv;
 }
