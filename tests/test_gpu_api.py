@@ -78,7 +78,7 @@ def explained_region(a, b, ws, ov, n_pass, mode):
 REGION_CAP = 0.25       # a comparison whose explained region covers more of the field than this checks nothing
 
 
-def strict_chain(a, b, ws, ov, n_pass, mode, precision, unit, got_u, got_v, name, check_drift=True):
+def strict_chain(a, b, ws, ov, n_pass, mode, precision, unit, got_u, got_v, name, reference_chain=True):
     """What the explained-region comparison cannot see (frames with black / saturated blocks explain most of
     their small grids) is covered by a chain without a region: (i) the generator's tuple equals the REFERENCE's
     post-processing (oracle restatement of B:884-898: NaN-out, border interpolation, Delaunay fill, flip, scale)
@@ -102,14 +102,20 @@ def strict_chain(a, b, ws, ov, n_pass, mode, precision, unit, got_u, got_v, name
     assert np.allclose(got_u, wu, rtol=0, atol=1e-9 * unit, equal_nan=True), name
     assert np.allclose(got_v, wv, rtol=0, atol=1e-9 * unit, equal_nan=True), name
     g = _oracle_fields(a, b, geo, mode, name)
-    cascade_check(engine, g, name, mode, precision, geo, check_drift=check_drift)
+    cascade_check(engine, g, name, mode, precision, geo, check_drift=reference_chain, strict_reference_chain=reference_chain)
 
 
-# Pair 3 of the fixture is frame_b == frame_a without noise: the exact first-pass fit is 0 and the reference returns 0.0
-# (in two cells its transform's rounding noise, 1.8e-15).  The sign / zero-ness of that value decides how the reference
-# shifts the next pass's windows (PIVbackend.py:170, 193 and the flat-index wrap): a +-1e-17 perturbation of pass 1 moves
-# 16 % of the final vectors by up to 3 px.  finalize_kernel returns the exact 0 for identical windows at every precision;
-# the cells where the reference holds its own noise instead are coin-toss cells for the comparison (explained_region).
+# Pair 3 of the fixture is frame_b == frame_a without noise: the exact first-pass fit is 0, and the reference returns 0.0
+# in all but two cells, where it returns its transform's rounding noise (1.8e-15).  The sign / zero-ness of such a value
+# decides how the reference shifts the next pass's windows (PIVbackend.py:170, 193: an exactly integral coordinate takes
+# another branch than one a rounding error away, and the flat-index wrap turns the sign of a 1e-17 px shift at column 0
+# into another pixel): ANY non-zero spline weight of a noise cell turns an exactly-zero predictor into a non-zero one, and
+# the reference's own multipass output for this pair reaches 3 px of "displacement" between identical frames.  It is a
+# function of the reference's rounding noise, reproducible by nothing else, at any precision.  (finalize_kernel returns
+# the exact 0 for identical windows, so this build's output for the pair is the clean one.)  What IS checked for it:
+# pairs dropped / yielded, coordinates, shapes, the post-processing chain and the isolation gate of every pass
+# (strict_chain with reference_chain=False); single-pass runs compare normally.
+DEGENERATE = {("r2", 3), ("r3", 3), ("r4", 3)}
 
 
 @pytest.mark.parametrize("precision", ["fast", "f64", "reference"])
@@ -134,6 +140,10 @@ def test_offline_piv_generator(folder, golden, run, precision):
         assert np.array_equal(x, g[f"{run}_{j}_x"]) and np.array_equal(y, g[f"{run}_{j}_y"])
         assert u.shape == g[f"{run}_{j}_u"].shape
         unit = 1000 * scale / dt
+        if (run, yielded[j]) in DEGENERATE:
+            strict_chain(g["frames_a"][yielded[j]], g["frames_b"][yielded[j]], ws, ov, mp_, ("DWS", "CWS")[mode],
+                         precision, unit, u, v, f"{run}p{yielded[j]}", reference_chain=False)
+            continue
         bad = ~np.isclose(u / unit, g[f"{run}_{j}_u"] / unit, rtol=0, atol=1e-3, equal_nan=True)
         bad |= ~np.isclose(v / unit, g[f"{run}_{j}_v"] / unit, rtol=0, atol=1e-3, equal_nan=True)
         i = yielded[j]

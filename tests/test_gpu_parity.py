@@ -333,7 +333,7 @@ def oracle_pass_from(a, b, geo_prev, geo, mode, u_prev, v_prev, inv_prev):
 
 
 def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP, max_differing=None,
-                  drift_frac=0.002, drift_min=2, check_drift=True):
+                  drift_frac=0.002, drift_min=2, check_drift=True, strict_reference_chain=True):
     """The whole plan (all passes on the device, batch of 2) against the reference's fields of EVERY pass.
     Three gates per pass p; every excuse set is SIZE-CAPPED (constant-input windows aside) and printed:
 
@@ -405,7 +405,9 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
             # the band of the drift gate (C): the same, with the fit clause at half the drift threshold
             Ed = fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5 * DRIFT_PX) | const | ties
             D = (np.abs(Ay_) @ prev_M.astype(np.float64) @ np.abs(Ax_).T) >= 1e-4
-            Dd = (np.abs(Ay_) @ prev_drift.astype(np.float64) @ np.abs(Ax_).T) >= 1e-4
+            # (a drifting coarse vector moves the fine predictor by weight x a few px: the 1e-4 px drift threshold needs
+            #  the downstream weight a decade lower than the 1e-3 px rule above)
+            Dd = (np.abs(Ay_) @ prev_drift.astype(np.float64) @ np.abs(Ax_).T) >= 1e-5
         free = E & ~const
         unexplained = M & ~E & ~D
         counts.append((int(M.sum()), int((M & E).sum()), int((M & ~E & D).sum()), int(unexplained.sum()), M.size))
@@ -416,7 +418,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
         assert free.mean() <= cap_p, (tag, p, "excuse set too large", int(free.sum()), M.size)
         if max_differing is not None:
             assert M.sum() <= max_differing[p], (tag, p, "differing cells", int(M.sum()), "cap", max_differing[p])
-        if precision == "reference" or p == 0:
+        if (precision == "reference" or p == 0) and strict_reference_chain:
             assert not unexplained.any(), (tag, p, np.argwhere(unexplained)[:6].tolist(), err[unexplained][:6].tolist())
         drift = (err > DRIFT_PX) | flip
         if p >= 1:

@@ -467,7 +467,12 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         return op(red[0], red[1]);
     };
     if (lo + slot < hi) fetch(lo + slot);
+    TPIV_STAMP_DECL
+    TPIV_STAMP_START;
     for (long long item = lo + slot; item < hi; item += per_xcd) {
+#ifdef TPIV_STAMPS
+        ++st_iter;
+#endif
         // (lane-derived values are re-made from an opaque copy of the thread index at every phase, so that the
         //  32 + 32 + 66 loop-invariant LDS addresses are not hoisted out of the item loop into registers)
 #define TPIV_F64_TID() [&]() TPIV_LAMBDA_INLINE { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; }()
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         // ---- R: rows forward
         cd x[M];
         rows_forward(da, db, TPIV_F64_TID() >> 6, ra, rb, x);
+        TPIV_STAMP(0);      // window sums, normalisation, rows forward
 
         // ---- T1 + C: transposition with the DIF step of the column transform, columns forward
         cd u[M];
@@ -517,8 +523,10 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
             const int t_ = TPIV_F64_TID();
             t1_read<1>(u, t_ & 63, 1 - (t_ >> 6), plane);
         }
+        TPIV_STAMP(1);      // transposition 1 (4 barriers)
         const int g = 1 - (TPIV_F64_TID() >> 6);     // parity of the column bins this thread owns (wave-uniform)
         cols_forward(u, g);
+        TPIV_STAMP(2);      // columns forward
 
         // ---- X: cross-spectrum; the mirrored bin sits in lane (64 - k) % 64 of the same wavefront
         {
@@ -528,9 +536,11 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
             else cross_spectrum_g<1>(u, partner, sh);
         }
 
+        TPIV_STAMP(3);      // cross-spectrum incl. the bpermute exchange
         // ---- Ci + T2: columns inverse, transposition with the DIT step
         cd t[M];
         cols_inverse(u, g, t);
+        TPIV_STAMP(4);      // columns inverse
         cd Y[M + 1];
         lds_barrier();                               // every thread has read its T1 column
         {
@@ -547,9 +557,11 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         lds_barrier();
         t2_read<1>(Y, TPIV_F64_TID() & 63, plane);
 
+        TPIV_STAMP(5);      // transposition 2 (4 barriers)
         // ---- Ri: rows inverse (c2r over the thread pair)
         double c[M];
         rows_inverse(Y, TPIV_F64_TID() >> 6, c);
+        TPIV_STAMP(6);      // rows inverse
 
         // ---- P: peak analysis on the float64 map
         auto dmin = [](double a, double b) TPIV_LAMBDA_INLINE { return fmin(a, b); };
@@ -579,8 +591,10 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         }
         sv = wg2(sv, dmax, sm.redd + 4);             // (the reductions also order the map writes before the reads below)
         if (tid < 8) reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + tid] = peak_record_slot(tid, m, sv, dead, plane);
+        TPIV_STAMP(7);      // peak analysis incl. the issue of the next window's loads
 #undef TPIV_F64_TID
     }
+    TPIV_STAMP_FLUSH(p);
 }
 
 static hipError_t launch_f64_split64(const PassParams& p, int n_cu, hipStream_t stream) {
