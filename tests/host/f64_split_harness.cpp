@@ -73,16 +73,19 @@ int main() {
         // Ri
         for (int t = 0; t < 128; ++t) rows_inverse(T[t].Y, t >> 6, T[t].c);
         // P
-        double cmin = 1.7e308;
+        double cmin = 1.7e308, graw = -1.7e308;
+        std::vector<double> rraw(128);
         for (int t = 0; t < 128; ++t) {
-            const double m = peak_local_min(T[t].c);
-            cmin = m < cmin ? m : cmin;
+            double mn;
+            peak_local_minmax(T[t].c, mn, rraw[t]);
+            cmin = mn < cmin ? mn : cmin;
+            graw = rraw[t] > graw ? rraw[t] : graw;
         }
-        double gmax = -1.0;
+        const double gmax = peak_shifted(graw, cmin);
         std::vector<double> rmax(128);
         for (int t = 0; t < 128; ++t) {
-            rmax[t] = peak_shift_and_rowmax(T[t].c, cmin, t & 63, t >> 6, plane.data());
-            gmax = rmax[t] > gmax ? rmax[t] : gmax;
+            peak_shift_and_write(T[t].c, cmin, t & 63, t >> 6, plane.data());
+            rmax[t] = peak_shifted(rraw[t], cmin);
         }
         int ywin = WS - 1;
         for (int t = 0; t < 128; ++t) {

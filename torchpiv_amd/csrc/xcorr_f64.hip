@@ -459,13 +459,6 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         load_dwords<NDW>(p.A + off, da);
         load_dwords<NDW>(p.B + off, db);
     };
-    auto wg2 = [&](auto v, auto op, auto* red) TPIV_LAMBDA_INLINE {      // reduction over the two wavefronts
-        v = grp_reduce<64>(v, op);
-        lds_barrier();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-        lds_barrier();
-        return op(red[0], red[1]);
-    };
     if (lo + slot < hi) fetch(lo + slot);
     TPIV_STAMP_DECL
     TPIV_STAMP_START;
@@ -563,33 +556,54 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         rows_inverse(Y, TPIV_F64_TID() >> 6, c);
         TPIV_STAMP(6);      // rows inverse
 
-        // ---- P: peak analysis on the float64 map
+        // ---- P: peak analysis on the float64 map.  Three exchanges between the two wavefronts, ONE barrier each (every
+        //      exchange has its own LDS slots, re-used a window later): (min, raw max) -> map -> first row of the maximum
+        //      -> second peak.
         auto dmin = [](double a, double b) TPIV_LAMBDA_INLINE { return fmin(a, b); };
         auto dmax = [](double a, double b) TPIV_LAMBDA_INLINE { return fmax(a, b); };
         auto imin = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
-        double cmin = peak_local_min(c);
+        double cmin, rraw;
+        peak_local_minmax(c, cmin, rraw);
         // prefetch: the last iteration re-loads its own window (no branch around the loads)
         fetch(item + per_xcd < hi ? item + per_xcd : item);
-        cmin = wg2(cmin, dmin, sm.redd);             // (its barriers also order the T2 reads before the map writes)
-        double rmax;
+        {
+            const double mn = grp_reduce<64>(cmin, dmin), mx = grp_reduce<64>(rraw, dmax);
+            const int t_ = TPIV_F64_TID();
+            if ((t_ & 63) == 0) {
+                sm.redd[t_ >> 6] = mn;
+                sm.redd[2 + (t_ >> 6)] = mx;
+            }
+            lds_barrier();                            // (also: every thread has read its T2 row -> the map may be written)
+            cmin = fmin(sm.redd[0], sm.redd[1]);
+        }
+        const double gmax = peak_shifted(fmax(sm.redd[2], sm.redd[3]), cmin);
         {
             const int t_ = TPIV_F64_TID();
-            rmax = peak_shift_and_rowmax(c, cmin, t_ & 63, t_ >> 6, plane);
+            peak_shift_and_write(c, cmin, t_ & 63, t_ >> 6, plane);
         }
-        const double gmax = wg2(rmax, dmax, sm.redd + 2);
         // arg-max = FIRST flat index holding the maximum (B:383): the smallest shifted row whose maximum is the global
         // one, then the first column of that row -- lane = column, one LDS read and a ballot (both wavefronts do it: same
         // row, same result, no exchange)
-        const int ywin = wg2(rmax == gmax ? (((TPIV_F64_TID() & 63) + WS / 2) & (WS - 1)) : WS - 1, imin, sm.redi);    // (map complete)
+        int ywin;
+        {
+            const int t_ = TPIV_F64_TID();
+            const int fy = ((t_ & 63) + WS / 2) & (WS - 1);
+            const int yw = grp_reduce<64>(peak_shifted(rraw, cmin) == gmax ? fy : WS - 1, imin);
+            if ((t_ & 63) == 0) sm.redi[t_ >> 6] = yw;
+            lds_barrier();                            // (also: map complete)
+            ywin = imin(sm.redi[0], sm.redi[1]);
+        }
         const unsigned long long hit = __ballot(plane[ywin * PL + (TPIV_F64_TID() & 63)] == gmax);
         const int xwin = hit ? (int)__builtin_ctzll(hit) : WS - 1;
         const int m = ywin * WS + xwin;
         double sv;
         {
             const int t_ = TPIV_F64_TID();
-            sv = peak_second_local(c, t_ & 63, t_ >> 6, m, p.val_win);
+            sv = grp_reduce<64>(peak_second_local(c, t_ & 63, t_ >> 6, m, p.val_win), dmax);
+            if ((t_ & 63) == 0) sm.redd[4 + (t_ >> 6)] = sv;
+            lds_barrier();
+            sv = fmax(sm.redd[4], sm.redd[5]);
         }
-        sv = wg2(sv, dmax, sm.redd + 4);             // (the reductions also order the map writes before the reads below)
         if (tid < 8) reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + tid] = peak_record_slot(tid, m, sv, dead, plane);
         TPIV_STAMP(7);      // peak analysis incl. the issue of the next window's loads
 #undef TPIV_F64_TID

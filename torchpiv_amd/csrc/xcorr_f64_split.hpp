@@ -284,33 +284,37 @@ TPIV_HD void rows_inverse(cd (&Y)[M + 1], int q, double (&c)[M]) {
 // c[2n + e] = corr[y][x = 4n + 2q + e].
 TPIV_HD int col_of(int n, int e, int q) { return 4 * n + 2 * q + e; }
 
-TPIV_HD double peak_local_min(const double (&c)[M]) {
-    double m = c[0];
+// one pass over the raw cells gives their minimum AND their maximum: v = (c - min) + 1e-7 is monotonic in c, so the
+// maximum of the shifted cells is the shifted maximum (exactly: the same two roundings)
+TPIV_HD void peak_local_minmax(const double (&c)[M], double& mn, double& mx) {
+    mn = c[0];
+    mx = c[0];
 #pragma unroll
-    for (int i = 1; i < M; ++i) m = fmin(m, c[i]);
-    return m;
+    for (int i = 1; i < M; ++i) {
+        mn = fmin(mn, c[i]);
+        mx = fmax(mx, c[i]);
+    }
 }
-// v = (c - min) + 1e-7 (B:518, B:381), written to the map (plane, shifted coordinates); returns the row maximum of the
-// thread's cells.  (No index is tracked here: the arg-max position comes from the map afterwards -- first the smallest
-// row whose maximum is the global one, then the first column of that row, peak_first_column -- which keeps the scan
-// free of compare / select chains.)
-TPIV_HD double peak_shift_and_rowmax(double (&c)[M], double cmin, int y, int q, double* plane) {
+TPIV_HD double peak_shifted(double c, double cmin) {       // B:518, B:381
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __dadd_rn(__dsub_rn(c, cmin), 1e-7);
+#else
+    return (c - cmin) + 1e-7;
+#endif
+}
+// v = (c - min) + 1e-7, written to the map (plane, shifted coordinates).  (No index is tracked: the arg-max position
+// comes from the map afterwards -- first the smallest row whose maximum is the global one, then the first column of that
+// row -- which keeps the scan free of compare / select chains.)
+TPIV_HD void peak_shift_and_write(double (&c)[M], double cmin, int y, int q, double* plane) {
     const int fy = (y + WS / 2) & (WS - 1);
     double* row = plane + fy * PL + 2 * q;
-    double rmax = 0.0;
     static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
         constexpr int i = decltype(ic)::value;
         constexpr int fx0 = (4 * (i >> 1) + (i & 1) + WS / 2) & (WS - 1);       // + 2 q: stays inside its group of four
-#if defined(__HIP_DEVICE_COMPILE__)
-        const double v = __dadd_rn(__dsub_rn(c[i], cmin), 1e-7);
-#else
-        const double v = (c[i] - cmin) + 1e-7;
-#endif
+        const double v = peak_shifted(c[i], cmin);
         c[i] = v;
         row[fx0] = v;
-        rmax = fmax(rmax, v);
     });
-    return rmax;
 }
 // second peak: the thread's maximum outside the flat-index exclusion zone of m (B:346-358): f in {clamp(m + i + 64 j),
 // |i|, |j| <= wv}: in row fy the columns mx + i (j = fy - my), mx + i + 64 (the row wrap, j = fy - my - 1) and
