@@ -332,6 +332,20 @@ def mask_ties(shape, geo_prev, geo, inv_prev):
     return np.abs(m - 0.5) < 1e-9
 
 
+def sign_sensitive(mode, u2, v2):
+    """CWS border windows whose half shift is a rounding error away from zero (|shift| < 1e-6 px: what a pass over
+    identical frames hands on).  float32(g) + v is integral for every pixel coordinate g >= 1 -- the reference's
+    "nearest sample" branch, whatever the sign of v -- but not at g = 0, where v < 0 floors to -1 and the flat-index clamp /
+    wrap fetches another pixel (B:162-180): for the windows that hold pixel row / column 0 the SIGN of a 1e-9 px predictor
+    decides a whole sample row, and two implementations of the same spline need not agree on the sign of a sum that
+    cancels to rounding noise.  u2, v2: the half shifts [n_rows, n_cols] of the chain under test."""
+    s = np.zeros(u2.shape, bool)
+    if mode == "CWS":
+        s[:, 0] |= np.abs(u2[:, 0]) < 1e-6
+        s[0, :] |= np.abs(v2[0, :]) < 1e-6
+    return s
+
+
 def oracle_pass_from(a, b, geo_prev, geo, mode, u_prev, v_prev, inv_prev):
     """The oracle's pass (B:690-740 / B:757-812) fed with GIVEN fields of the pass before (numpy; e.g. the
     GPU's own): returns its u, v, validity and the windows it staged (for the noise band)."""
@@ -345,7 +359,7 @@ def oracle_pass_from(a, b, geo_prev, geo, mode, u_prev, v_prev, inv_prev):
     else:
         aa = O.shift_dws(a, it.idx, -f(u2, np.int64), -f(v2, np.int64))
         bb = O.shift_dws(b, it.idx, f(u2, np.int64), f(v2, np.int64))
-    return ru, rv, rval, aa, bb
+    return ru, rv, rval, aa, bb, sign_sensitive(mode, u2, v2)
 
 
 def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP, max_differing=None,
@@ -417,6 +431,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
             const = constant_windows(aa, bb, nr, nc)
             E = fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5e-3) | const
             ties = mask_ties((H, W), geo[p - 1], geo[p], g[f"{name}_{mode}_p{p-1}_val"])
+            ties |= sign_sensitive(mode, u2[0].cpu().numpy(), v2[0].cpu().numpy())
             E |= ties
             # the band of the drift gate (C): the same, with the fit clause at half the drift threshold
             Ed = fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5 * DRIFT_PX) | const | ties
@@ -440,10 +455,10 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
         if p >= 1:
             # (B) isolation: oracle pass p from the GPU's own pass p-1
             gu, gv, gi = fields[p - 1]
-            ou, ov_, oval, aa2, bb2 = oracle_pass_from(a, b, geo[p - 1], geo[p], mode, gu, gv, gi)
+            ou, ov_, oval, aa2, bb2, sens = oracle_pass_from(a, b, geo[p - 1], geo[p], mode, gu, gv, gi)
             const2 = constant_windows(aa2, bb2, nr, nc)
             E2 = fp32_noise_excuse(aa2, bb2, nr, nc, ulps=16.0, fit_tol=0.5e-3) | const2
-            E2 |= mask_ties((H, W), geo[p - 1], geo[p], gi)
+            E2 |= mask_ties((H, W), geo[p - 1], geo[p], gi) | sens
             err2 = np.maximum(np.abs(pu - ou), np.abs(pv - ov_))
             M2 = (err2 > TOL_PX) | (pi != oval)
             free2 = E2 & ~const2

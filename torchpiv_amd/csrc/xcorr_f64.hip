@@ -559,8 +559,8 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         // ---- P: peak analysis on the float64 map.  Three exchanges between the two wavefronts, ONE barrier each (every
         //      exchange has its own LDS slots, re-used a window later): (min, raw max) -> map -> first row of the maximum
         //      -> second peak.
-        auto dmin = [](double a, double b) TPIV_LAMBDA_INLINE { return fmin(a, b); };
-        auto dmax = [](double a, double b) TPIV_LAMBDA_INLINE { return fmax(a, b); };
+        auto dmin = [](double a, double b) TPIV_LAMBDA_INLINE { return dmin2(a, b); };
+        auto dmax = [](double a, double b) TPIV_LAMBDA_INLINE { return dmax2(a, b); };
         auto imin = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
         double cmin, rraw;
         peak_local_minmax(c, cmin, rraw);
@@ -574,9 +574,9 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
                 sm.redd[2 + (t_ >> 6)] = mx;
             }
             lds_barrier();                            // (also: every thread has read its T2 row -> the map may be written)
-            cmin = fmin(sm.redd[0], sm.redd[1]);
+            cmin = dmin2(sm.redd[0], sm.redd[1]);
         }
-        const double gmax = peak_shifted(fmax(sm.redd[2], sm.redd[3]), cmin);
+        const double gmax = peak_shifted(dmax2(sm.redd[2], sm.redd[3]), cmin);
         {
             const int t_ = TPIV_F64_TID();
             peak_shift_and_write(c, cmin, t_ & 63, t_ >> 6, plane);
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
             sv = grp_reduce<64>(peak_second_local(c, t_ & 63, t_ >> 6, m, p.val_win), dmax);
             if ((t_ & 63) == 0) sm.redd[4 + (t_ >> 6)] = sv;
             lds_barrier();
-            sv = fmax(sm.redd[4], sm.redd[5]);
+            sv = dmax2(sm.redd[4], sm.redd[5]);
         }
         if (tid < 8) reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + tid] = peak_record_slot(tid, m, sv, dead, plane);
         TPIV_STAMP(7);      // peak analysis incl. the issue of the next window's loads

@@ -284,6 +284,26 @@ TPIV_HD void rows_inverse(cd (&Y)[M + 1], int q, double (&c)[M]) {
 // c[2n + e] = corr[y][x = 4n + 2q + e].
 TPIV_HD int col_of(int n, int e, int q) { return 4 * n + 2 * q + e; }
 
+// min / max of two finite doubles as ONE instruction (fmin / fmax are compiled to v_min_f64 / v_max_f64 plus a
+// canonicalising v_max_f64 x, x per operand -- sNaN quieting the map values never need: 100 float64 instructions per window)
+TPIV_HD double dmin2(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a < b ? a : b;
+#endif
+}
+TPIV_HD double dmax2(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a > b ? a : b;
+#endif
+}
 // one pass over the raw cells gives their minimum AND their maximum: v = (c - min) + 1e-7 is monotonic in c, so the
 // maximum of the shifted cells is the shifted maximum (exactly: the same two roundings)
 TPIV_HD void peak_local_minmax(const double (&c)[M], double& mn, double& mx) {
@@ -291,8 +311,8 @@ TPIV_HD void peak_local_minmax(const double (&c)[M], double& mn, double& mx) {
     mx = c[0];
 #pragma unroll
     for (int i = 1; i < M; ++i) {
-        mn = fmin(mn, c[i]);
-        mx = fmax(mx, c[i]);
+        mn = dmin2(mn, c[i]);
+        mx = dmax2(mx, c[i]);
     }
 }
 TPIV_HD double peak_shifted(double c, double cmin) {       // B:518, B:381
@@ -352,7 +372,7 @@ TPIV_HD double peak_second_local(const double (&c)[M], int y, int q, int m, int 
         const bool excl = ((fx0 < 32 ? exl : exh) >> (fx0 & 31)) & 1u;
         const double v = excl ? -c[i] : c[i];
 #endif
-        sv = fmax(sv, v);
+        sv = dmax2(sv, v);
     });
     return sv;
 }
