@@ -431,8 +431,10 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
             const = constant_windows(aa, bb, nr, nc)
             E = fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5e-3) | const
             ties = mask_ties((H, W), geo[p - 1], geo[p], g[f"{name}_{mode}_p{p-1}_val"])
-            ties |= sign_sensitive(mode, u2[0].cpu().numpy(), v2[0].cpu().numpy())
+            sens_ref = sign_sensitive(mode, u2[0].cpu().numpy(), v2[0].cpu().numpy())
+            ties |= sens_ref
             E |= ties
+            const = const | sens_ref        # (a structural class like the constant-input windows: outside the size cap)
             # the band of the drift gate (C): the same, with the fit clause at half the drift threshold
             Ed = fp32_noise_excuse(aa, bb, nr, nc, ulps=16.0, fit_tol=0.5 * DRIFT_PX) | const | ties
             D = (np.abs(Ay_) @ prev_M.astype(np.float64) @ np.abs(Ax_).T) >= 1e-4
@@ -459,6 +461,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
             const2 = constant_windows(aa2, bb2, nr, nc)
             E2 = fp32_noise_excuse(aa2, bb2, nr, nc, ulps=16.0, fit_tol=0.5e-3) | const2
             E2 |= mask_ties((H, W), geo[p - 1], geo[p], gi) | sens
+            const2 = const2 | sens
             err2 = np.maximum(np.abs(pu - ou), np.abs(pv - ov_))
             M2 = (err2 > TOL_PX) | (pi != oval)
             free2 = E2 & ~const2

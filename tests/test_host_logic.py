@@ -295,3 +295,41 @@ def test_f64_split_scheme_on_the_host(tmp_path):
                 assert rec[slot] == got.flat[q], (i, slot)
         if 3 <= i < 7:                                      # the circular shift is found exactly
             assert (m // 64 - 32, m % 64 - 32) == (3 * i - 13, 5 - 2 * i)
+
+
+def test_fast_hole_fill_is_the_reference_interpolator_bit_for_bit():
+    """torchpiv_amd._qhull.qhull_fill (scipy.spatial.Delaunay + the barycentric arithmetic of scipy's _interpnd spelled out
+    in numpy) against the reference's literal scipy.interpolate.LinearNDInterpolator call on random hole patterns --
+    isolated invalid vectors (co-circular diamonds: Qhull's tie-break decides), runs, blobs, holes at the border: every
+    filled value bit-identical, NaNs (targets outside the hull) and refusals (collinear rings) alike."""
+    from torchpiv_amd._qhull import qhull_fill, qhull_fill_reference
+    rng = np.random.default_rng(2024)
+    n_vals = n_masks = n_nan = n_refused = 0
+    for trial in range(700):
+        nr, nc = rng.integers(6, 70, 2)
+        h = rng.random((nr, nc)) < rng.choice([0.004, 0.02, 0.05, 0.12])
+        if rng.random() < 0.35:
+            r, c = rng.integers(0, nr - 3), rng.integers(0, nc - 3)
+            h[r:r + rng.integers(1, 4), c:c + rng.integers(1, 5)] = True
+        if rng.random() < 0.1:
+            h[rng.integers(0, nr), :] = True               # a whole row: the ring falls apart into two lines
+        if not h.any():
+            continue
+        d = h.copy()
+        d[1:] |= h[:-1]
+        d[:-1] |= h[1:]
+        d[:, 1:] |= h[:, :-1]
+        d[:, :-1] |= h[:, 1:]
+        pts, tg = np.argwhere(d & ~h), np.argwhere(h)
+        vals = rng.standard_normal((len(pts), 2)) * 5
+        ref, got = qhull_fill_reference(pts, vals, tg), qhull_fill(pts, vals, tg)
+        assert (ref is None) == (got is None), trial
+        if ref is None:
+            n_refused += 1
+            continue
+        assert np.array_equal(ref, got, equal_nan=True), trial
+        n_masks += 1
+        n_vals += ref.size
+        n_nan += int(np.isnan(ref).sum())
+    print(f"  {n_masks} masks, {n_vals} filled values bit-identical ({n_nan} NaN outside the hull), {n_refused} rings refused by Qhull")
+    assert n_masks > 500 and n_nan > 0 and n_refused > 0
