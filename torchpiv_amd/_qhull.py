@@ -33,7 +33,8 @@ def qhull_fill(points, values, targets):
         return None
     x = np.ascontiguousarray(targets, dtype=np.float64)
     values = np.asarray(values, dtype=np.float64)
-    if values.ndim == 1:
+    flat = values.ndim == 1
+    if flat:
         values = values[:, None]
     # the simplex walk of LinearNDInterpolator._do_evaluate (same routine, same start-from-the-last-hit order)
     s = tri.find_simplex(x)
@@ -50,4 +51,9 @@ def qhull_fill(points, values, targets):
     for j, c in enumerate((c0, c1, c2)):         # out += c[j] * values[vertex j], in vertex order
         out = out + c[:, None] * values[simp[:, j]]
     out[~inside] = np.nan                        # outside the hull: fill_value
-    return out
+    return out[:, 0] if flat else out
+
+
+def qhull_fill_many(jobs):
+    """[qhull_fill(*job) for job in jobs] -- one task of the worker pool carries several pairs (IPC per task, not per pair)."""
+    return [qhull_fill(*job) for job in jobs]

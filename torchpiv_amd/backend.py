@@ -26,7 +26,7 @@ import torch
 
 from . import engine
 from ._lib import PRECISIONS
-from ._qhull import qhull_fill      # numpy/scipy-only module: the fill worker processes import nothing else
+from ._qhull import qhull_fill, qhull_fill_many      # numpy/scipy-only module: the fill worker processes import nothing else
 from .io import PIVDataset, ToTensor, natural_keys  # noqa: F401  (re-exported like the reference)
 
 
@@ -453,26 +453,42 @@ class OfflinePIV:
         for _ in range(2 * int(too_many.sum())):                  # once for u, once for v (B:306, B:889-890)
             print(TOO_MANY_MSG)
         out = [None] * n
-        jobs = []
-        for i in np.flatnonzero(keep):
-            if need_host[i]:
-                hole = (ck[i] >= 1) & (ck[i] <= 4)
-                rg = _ring_of(hole)
-                jobs.append((int(i), hole, (np.argwhere(rg), np.stack([uk[i][rg], vk[i][rg]], axis=1), np.argwhere(hole))))
-            else:
-                st["device_complete"] += 1
-                out[int(i)] = (uk[i], vk[i])
-        if jobs:
+        for i in np.flatnonzero(keep & ~need_host):
+            st["device_complete"] += 1
+            out[int(i)] = (uk[i], vk[i])
+        need = np.flatnonzero(need_host)
+        if need.size:
+            # ring points, their values and the hole cells of ALL pairs of the batch that need the triangulation, in one
+            # sweep (np.argwhere over the stack lists pair after pair, row-major inside a pair: the reference's order)
+            holes = (ck[need] >= 1) & (ck[need] <= 4)
+            rings = np.zeros_like(holes)
+            rings[:, 1:, :] |= holes[:, :-1, :]
+            rings[:, :-1, :] |= holes[:, 1:, :]
+            rings[:, :, 1:] |= holes[:, :, :-1]
+            rings[:, :, :-1] |= holes[:, :, 1:]
+            rings &= ~holes
+            hp, rp = np.argwhere(holes), np.argwhere(rings)
+            vals = np.stack([uk[need][rings], vk[need][rings]], axis=1)
+            h_cut = np.searchsorted(hp[:, 0], np.arange(need.size + 1))
+            r_cut = np.searchsorted(rp[:, 0], np.arange(need.size + 1))
+            jobs = [(rp[r_cut[k]:r_cut[k + 1], 1:], vals[r_cut[k]:r_cut[k + 1]], hp[h_cut[k]:h_cut[k + 1], 1:])
+                    for k in range(need.size)]
             pool = self._fill_pool()
-            sols = pool.starmap(qhull_fill, [j[2] for j in jobs], chunksize=max(1, len(jobs) // (4 * self.fill_workers))) \
-                if pool is not None else [qhull_fill(*j[2]) for j in jobs]
-            for (i, hole, _), vals in zip(jobs, sols):
+            if pool is not None:
+                per = max(1, -(-len(jobs) // (2 * self.fill_workers)))          # two tasks per worker and batch
+                chunks = [jobs[k:k + per] for k in range(0, len(jobs), per)]
+                sols = [s_ for part in pool.map(qhull_fill_many, chunks) for s_ in part]
+            else:
+                sols = qhull_fill_many(jobs)
+            for k, vals_k in enumerate(sols):
+                i = int(need[k])
                 st["host_fallback"] += 1
-                if vals is None:
+                if vals_k is None:
                     st["dropped_by_qhull"] += 1
                     continue
-                uk[i][hole] = vals[:, 0]
-                vk[i][hole] = vals[:, 1]
+                cells = hp[h_cut[k]:h_cut[k + 1], 1:]
+                uk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 0]
+                vk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 1]
                 out[i] = (uk[i], vk[i])
         return out
 
