@@ -33,8 +33,7 @@ int main() {
         unsigned long long sa = 0, sb = 0;
         for (int i = 0; i < 4096; ++i) sa += a[i], sb += b[i];
         const bool dead = sa == 0 || sb == 0;
-        const double pre = 0.5 / WS;
-        const double ra = dead ? 0.0 : (double)(WS * WS) / (double)sa * pre, rb = dead ? 0.0 : (double)(WS * WS) / (double)sb * pre;
+        const double map_scale = dead ? 0.0 : ((double)(WS * WS) * 0.25) / ((double)sa * (double)sb);
         // R
         for (int t = 0; t < 128; ++t) {
             const int y = t & 63, h = t >> 6;
@@ -42,7 +41,7 @@ int main() {
                 T[t].da[q] = a[y * 64 + 4 * q] | (a[y * 64 + 4 * q + 1] << 8) | (a[y * 64 + 4 * q + 2] << 16) | ((uint32_t)a[y * 64 + 4 * q + 3] << 24);
                 T[t].db[q] = b[y * 64 + 4 * q] | (b[y * 64 + 4 * q + 1] << 8) | (b[y * 64 + 4 * q + 2] << 16) | ((uint32_t)b[y * 64 + 4 * q + 3] << 24);
             }
-            rows_forward(T[t].da, T[t].db, h, ra, rb, T[t].x);
+            rows_forward(T[t].da, T[t].db, h, T[t].x);
         }
         // T1, one component at a time
         for (int t = 0; t < 128; ++t) t1_write<0>(T[t].x, t & 63, t >> 6, plane.data());
@@ -81,11 +80,11 @@ int main() {
             cmin = mn < cmin ? mn : cmin;
             graw = rraw[t] > graw ? rraw[t] : graw;
         }
-        const double gmax = peak_shifted(graw, cmin);
+        const double gmax = peak_shifted(graw, cmin, map_scale);
         std::vector<double> rmax(128);
         for (int t = 0; t < 128; ++t) {
-            peak_shift_and_write(T[t].c, cmin, t & 63, t >> 6, plane.data());
-            rmax[t] = peak_shifted(rraw[t], cmin);
+            peak_shift_and_write(T[t].c, cmin, map_scale, t & 63, t >> 6, plane.data());
+            rmax[t] = peak_shifted(rraw[t], cmin, map_scale);
         }
         int ywin = WS - 1;
         for (int t = 0; t < 128; ++t) {

@@ -483,16 +483,15 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
             ib = (unsigned)(s2 >> 32);
         }
         const bool dead = ia == 0u || ib == 0u;          // zero-mean window: 0/0 = NaN map in the reference
-        // a / mean(a) (B:513-514) as (a[j] +- a[j+32]) * (n^2 / sum): one division per window; 0.5/64 on both inputs
-        // is the 1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra (exact power of two)
-        constexpr double PRE = 0.5 / (double)WS;
-        const double ra = dead ? 0.0 : ((double)(WS * WS) / (double)ia) * PRE;
-        const double rb = dead ? 0.0 : ((double)(WS * WS) / (double)ib) * PRE;
+        // a / mean(a), b / mean(b) (B:513-514) as ONE factor on the correlation map (xcorr_f64_split.hpp, rows_forward):
+        // n^2 / sum(a) * n^2 / sum(b), times 1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra;
+        // sum(a) sum(b) < 2^42 is exact, so this is one correctly rounded division per window
+        const double map_scale = dead ? 0.0 : ((double)(WS * WS) * 0.25) / ((double)ia * (double)ib);
 
         // ---- R: rows forward
         cd x[M];
-        rows_forward(da, db, TPIV_F64_TID() >> 6, ra, rb, x);
-        TPIV_STAMP(0);      // window sums, normalisation, rows forward
+        rows_forward(da, db, TPIV_F64_TID() >> 6, x);
+        TPIV_STAMP(0);      // window sums, rows forward
 
         // ---- T1 + C: transposition with the DIF step of the column transform, columns forward
         cd u[M];
@@ -576,10 +575,10 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
             lds_barrier();                            // (also: every thread has read its T2 row -> the map may be written)
             cmin = dmin2(sm.redd[0], sm.redd[1]);
         }
-        const double gmax = peak_shifted(dmax2(sm.redd[2], sm.redd[3]), cmin);
+        const double gmax = peak_shifted(dmax2(sm.redd[2], sm.redd[3]), cmin, map_scale);
         {
             const int t_ = TPIV_F64_TID();
-            peak_shift_and_write(c, cmin, t_ & 63, t_ >> 6, plane);
+            peak_shift_and_write(c, cmin, map_scale, t_ & 63, t_ >> 6, plane);
         }
         // arg-max = FIRST flat index holding the maximum (B:383): the smallest shifted row whose maximum is the global
         // one, then the first column of that row -- lane = column, one LDS read and a ballot (both wavefronts do it: same
@@ -588,7 +587,7 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         {
             const int t_ = TPIV_F64_TID();
             const int fy = ((t_ & 63) + WS / 2) & (WS - 1);
-            const int yw = grp_reduce<64>(peak_shifted(rraw, cmin) == gmax ? fy : WS - 1, imin);
+            const int yw = grp_reduce<64>(peak_shifted(rraw, cmin, map_scale) == gmax ? fy : WS - 1, imin);
             if ((t_ & 63) == 0) sm.redi[t_ >> 6] = yw;
             lds_barrier();                            // (also: map complete)
             ywin = imin(sm.redi[0], sm.redi[1]);

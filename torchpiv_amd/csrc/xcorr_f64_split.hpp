@@ -68,16 +68,18 @@ __device__ __forceinline__ void lds_wait(double (&v)[8]) {
 __device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned)(uintptr_t)p; }     // low dword of a flat LDS address
 #endif
 
-// ---- R: thread (y, h).  da / db: row y of frame a / b (64 bytes each); ra, rb: 1/mean(a), 1/mean(b) times the
-// power of two 0.5/64 (1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra, exact).
-TPIV_HD void rows_forward(const uint32_t (&da)[NDW], const uint32_t (&db)[NDW], int h, double ra, double rb, cd (&x)[M]) {
+// ---- R: thread (y, h).  da / db: row y of frame a / b (64 bytes each).  The samples go in as they are: the
+// normalisation a / mean(a), b / mean(b) of B:513-514 is linear, so it is ONE factor 1 / (mean(a) mean(b)) on the whole
+// correlation map, applied where the map is shifted by its minimum (peak_shifted) -- 64 multiplies per thread and one of
+// two divisions per window less, at rounding-level differences (1e-16 relative) from scaling every sample first.
+TPIV_HD void rows_forward(const uint32_t (&da)[NDW], const uint32_t (&db)[NDW], int h, cd (&x)[M]) {
     const float sg = h ? -1.0f : 1.0f;
     static_for<0, M>([&](auto jc) TPIV_LAMBDA_INLINE {
         constexpr int j = decltype(jc)::value;
         // sums / differences of two bytes: exact in float32, converted once
         const float sa = byte_of<j>(da) + sg * byte_of<j + M>(da);
         const float sb = byte_of<j>(db) + sg * byte_of<j + M>(db);
-        x[j] = cd{(double)sa * ra, (double)sb * rb};
+        x[j] = cd{(double)sa, (double)sb};
     });
     if (h) {
         static_for<1, M>([&](auto jc) TPIV_LAMBDA_INLINE {
@@ -146,7 +148,7 @@ TPIV_HD void cols_forward(cd (&u)[M], int g) {
 }
 
 // ---- X: cross-spectrum in place.  With Z(k) = a + ib, Z(-k) = c + id:  4 P(k) = 2 (a d + b c) + i ((c^2 - a^2) + (d^2 - b^2))
-// (the factor 0.25 / n^2 is in the inputs).  sh(value, reg, partner) returns the PARTNER thread's value of register `reg`
+// (the factor 0.25 / n^2 rides in the map scale, peak_shifted).  sh(value, reg, partner) returns the PARTNER thread's value of register `reg`
 // (device: ds_bpermute of `value`; the host harness looks the register up).
 // (device: an empty asm on a value keeps computations that depend on it where they are written -- left alone, the
 //  compiler hoists the squares a^2, b^2 of ALL bins out of both parity branches and spills 48 of them)
@@ -315,23 +317,25 @@ TPIV_HD void peak_local_minmax(const double (&c)[M], double& mn, double& mx) {
         mx = dmax2(mx, c[i]);
     }
 }
-TPIV_HD double peak_shifted(double c, double cmin) {       // B:518, B:381
+// (corr - min) + 1e-7 of B:518 / B:381 on the normalised map: `scale` = 1 / (mean(a) mean(b)) times the constant factors of
+// the transforms (rows_forward)
+TPIV_HD double peak_shifted(double c, double cmin, double scale) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __dadd_rn(__dsub_rn(c, cmin), 1e-7);
+    return __fma_rn(__dsub_rn(c, cmin), scale, 1e-7);
 #else
-    return (c - cmin) + 1e-7;
+    return (c - cmin) * scale + 1e-7;
 #endif
 }
 // v = (c - min) + 1e-7, written to the map (plane, shifted coordinates).  (No index is tracked: the arg-max position
 // comes from the map afterwards -- first the smallest row whose maximum is the global one, then the first column of that
 // row -- which keeps the scan free of compare / select chains.)
-TPIV_HD void peak_shift_and_write(double (&c)[M], double cmin, int y, int q, double* plane) {
+TPIV_HD void peak_shift_and_write(double (&c)[M], double cmin, double scale, int y, int q, double* plane) {
     const int fy = (y + WS / 2) & (WS - 1);
     double* row = plane + fy * PL + 2 * q;
     static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
         constexpr int i = decltype(ic)::value;
         constexpr int fx0 = (4 * (i >> 1) + (i & 1) + WS / 2) & (WS - 1);       // + 2 q: stays inside its group of four
-        const double v = peak_shifted(c[i], cmin);
+        const double v = peak_shifted(c[i], cmin, scale);
         c[i] = v;
         row[fx0] = v;
     });
