@@ -14,13 +14,14 @@ ap.add_argument("--distinct", type=int, default=2)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--kind", default="wavy")
 ap.add_argument("--width", type=int, default=0, help="frame width when it differs from --size (row-pitch experiments)")
+ap.add_argument("--precision", default="fast", choices=("fast", "f64", "reference"))
 a = ap.parse_args()
 H = a.size
 W = a.width or a.size
 A0, B0 = synth.make_batch(a.distinct, H, W, device="cuda", kind=a.kind)
 A = A0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
 B = B0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
-plan = engine.Plan(H, W, a.ws, a.ws // 2, n_pass=a.passes, mode=a.mode, max_batch=a.batch)
+plan = engine.Plan(H, W, a.ws, a.ws // 2, n_pass=a.passes, mode=a.mode, max_batch=a.batch, precision=a.precision)
 out = plan.run(A, B)
 torch.cuda.synchronize()
 for p in range(a.passes):
@@ -33,7 +34,7 @@ for i in range(a.iters):
 torch.cuda.synchronize()
 ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.iters)]
 t = sorted(ts)[len(ts) // 2]
-print(f"size {H} ws {a.ws} passes {a.passes} {a.mode} batch {a.batch}: {t:.3f} ms/batch, "
+print(f"size {H} ws {a.ws} passes {a.passes} {a.mode} batch {a.batch} precision {a.precision}: {t:.3f} ms/batch, "
       f"{t / a.batch * 1000:.1f} us/pair, {a.batch / t * 1000:.1f} pairs/s  (all: {[round(x, 2) for x in ts]})")
 plan.set_timing(True)
 for i in range(3):

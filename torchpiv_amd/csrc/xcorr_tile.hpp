@@ -513,7 +513,13 @@ struct CoopGeo {
     static constexpr int NCH = (T + WS - 1) / WS;             // chunks per lane
     static constexpr int PITCH4 = RPG | 1;                    // LDS row pitch in 16-byte units (odd: see above)
     static constexpr int PATCH4 = NROW * PITCH4;              // 16-byte units per patch
-    static constexpr int FLOATS = (64 / WS) * 2 * PATCH4 * 4; // all patches of a wavefront, in floats
+    // The two patches of a window form a block whose size is a multiple of 256 bytes: a 16-byte row read covers the
+    // 64 banks with 16 lanes, and for 16x16 (32x32) tiles those lanes belong to two windows -- with the blocks a
+    // multiple of 256 bytes apart the rows of both interleave on the same 12-dword lattice (conflict-free); at the
+    // natural size (1632 bytes for 16x16) they collided: SQ_LDS_BANK_CONFLICT 35 % of the LDS-active cycles of the
+    // 16x16 CWS pass (profiles/r02).
+    static constexpr int BLOCK4 = (2 * PATCH4 + 15) / 16 * 16;
+    static constexpr int FLOATS = (64 / WS) * BLOCK4 * 4;     // all patches of a wavefront, in floats
     static constexpr int LDS_FLOATS = FLOATS + (64 / WS) * (WS + 1) * 4;      // + the x-weight tables
     static_assert(!ON || RPG <= PITCH4, "patch row pitch");
     __device__ static __forceinline__ void chunk(int ci, int& j, int& part) {
@@ -761,6 +767,14 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
     }
 }
 
+// first dword of a 16-byte LDS unit, read AS a ds_read_b128 (the empty asm keeps all four components "used": left
+// alone, the compiler narrows the load to a ds_read_b32, which is bank-conflicted at the patch row pitch)
+__device__ __forceinline__ uint32_t read_unit_x(const uint4* src) {
+    uint4 t = *src;
+    asm volatile("" : "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));
+    return t.x;
+}
+
 // raw rows -> float samples x[k] = (a, b) and the lane's partial sums
 // RBH: the per-pixel slow paths park a row in LDS in RBH pieces (2 when the planar 64x64 layout
 // leaves only 64 x 33 floats)
@@ -844,7 +858,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                 // the chunks go to LDS, the lane's rows come back (same wavefront: program order is enough)
                 uint4* pl = reinterpret_cast<uint4*>(lds);
                 const int w_ = lane / WS;
-                uint4* pa = pl + (w_ * 2) * CG::PATCH4;
+                uint4* pa = pl + w_ * CG::BLOCK4;
                 uint4* pb = pa + CG::PATCH4;
                 wave_sync();
 #pragma unroll
@@ -872,7 +886,10 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                         const uint4 t = src[q];
                         d[4 * q] = t.x, d[4 * q + 1] = t.y, d[4 * q + 2] = t.z, d[4 * q + 3] = t.w;
                     }
-                    d[NB - 1] = reinterpret_cast<const uint32_t*>(src)[NB - 1];          // NB = 4 m + 1
+                    // NB = 4 m + 1: the last dword comes with one more 16-byte read (the row holds RPG = m + 1 units) -- a
+                    // ds_read_b32 at a row pitch of 12 dwords is 4-way bank-conflicted
+                    static_assert(CG::RPG * 4 >= NB, "patch rows hold the whole 16-byte unit of the last dword");
+                    d[NB - 1] = read_unit_x(src + NB / 4);
                 };
                 if (raw.fix) {
                     // border windows: a source row entirely outside the frame reads the first / last pixel of the
@@ -946,7 +963,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                             const uint4 t = src[q];
                             d[4 * q] = t.x, d[4 * q + 1] = t.y, d[4 * q + 2] = t.z, d[4 * q + 3] = t.w;
                         } else {
-                            d[NB - 1] = reinterpret_cast<const uint32_t*>(src)[NB - 1];
+                            d[NB - 1] = read_unit_x(src + NB / 4);
                         }
                     };
                     one(lz0, ra0), one(lz1, ra1), one(lz2, rb0), one(lz3, rb1);
