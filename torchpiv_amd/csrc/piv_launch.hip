@@ -183,7 +183,7 @@ const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int le
     precision = pass_precision(precision, mode);
     if (precision && mode == MODE_PASS1) {
         if (ws == 64) snprintf(buf, len, "xcorr_f64_split64_kernel");
-        else if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_kernel<%d>", ws);
+        else if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_tile_kernel<%d>", ws);
         else snprintf(buf, len, "xcorr_generic_kernel<0, double>");
     } else if (ws == 8) {
         snprintf(buf, len, "xcorr_w8_kernel<%d, %s>", mode, (precision && mode != MODE_PASS1) ? "false" : "true");

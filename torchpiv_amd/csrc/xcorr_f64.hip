@@ -619,6 +619,319 @@ static hipError_t launch_f64_split64(const PassParams& p, int n_cu, hipStream_t 
     return hipGetLastError();
 }
 
+// =====================================================================================================
+// 8 ... 32 pixel windows, second generation: lane = one image row of a window, the whole line (WS complex float64
+// samples, frame a in the real part, frame b in the imaginary part) in registers -- the float32 tile kernel's scheme
+// (xcorr_tile.hpp) in float64.  A workgroup is ONE wavefront = 64 / WS windows: no barriers anywhere; LDS only
+// transposes between the row and the column transform, one float64 plane of WS x (WS + 1) per window at a time
+// (32x32: 16.9 KB per wavefront, eight wavefronts per CU = two per SIMD at <= 256 VGPRs), and holds the map for the
+// data-dependent look-ups of the peak analysis.  The last transform is a c2r one (only spectrum columns 0 .. WS/2 cross
+// the LDS the second time); the normalisation is one factor on the map (xcorr_f64_split.hpp, rows_forward).
+// =====================================================================================================
+template <int WS>
+struct F64TileGeo {
+    static constexpr int WPW = 64 / WS;             // windows per wavefront
+    static constexpr int P = WS + 1;                // plane pitch in doubles
+    static constexpr int PLANE = WS * P;            // doubles per window
+    static constexpr int NDW = WS / 4;
+    static constexpr int M = WS / 2;
+};
+
+// 8-value batches of explicit ds_read_b64 (see xcorr_f64_split.hpp: merged ds_read2_b64 pairs run at half rate)
+template <int N, int STRIDE_BYTES, typename F>
+__device__ __forceinline__ void lds_read_seq(unsigned base, F&& sink) {
+    // sink(index, value) for index = 0 .. N-1 at byte offsets index * STRIDE_BYTES
+    constexpr int NB = (N + 7) / 8;
+    double v[2][8];
+    auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
+        constexpr int b_ = decltype(bc)::value;
+        static_for<0, 8>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int i = 8 * b_ + decltype(ic)::value;
+            if constexpr (i < N) v[b_ & 1][decltype(ic)::value] = f64s::lds_rd<i * STRIDE_BYTES>(base);
+            else v[b_ & 1][decltype(ic)::value] = 0.0;
+        });
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
+        constexpr int b_ = decltype(bc)::value;
+        if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
+        constexpr int next = (b_ + 1 < NB) ? ((N - 8 * (b_ + 1)) < 8 ? (N - 8 * (b_ + 1)) : 8) : 0;
+        f64s::lds_wait<next>(v[b_ & 1]);
+        static_for<0, 8>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int i = 8 * b_ + decltype(ic)::value;
+            if constexpr (i < N) sink(std::integral_constant<int, i>{}, v[b_ & 1][decltype(ic)::value]);
+        });
+    });
+}
+
+template <int WS>
+__global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
+    using G = F64TileGeo<WS>;
+    constexpr int P = G::P, M = G::M, NDW = G::NDW, WPW = G::WPW;
+    __shared__ double tile[WPW * G::PLANE];
+
+    const int N = p.n_rows * p.n_cols;
+    const int groups = (N + WPW - 1) / WPW;
+    const long long items = (long long)p.batch * groups;
+    const int st = p.ws - p.ov;
+    const int HW = p.H * p.W;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const long long chunk = (items + 7) / 8;
+    const long long lo = (long long)xcd * chunk;
+    const long long hi = lo + chunk < items ? lo + chunk : items;
+
+    // item -> (pair, window) of this lane; lanes of a window slot past the last window of a pair re-do that last window
+    // (their stores are suppressed)
+    auto geom = [&](long long it, int& pair_, int& win_, bool& active) TPIV_LAMBDA_INLINE {
+        const int w_ = (int)(threadIdx.x / WS);
+        pair_ = (int)(it / groups);
+        const int raw = (int)(it % groups) * WPW + w_;
+        active = raw < N;
+        win_ = active ? raw : N - 1;
+    };
+    uint32_t da[NDW], db[NDW];
+    auto fetch = [&](long long it) TPIV_LAMBDA_INLINE {
+        int pair_, win_;
+        bool act_;
+        geom(it, pair_, win_, act_);
+        const int yy0 = (win_ / p.n_cols) * st, xx0 = (win_ % p.n_cols) * st;
+        const size_t off = (size_t)pair_ * HW + (size_t)(yy0 + (int)(threadIdx.x % WS)) * p.W + xx0;
+        load_dwords<NDW>(p.A + off, da);
+        load_dwords<NDW>(p.B + off, db);
+    };
+    if (lo + slot < hi) fetch(lo + slot);
+    for (long long item = lo + slot; item < hi; item += per_xcd) {
+        int pair, win;
+        bool active;
+        geom(item, pair, win, active);
+        const size_t fidx = (size_t)pair * N + win;
+        const int lane = fresh_lane();
+        const int w = lane / WS, r = lane % WS;
+        double* const pl = tile + w * G::PLANE;          // this window's plane
+
+        // ---- window sums (exact integers), map scale
+        unsigned ia = 0, ib = 0;
+#pragma unroll
+        for (int q = 0; q < NDW; ++q) {
+            ia = __builtin_amdgcn_sad_u8(da[q], 0u, ia);
+            ib = __builtin_amdgcn_sad_u8(db[q], 0u, ib);
+        }
+        {
+            auto uadd = [](unsigned long long a, unsigned long long b) TPIV_LAMBDA_INLINE { return a + b; };
+            const unsigned long long s2 = grp_reduce<WS>((unsigned long long)ia | ((unsigned long long)ib << 32), uadd);
+            ia = (unsigned)s2;
+            ib = (unsigned)(s2 >> 32);
+        }
+        const bool dead = ia == 0u || ib == 0u;
+        const double map_scale = dead ? 0.0 : ((double)(WS * WS) * 0.25) / ((double)ia * (double)ib);
+
+        // ---- rows forward: x[k] = a[k] + i b[k], bin kx at x[FFT_POS<kx>]
+        cd x[WS];
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            x[k] = cd{(double)byte_f<k, NDW>(da), (double)byte_f<k, NDW>(db)};
+        });
+        fft_inreg_d<WS, 1>(x);
+
+        // ---- transposition 1 (one plane at a time): lane (w, kx) gets x[y] = X[y][kx]
+        {
+            const unsigned rd_base = f64s::lds_addr(pl + r);
+            wave_sync();
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                pl[r * P + k] = x[FFT_POS<k, WS>].x;
+            });
+            wave_sync();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double xr[WS];
+            lds_read_seq<WS, P * 8>(rd_base, [&](auto ic, double v) TPIV_LAMBDA_INLINE { xr[decltype(ic)::value] = v; });
+            wave_sync();
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                pl[r * P + k] = x[FFT_POS<k, WS>].y;
+            });
+            wave_sync();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lds_read_seq<WS, P * 8>(rd_base, [&](auto ic, double v) TPIV_LAMBDA_INLINE {
+                constexpr int i = decltype(ic)::value;
+                x[i] = cd{xr[i], v};
+            });
+        }
+        // ---- columns forward: Z(ky, kx = lane) at x[FFT_POS<ky>]
+        fft_inreg_d<WS, 1>(x);
+
+        // ---- cross-spectrum: Z(-ky, -kx) sits in lane (-kx mod WS) of the window, register (-ky mod WS)
+        {
+            const int partner = (lane - r) + ((WS - r) % WS);
+            static_for<0, WS / 2 + 1>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int ky = decltype(kc)::value;
+                constexpr int nky = (WS - ky) % WS;
+                constexpr int p1 = FFT_POS<ky, WS>, p2 = FFT_POS<nky, WS>;
+                cd z1 = x[p1];
+                f64s::pin(z1);
+                if constexpr (ky == nky) {
+                    const cd m1{__shfl(z1.x, partner, 64), __shfl(z1.y, partner, 64)};
+                    x[p1] = f64s::cross_bin(z1, m1);
+                } else {
+                    cd z2 = x[p2];
+                    f64s::pin(z2);
+                    const cd m1{__shfl(z2.x, partner, 64), __shfl(z2.y, partner, 64)};       // Z(-ky, -kx)
+                    const cd m2{__shfl(z1.x, partner, 64), __shfl(z1.y, partner, 64)};       // Z(+ky, -kx)
+                    x[p1] = f64s::cross_bin(z1, m1);
+                    x[p2] = f64s::cross_bin(z2, m2);
+                }
+            });
+        }
+
+        // ---- columns inverse (natural-order input: rename), row y at t[FFT_POS<y>]
+        cd t[WS];
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int ky = decltype(kc)::value;
+            t[ky] = x[FFT_POS<ky, WS>];
+        });
+        fft_inreg_d<WS, -1>(t);
+
+        // ---- transposition 2, half: the map rows are real, so lane (w, y) needs spectrum columns 0 .. WS/2 only
+        cd hs[M + 1];
+        {
+            const unsigned rd_base = f64s::lds_addr(pl + r);
+            cd b[WS];
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                b[k] = t[FFT_POS<k, WS>];
+                asm volatile("" : "+v"(b[k].x), "+v"(b[k].y));       // (keeps the tail of the transform out of the branch)
+            });
+            wave_sync();
+            if (r <= M) {
+                static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    pl[r * P + k] = b[k].x;                            // row kx, column y
+                });
+            }
+            wave_sync();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lds_read_seq<M + 1, P * 8>(rd_base, [&](auto ic, double v) TPIV_LAMBDA_INLINE { hs[decltype(ic)::value].x = v; });
+            wave_sync();
+            if (r <= M) {
+                static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    pl[r * P + k] = b[k].y;
+                });
+            }
+            wave_sync();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lds_read_seq<M + 1, P * 8>(rd_base, [&](auto ic, double v) TPIV_LAMBDA_INLINE { hs[decltype(ic)::value].y = v; });
+            wave_sync();
+        }
+        // ---- rows inverse (c2r): corr(y = r, 2m) + i corr(y, 2m + 1) at hs[FFT_POS<m, M>]
+        c2r_pre_d<WS>(hs);
+        cd z[M];
+        static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
+            constexpr int m = decltype(mc)::value;
+            z[m] = hs[m];
+        });
+        fft_inreg_d<M, -1>(z);
+        double c[WS];                                  // c[x'] in fftshift coordinates
+        static_for<0, WS>([&](auto xc) TPIV_LAMBDA_INLINE {
+            constexpr int xs = decltype(xc)::value;
+            constexpr int xo = (xs + WS / 2) % WS;
+            c[xs] = (xo & 1) ? z[FFT_POS<xo / 2, M>].y : z[FFT_POS<xo / 2, M>].x;
+        });
+
+        // ---- next item's rows fly during the peak analysis (the last iteration re-loads its own)
+        fetch(item + per_xcd < hi ? item + per_xcd : item);
+
+        // ---- peak analysis on the float64 map (B:346-358, B:381-392, B:518)
+        {
+            auto dmin = [](double a_, double b_) TPIV_LAMBDA_INLINE { return f64s::dmin2(a_, b_); };
+            auto dmax = [](double a_, double b_) TPIV_LAMBDA_INLINE { return f64s::dmax2(a_, b_); };
+            auto imin = [](int a_, int b_) TPIV_LAMBDA_INLINE { return a_ < b_ ? a_ : b_; };
+            double cmin = c[0], rraw = c[0];
+#pragma unroll
+            for (int k = 1; k < WS; ++k) {
+                cmin = f64s::dmin2(cmin, c[k]);
+                rraw = f64s::dmax2(rraw, c[k]);
+            }
+            cmin = grp_reduce<WS>(cmin, dmin);
+            const int ys = (r + WS / 2) % WS;
+            wave_sync();
+            static_for<0, WS>([&](auto xc) TPIV_LAMBDA_INLINE {
+                constexpr int xs = decltype(xc)::value;
+                const double v = f64s::peak_shifted(c[xs], cmin, map_scale);
+                c[xs] = v;
+                pl[ys * P + xs] = v;
+            });
+            const double rmax = f64s::peak_shifted(rraw, cmin, map_scale);
+            const double gmax = grp_reduce<WS>(rmax, dmax);
+            const int ywin = grp_reduce<WS>(rmax == gmax ? ys : WS - 1, imin);       // first row holding the maximum
+            wave_sync();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int xwin = grp_reduce<WS>(pl[ywin * P + r] == gmax ? r : WS - 1, imin);   // lane r = column r
+            const int KD = WS * WS;
+            const int m = ywin * WS + xwin;
+            const int wv = p.val_win;
+            // second peak: maximum outside the flat-index exclusion zone (see xcorr_tile.hpp, peak_analysis)
+            double sv;
+            {
+                const int dj = ys - ywin;
+                unsigned ex = 0u;
+                auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
+                    lo_ = lo_ < 0 ? 0 : lo_;
+                    hi_ = hi_ > WS - 1 ? WS - 1 : hi_;
+                    if (lo_ > hi_) return 0u;
+                    const int len = hi_ - lo_ + 1;
+                    const unsigned ones = len >= 32 ? ~0u : ((1u << len) - 1u);
+                    return ones << lo_;
+                };
+                if (dj >= -wv && dj <= wv) ex |= span(xwin - wv, xwin + wv);
+                if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(xwin - wv + WS, xwin + wv + WS);
+                if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(xwin - wv - WS, xwin + wv - WS);
+                if (ys == 0 && (m - wv - wv * WS) <= 0) ex |= 1u;
+                if (ys == WS - 1 && (m + wv + wv * WS) >= KD - 1) ex |= 1u << (WS - 1);
+                sv = -1.0;
+                static_for<0, WS>([&](auto xc) TPIV_LAMBDA_INLINE {
+                    constexpr int xs = decltype(xc)::value;
+                    const int kill = __builtin_amdgcn_sbfe((int)ex, xs, 1);
+                    const double v = __hiloint2double(__double2hiint(c[xs]) | (kill & (int)0x80000000), __double2loint(c[xs]));
+                    sv = f64s::dmax2(sv, v);
+                });
+                sv = grp_reduce<WS>(sv, dmax);
+            }
+            if (r < 8 && active) {
+                int left = m + 1, right = m - 1, top = m + WS, bot = m - WS;      // B:385-392 (flat index)
+                if (left >= KD - 1) left = m;
+                if (right <= 0) right = m;
+                if (top >= KD - 1) top = m;
+                if (bot <= 0) bot = m;
+                int q = m;
+                q = (r == 1) ? left : q;
+                q = (r == 2) ? right : q;
+                q = (r == 3) ? top : q;
+                q = (r == 4) ? bot : q;
+                double outv = pl[(q / WS) * P + (q % WS)];
+                outv = (r == 5) ? (sv >= 0.0 ? sv : 0.0) : outv;
+                outv = (r == 6) ? (double)m : outv;
+                outv = (r == 7) ? (dead ? 1.0 : 0.0) : outv;
+                reinterpret_cast<double*>(p.peak_raw)[fidx * 8 + r] = outv;
+            }
+            wave_sync();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // record look-ups done before the plane is reused
+        }
+    }
+}
+
+template <int WS>
+static hipError_t launch_f64_tile(const PassParams& p, int n_cu, hipStream_t stream) {
+    using G = F64TileGeo<WS>;
+    const long long groups = ((long long)p.n_rows * p.n_cols + G::WPW - 1) / G::WPW;
+    const long long items = (long long)p.batch * groups;
+    if (items <= 0) return hipErrorInvalidValue;
+    long long blocks = items < (long long)n_cu * 8 ? items : (long long)n_cu * 8;       // two wavefronts per SIMD
+    blocks = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((xcorr_f64_tile_kernel<WS>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <int WS>
 hipError_t launch_f64(const PassParams& p, int n_cu, hipStream_t stream) {
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
@@ -632,19 +945,21 @@ hipError_t launch_f64(const PassParams& p, int n_cu, hipStream_t stream) {
 
 }  // namespace
 
+// TPIV_F64_GEN1=1: the first-generation LDS-resident kernel (A/B runs)
+static bool gen1() {
+    static const bool v = [] {
+        const char* e = getenv("TPIV_F64_GEN1");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
 hipError_t launch_xcorr_f64(const PassParams& p, int n_cu, hipStream_t stream) {
     switch (p.ws) {
-        case 8: return launch_f64<8>(p, n_cu, stream);
-        case 16: return launch_f64<16>(p, n_cu, stream);
-        case 32: return launch_f64<32>(p, n_cu, stream);
-        case 64: {
-            // TPIV_F64_GEN1=1: the first-generation LDS-resident kernel (A/B runs)
-            static const bool gen1 = [] {
-                const char* e = getenv("TPIV_F64_GEN1");
-                return e && e[0] == '1';
-            }();
-            return gen1 ? launch_f64<64>(p, n_cu, stream) : launch_f64_split64(p, n_cu, stream);
-        }
+        case 8: return gen1() ? launch_f64<8>(p, n_cu, stream) : launch_f64_tile<8>(p, n_cu, stream);
+        case 16: return gen1() ? launch_f64<16>(p, n_cu, stream) : launch_f64_tile<16>(p, n_cu, stream);
+        case 32: return gen1() ? launch_f64<32>(p, n_cu, stream) : launch_f64_tile<32>(p, n_cu, stream);
+        case 64: return gen1() ? launch_f64<64>(p, n_cu, stream) : launch_f64_split64(p, n_cu, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -66,6 +66,13 @@ __device__ __forceinline__ void lds_wait(double (&v)[8]) {
                  : "n"(LEFT));
 }
 __device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned)(uintptr_t)p; }     // low dword of a flat LDS address
+#elif defined(__HIPCC__)
+// host pass of a HIP translation unit: the kernels' bodies are parsed, never run
+template <int OFF>
+inline double lds_rd(unsigned) { return 0.0; }
+template <int LEFT>
+inline void lds_wait(double (&)[8]) {}
+inline unsigned lds_addr(const double*) { return 0u; }
 #endif
 
 // ---- R: thread (y, h).  da / db: row y of frame a / b (64 bytes each).  The samples go in as they are: the
