@@ -246,9 +246,10 @@ def test_image_decode_follows_opencv_rules(tmp_path):
     assert np.array_equal(tio.imdecode_gray(str(tmp_path / "g8.tif")), g8)
 
 
-def test_f64_split_scheme_on_the_host(tmp_path):
-    """The float64 first pass for 64x64 windows (two threads per line, 32-point codelets, radix-2 steps folded into
-    the transposes; torchpiv_amd/csrc/xcorr_f64_split.hpp) run thread by thread on the CPU by
+@pytest.mark.parametrize("W", [64, 128])
+def test_f64_split_scheme_on_the_host(tmp_path, W):
+    """The float64 first pass for 64x64 / 128x128 windows (two threads per line, 32- / 64-point codelets, radix-2 steps
+    folded into the transposes; torchpiv_amd/csrc/xcorr_f64_split.hpp) run thread by thread on the CPU by
     tests/host/f64_split_harness.cpp -- the very functions the kernel calls, with the LDS plane as an array and a
     barrier as the end of a loop -- against numpy: correlation maps to 1e-13 of their maximum, arg-max, records."""
     import struct
@@ -256,45 +257,46 @@ def test_f64_split_scheme_on_the_host(tmp_path):
     exe = str(tmp_path / "f64h")
     subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host", "f64_split_harness.cpp")],
                    check=True)
-    rng = np.random.default_rng(64)
-    n = 10
-    A = rng.integers(0, 256, size=(n, 64, 64)).astype(np.uint8)
-    B = rng.integers(0, 256, size=(n, 64, 64)).astype(np.uint8)
-    for i in range(3, 7):                                   # particle-like windows with known circular shifts
-        A[i] = ((rng.random((64, 64)) < 0.05) * rng.integers(60, 250, size=(64, 64)) + 8).astype(np.uint8)
-        B[i] = np.roll(A[i], (3 * i - 13, 5 - 2 * i), axis=(0, 1))
-    A[7][:] = 0                                             # zero-mean window: "dead"
-    A[8][:] = 77                                            # constant windows: flat map
-    B[8][:] = 13
-    A[9][:, :32] = 255                                      # saturated half
+    rng = np.random.default_rng(W)
+    n = 10 if W == 64 else 6
+    A = rng.integers(0, 256, size=(n, W, W)).astype(np.uint8)
+    B = rng.integers(0, 256, size=(n, W, W)).astype(np.uint8)
+    shifts = {i: (3 * i - 7, 5 - 2 * i) for i in range(1, 4)}
+    for i, (dy, dx) in shifts.items():                      # particle-like windows with known circular shifts
+        A[i] = ((rng.random((W, W)) < 0.05) * rng.integers(60, 250, size=(W, W)) + 8).astype(np.uint8)
+        B[i] = np.roll(A[i], (dy, dx), axis=(0, 1))
+    A[4][:] = 0                                             # zero-mean window: "dead"
+    A[5][:] = 77                                            # constant windows: flat map
+    B[5][:] = 13
+    A[0][:, :W // 2] = 255                                  # saturated half
     inp = struct.pack("<i", n) + b"".join(A[i].tobytes() + B[i].tobytes() for i in range(n))
-    out = subprocess.run([exe], input=inp, capture_output=True, check=True).stdout
-    d = np.frombuffer(out, dtype=np.float64).reshape(n, 4096 + 8)
+    out = subprocess.run([exe, str(W)], input=inp, capture_output=True, check=True).stdout
+    d = np.frombuffer(out, dtype=np.float64).reshape(n, W * W + 8)
     for i in range(n):
         aa, bb = A[i:i + 1].astype(np.float64), B[i:i + 1].astype(np.float64)
-        rec = d[i, 4096:]
-        if i == 7:
+        rec = d[i, W * W:]
+        if i == 4:
             assert rec[7] == 1.0                            # flagged dead: finalize writes u = v = 0, valid
             continue
         assert rec[7] == 0.0
         aa, bb = aa / aa.mean(), bb / bb.mean()
         c = O.xcorr_fft(aa, bb)[0]
         ref = c - c.min() + 1e-7
-        got = d[i, :4096].reshape(64, 64)
+        got = d[i, :W * W].reshape(W, W)
         assert np.abs(got - ref).max() <= 1e-13 * max(ref.max(), 1.0), i
-        if i == 8:
+        if i == 5:
             assert int(rec[6]) == 0                         # flat map: first flat index
             continue
         m = int(rec[6])
         assert m == int(ref.argmax()) and rec[0] == got.flat[m], i
         flat = ref.reshape(1, -1).copy()
-        m2 = O.second_peak(flat, np.array([m]), 3, 64, 64)[0]
+        m2 = O.second_peak(flat, np.array([m]), 3, W, W)[0]
         assert abs(rec[5] - ref.flat[m2]) <= 1e-13 * ref.max(), i
-        for slot, q in ((1, m + 1), (2, m - 1), (3, m + 64), (4, m - 64)):
-            if 0 < q < 4095:
+        for slot, q in ((1, m + 1), (2, m - 1), (3, m + W), (4, m - W)):
+            if 0 < q < W * W - 1:
                 assert rec[slot] == got.flat[q], (i, slot)
-        if 3 <= i < 7:                                      # the circular shift is found exactly
-            assert (m // 64 - 32, m % 64 - 32) == (3 * i - 13, 5 - 2 * i)
+        if i in shifts:                                     # the circular shift is found exactly
+            assert (m // W - W // 2, m % W - W // 2) == shifts[i]
 
 
 def test_fast_hole_fill_is_the_reference_interpolator_bit_for_bit():

@@ -182,7 +182,7 @@ static int pass_precision(int precision, int mode) {
 const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len) {
     precision = pass_precision(precision, mode);
     if (precision && mode == MODE_PASS1) {
-        if (ws == 64) snprintf(buf, len, "xcorr_f64_split64_kernel");
+        if (ws == 64 || ws == 128) snprintf(buf, len, "xcorr_f64_split_kernel<%d>", ws);
         else if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_tile_kernel<%d>", ws);
         else snprintf(buf, len, "xcorr_generic_kernel<0, double>");
     } else if (ws == 8) {
@@ -216,7 +216,12 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
     if (mode == MODE_CWSF) {
         e = generic();
     } else if (f64) {
-        e = tile_size(p.ws) ? launch_xcorr_f64(p, n_cu, stream) : generic();
+        // (TPIV_F64_GENERIC128=1: the generic-size DFT kernel for 128x128, as before the split kernel existed -- A/B runs)
+        static const bool gen128 = [] {
+            const char* env = getenv("TPIV_F64_GENERIC128");
+            return env && env[0] == '1';
+        }();
+        e = (tile_size(p.ws) || (p.ws == 128 && !gen128)) ? launch_xcorr_f64(p, n_cu, stream) : generic();
     } else if (tile_size(p.ws)) {       // per-XCD work queue of the tile kernel: counters behind the peak records
         p.work_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.peak_raw) +
                                                  work_ctr_offset(p.batch, p.n_rows * p.n_cols));

@@ -427,15 +427,26 @@ __global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_ker
 // kept the 16-byte elements in LDS and walked radix-8 stages over them: 35 ms per 256 pairs at 43 % LDS bank
 // conflicts and ~25 barriers per window (profiles/r02); it still serves 8 ... 32 pixel windows.
 // =====================================================================================================
+template <int W>
 struct F64SplitShared {
-    double plane[f64s::WS * f64s::PL];
-    double redd[8];
+    double plane[W * (W + 1)];
+    double redd[16];
+    unsigned long long redu[4];
     int redi[4];
 };
 
-__global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p) {
-    using namespace f64s;
-    __shared__ F64SplitShared sm;
+// W = 64: 128 threads (two wavefronts: wavefront = half of every line), 33 KB, four workgroups per CU, <= 256 VGPRs.
+// W = 128: 256 threads (wavefronts 0-1 = first halves of lines 0..63 / 64..127, wavefronts 2-3 = second halves), 132 KB:
+//          one workgroup per CU and one wavefront per SIMD with up to 512 registers (64-point codelets hold 256).
+template <int W>
+__global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel(PassParams p) {
+    using S = f64s::Split<W>;
+    using f64s::dmax2;
+    using f64s::dmin2;
+    using f64s::peak_shifted;
+    constexpr int M = S::M, PL = S::PL, NDW = S::NDW, NWV = 2 * W / 64;      // wavefronts per workgroup
+    constexpr int LB = W == 64 ? 6 : 7;                                          // log2 W: line = t & (W - 1), half = t >> LB
+    __shared__ F64SplitShared<W> sm;
     double* const plane = sm.plane;
     const int tid = threadIdx.x;
 
@@ -449,15 +460,26 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
     const long long lo = (long long)xcd * chunk;
     const long long hi = lo + chunk < items ? lo + chunk : items;
 
-    // both threads of a line load the whole image row (64 bytes per frame); the next window's rows are fetched
-    // while the peak analysis of the current one runs
+    // both threads of a line load the whole image row; the next window's rows are fetched while the peak analysis of
+    // the current one runs
     uint32_t da[NDW], db[NDW];
     auto fetch = [&](long long it) TPIV_LAMBDA_INLINE {
         const int pair_ = (int)(it / N), win_ = (int)(it % N);
         const int yy0 = (win_ / p.n_cols) * st, xx0 = (win_ % p.n_cols) * st;
-        const size_t off = (size_t)pair_ * HW + (size_t)(yy0 + (tid & 63)) * p.W + xx0;
+        const size_t off = (size_t)pair_ * HW + (size_t)(yy0 + (tid & (W - 1))) * p.W + xx0;
         load_dwords<NDW>(p.A + off, da);
         load_dwords<NDW>(p.B + off, db);
+    };
+    // exchange between the wavefronts of the workgroup, ONE barrier: every exchange has its own LDS slots (re-used a
+    // window later, many barriers on)
+    auto exchange = [&](auto v, auto op, auto* slots) TPIV_LAMBDA_INLINE {
+        v = grp_reduce<64>(v, op);
+        if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = v;
+        lds_barrier();
+        auto r = slots[0];
+#pragma unroll
+        for (int w_ = 1; w_ < NWV; ++w_) r = op(r, slots[w_]);
+        return r;
     };
     if (lo + slot < hi) fetch(lo + slot);
     TPIV_STAMP_DECL
@@ -467,9 +489,10 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         ++st_iter;
 #endif
         // (lane-derived values are re-made from an opaque copy of the thread index at every phase, so that the
-        //  32 + 32 + 66 loop-invariant LDS addresses are not hoisted out of the item loop into registers)
+        //  loop-invariant LDS addresses are not hoisted out of the item loop into registers)
 #define TPIV_F64_TID() [&]() TPIV_LAMBDA_INLINE { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; }()
-        // ---- window sums: every wavefront holds all 64 rows -> no cross-wave exchange; exact integers
+        // ---- window sums: exact integers.  64x64: every wavefront holds all 64 rows (no exchange); 128x128: the rows of
+        //      wavefronts 0 and 1 together
         unsigned ia = 0, ib = 0;
 #pragma unroll
         for (int q = 0; q < NDW; ++q) {
@@ -478,19 +501,24 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         }
         {
             auto uadd = [](unsigned long long a, unsigned long long b) TPIV_LAMBDA_INLINE { return a + b; };
-            const unsigned long long s2 = grp_reduce<64>((unsigned long long)ia | ((unsigned long long)ib << 32), uadd);
+            unsigned long long s2 = grp_reduce<64>((unsigned long long)ia | ((unsigned long long)ib << 32), uadd);
+            if constexpr (W == 128) {
+                if ((threadIdx.x & 63) == 0) sm.redu[threadIdx.x >> 6] = s2;
+                lds_barrier();
+                s2 = sm.redu[0] + sm.redu[1];
+            }
             ia = (unsigned)s2;
             ib = (unsigned)(s2 >> 32);
         }
         const bool dead = ia == 0u || ib == 0u;          // zero-mean window: 0/0 = NaN map in the reference
         // a / mean(a), b / mean(b) (B:513-514) as ONE factor on the correlation map (xcorr_f64_split.hpp, rows_forward):
         // n^2 / sum(a) * n^2 / sum(b), times 1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra;
-        // sum(a) sum(b) < 2^42 is exact, so this is one correctly rounded division per window
-        const double map_scale = dead ? 0.0 : ((double)(WS * WS) * 0.25) / ((double)ia * (double)ib);
+        // sum(a) sum(b) < 2^44 is exact, so this is one correctly rounded division per window
+        const double map_scale = dead ? 0.0 : ((double)(W * W) * 0.25) / ((double)ia * (double)ib);
 
         // ---- R: rows forward
         cd x[M];
-        rows_forward(da, db, TPIV_F64_TID() >> 6, x);
+        S::rows_forward(da, db, TPIV_F64_TID() >> LB, x);
         TPIV_STAMP(0);      // window sums, rows forward
 
         // ---- T1 + C: transposition with the DIF step of the column transform, columns forward
@@ -498,71 +526,96 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
         lds_barrier();                               // plane free (the previous window's record reads)
         {
             const int t_ = TPIV_F64_TID();
-            t1_write<0>(x, t_ & 63, t_ >> 6, plane);
+            S::template t1_write<0>(x, t_ & (W - 1), t_ >> LB, plane);
         }
         lds_barrier();
         {
             const int t_ = TPIV_F64_TID();
-            t1_read<0>(u, t_ & 63, 1 - (t_ >> 6), plane);
+            S::template t1_read<0>(u, t_ & (W - 1), 1 - (t_ >> LB), plane);
         }
         lds_barrier();
         {
             const int t_ = TPIV_F64_TID();
-            t1_write<1>(x, t_ & 63, t_ >> 6, plane);
+            S::template t1_write<1>(x, t_ & (W - 1), t_ >> LB, plane);
         }
         lds_barrier();
         {
             const int t_ = TPIV_F64_TID();
-            t1_read<1>(u, t_ & 63, 1 - (t_ >> 6), plane);
+            S::template t1_read<1>(u, t_ & (W - 1), 1 - (t_ >> LB), plane);
         }
         TPIV_STAMP(1);      // transposition 1 (4 barriers)
-        const int g = 1 - (TPIV_F64_TID() >> 6);     // parity of the column bins this thread owns (wave-uniform)
-        cols_forward(u, g);
+        const int g = 1 - (TPIV_F64_TID() >> LB);    // parity of the column bins this thread owns (wave-uniform)
+        S::cols_forward(u, g);
         TPIV_STAMP(2);      // columns forward
 
-        // ---- X: cross-spectrum; the mirrored bin sits in lane (64 - k) % 64 of the same wavefront
-        {
+        // ---- X: cross-spectrum
+        if constexpr (W == 64) {
+            // the mirrored bin sits in lane (64 - k) % 64 of the same wavefront
             const int partner = (64 - (TPIV_F64_TID() & 63)) & 63;
             auto sh = [](double v, int, int, int pt) TPIV_LAMBDA_INLINE { return __shfl(v, pt, 64); };
-            if (g == 0) cross_spectrum_g<0>(u, partner, sh);
-            else cross_spectrum_g<1>(u, partner, sh);
+            if (g == 0) S::template cross_spectrum_g<0>(u, partner, sh);
+            else S::template cross_spectrum_g<1>(u, partner, sh);
+        } else {
+            // the mirrored column lives in another wavefront: through the plane, one component at a time
+            double mre[M];
+            lds_barrier();                           // every thread has read its T1 column
+            {
+                const int t_ = TPIV_F64_TID();
+                S::template cross_write<0>(u, t_ & (W - 1), 1 - (t_ >> LB), plane);
+            }
+            lds_barrier();
+            {
+                const int t_ = TPIV_F64_TID();
+                S::cross_read(mre, t_ & (W - 1), 1 - (t_ >> LB), plane);
+            }
+            lds_barrier();
+            {
+                const int t_ = TPIV_F64_TID();
+                S::template cross_write<1>(u, t_ & (W - 1), 1 - (t_ >> LB), plane);
+            }
+            lds_barrier();
+            double mim[M];
+            {
+                const int t_ = TPIV_F64_TID();
+                S::cross_read(mim, t_ & (W - 1), 1 - (t_ >> LB), plane);
+            }
+            S::cross_finish(u, mre, mim);
         }
 
-        TPIV_STAMP(3);      // cross-spectrum incl. the bpermute exchange
+        TPIV_STAMP(3);      // cross-spectrum incl. the exchange
         // ---- Ci + T2: columns inverse, transposition with the DIT step
         cd t[M];
-        cols_inverse(u, g, t);
+        S::cols_inverse(u, g, t);
         TPIV_STAMP(4);      // columns inverse
         cd Y[M + 1];
-        lds_barrier();                               // every thread has read its T1 column
+        lds_barrier();                               // every thread has read what it needs from the plane
         {
             const int t_ = TPIV_F64_TID();
-            t2_write<0>(t, t_ & 63, 1 - (t_ >> 6), plane);
+            S::template t2_write<0>(t, t_ & (W - 1), 1 - (t_ >> LB), plane);
         }
         lds_barrier();
-        t2_read<0>(Y, TPIV_F64_TID() & 63, plane);
+        S::template t2_read<0>(Y, TPIV_F64_TID() & (W - 1), plane);
         lds_barrier();
         {
             const int t_ = TPIV_F64_TID();
-            t2_write<1>(t, t_ & 63, 1 - (t_ >> 6), plane);
+            S::template t2_write<1>(t, t_ & (W - 1), 1 - (t_ >> LB), plane);
         }
         lds_barrier();
-        t2_read<1>(Y, TPIV_F64_TID() & 63, plane);
+        S::template t2_read<1>(Y, TPIV_F64_TID() & (W - 1), plane);
 
         TPIV_STAMP(5);      // transposition 2 (4 barriers)
         // ---- Ri: rows inverse (c2r over the thread pair)
         double c[M];
-        rows_inverse(Y, TPIV_F64_TID() >> 6, c);
+        S::rows_inverse(Y, TPIV_F64_TID() >> LB, c);
         TPIV_STAMP(6);      // rows inverse
 
-        // ---- P: peak analysis on the float64 map.  Three exchanges between the two wavefronts, ONE barrier each (every
-        //      exchange has its own LDS slots, re-used a window later): (min, raw max) -> map -> first row of the maximum
-        //      -> second peak.
+        // ---- P: peak analysis on the float64 map.  Three exchanges between the wavefronts, ONE barrier each:
+        //      (min, raw max) -> map -> first row of the maximum -> second peak.
         auto dmin = [](double a, double b) TPIV_LAMBDA_INLINE { return dmin2(a, b); };
         auto dmax = [](double a, double b) TPIV_LAMBDA_INLINE { return dmax2(a, b); };
         auto imin = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
         double cmin, rraw;
-        peak_local_minmax(c, cmin, rraw);
+        S::peak_local_minmax(c, cmin, rraw);
         // prefetch: the last iteration re-loads its own window (no branch around the loads)
         fetch(item + per_xcd < hi ? item + per_xcd : item);
         {
@@ -570,52 +623,62 @@ __global__ __launch_bounds__(128, 2) void xcorr_f64_split64_kernel(PassParams p)
             const int t_ = TPIV_F64_TID();
             if ((t_ & 63) == 0) {
                 sm.redd[t_ >> 6] = mn;
-                sm.redd[2 + (t_ >> 6)] = mx;
+                sm.redd[4 + (t_ >> 6)] = mx;
             }
             lds_barrier();                            // (also: every thread has read its T2 row -> the map may be written)
-            cmin = dmin2(sm.redd[0], sm.redd[1]);
         }
-        const double gmax = peak_shifted(dmax2(sm.redd[2], sm.redd[3]), cmin, map_scale);
+        double graw = sm.redd[4];
+        cmin = sm.redd[0];
+#pragma unroll
+        for (int w_ = 1; w_ < NWV; ++w_) {
+            cmin = dmin2(cmin, sm.redd[w_]);
+            graw = dmax2(graw, sm.redd[4 + w_]);
+        }
+        // the maximum of the shifted map is the shifted raw maximum (monotonic, same roundings)
+        const double gmax = peak_shifted(graw, cmin, map_scale);
         {
             const int t_ = TPIV_F64_TID();
-            peak_shift_and_write(c, cmin, map_scale, t_ & 63, t_ >> 6, plane);
+            S::peak_shift_and_write(c, cmin, map_scale, t_ & (W - 1), t_ >> LB, plane);
         }
         // arg-max = FIRST flat index holding the maximum (B:383): the smallest shifted row whose maximum is the global
-        // one, then the first column of that row -- lane = column, one LDS read and a ballot (both wavefronts do it: same
+        // one, then the first column of that row -- lane = column, LDS reads and ballots (every wavefront does it: same
         // row, same result, no exchange)
         int ywin;
         {
             const int t_ = TPIV_F64_TID();
-            const int fy = ((t_ & 63) + WS / 2) & (WS - 1);
-            const int yw = grp_reduce<64>(peak_shifted(rraw, cmin, map_scale) == gmax ? fy : WS - 1, imin);
-            if ((t_ & 63) == 0) sm.redi[t_ >> 6] = yw;
-            lds_barrier();                            // (also: map complete)
-            ywin = imin(sm.redi[0], sm.redi[1]);
+            const int fy = ((t_ & (W - 1)) + W / 2) & (W - 1);
+            ywin = exchange(peak_shifted(rraw, cmin, map_scale) == gmax ? fy : W - 1, imin, sm.redi);      // (also: map complete)
         }
-        const unsigned long long hit = __ballot(plane[ywin * PL + (TPIV_F64_TID() & 63)] == gmax);
-        const int xwin = hit ? (int)__builtin_ctzll(hit) : WS - 1;
-        const int m = ywin * WS + xwin;
+        int xwin = W - 1;
+        {
+            const int l_ = TPIV_F64_TID() & 63;
+#pragma unroll
+            for (int part = W / 64 - 1; part >= 0; --part) {
+                const unsigned long long hit = __ballot(plane[ywin * PL + 64 * part + l_] == gmax);
+                xwin = hit ? 64 * part + (int)__builtin_ctzll(hit) : xwin;
+            }
+        }
+        const int m = ywin * W + xwin;
         double sv;
         {
             const int t_ = TPIV_F64_TID();
-            sv = grp_reduce<64>(peak_second_local(c, t_ & 63, t_ >> 6, m, p.val_win), dmax);
-            if ((t_ & 63) == 0) sm.redd[4 + (t_ >> 6)] = sv;
-            lds_barrier();
-            sv = dmax2(sm.redd[4], sm.redd[5]);
+            sv = exchange(S::peak_second_local(c, t_ & (W - 1), t_ >> LB, m, p.val_win), dmax, sm.redd + 8);
         }
-        if (tid < 8) reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + tid] = peak_record_slot(tid, m, sv, dead, plane);
+        if (tid < 8) reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + tid] = S::peak_record_slot(tid, m, sv, dead, plane);
         TPIV_STAMP(7);      // peak analysis incl. the issue of the next window's loads
 #undef TPIV_F64_TID
     }
     TPIV_STAMP_FLUSH(p);
 }
 
-static hipError_t launch_f64_split64(const PassParams& p, int n_cu, hipStream_t stream) {
+template <int W>
+static hipError_t launch_f64_split(const PassParams& p, int n_cu, hipStream_t stream) {
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
     if (items <= 0) return hipErrorInvalidValue;
-    long long blocks = items < (long long)n_cu * 4 ? items : (long long)n_cu * 4;       // LDS: 33.4 KB per workgroup
+    const int per_cu = W == 64 ? 4 : 1;              // LDS: 33.4 KB / 132.3 KB per workgroup
+    long long blocks = items < (long long)n_cu * per_cu ? items : (long long)n_cu * per_cu;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(xcorr_f64_split64_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, p);
+    hipLaunchKernelGGL((xcorr_f64_split_kernel<W>), dim3((unsigned)blocks), dim3(2 * W), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -959,7 +1022,8 @@ hipError_t launch_xcorr_f64(const PassParams& p, int n_cu, hipStream_t stream) {
         case 8: return gen1() ? launch_f64<8>(p, n_cu, stream) : launch_f64_tile<8>(p, n_cu, stream);
         case 16: return gen1() ? launch_f64<16>(p, n_cu, stream) : launch_f64_tile<16>(p, n_cu, stream);
         case 32: return gen1() ? launch_f64<32>(p, n_cu, stream) : launch_f64_tile<32>(p, n_cu, stream);
-        case 64: return gen1() ? launch_f64<64>(p, n_cu, stream) : launch_f64_split64(p, n_cu, stream);
+        case 64: return gen1() ? launch_f64<64>(p, n_cu, stream) : launch_f64_split<64>(p, n_cu, stream);
+        case 128: return launch_f64_split<128>(p, n_cu, stream);
         default: return hipErrorInvalidValue;
     }
 }

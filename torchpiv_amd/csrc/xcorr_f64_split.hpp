@@ -1,4 +1,4 @@
-// Per-thread arithmetic of the float64 first pass for 64x64 windows (xcorr_f64.hip), written as host/device
+// Per-thread arithmetic of the float64 first pass for 64x64 and 128x128 windows (xcorr_f64.hip), written as host/device
 // functions so that the CPU suite can run the WHOLE scheme -- index maps, splits, partner bins, combines --
 // thread by thread against numpy (tests/host/f64_split_harness.cpp, tests/test_host_logic.py).
 //
@@ -28,6 +28,11 @@
 //
 // The odd halves carry 30 twiddle products per stage; the parities are assigned so that wave 0 takes them in the
 // column stages and wave 1 in the row stages.
+//
+// 128x128 windows run the same scheme with 64-point codelets (Split<128>: 256 threads, line = t % 128, half = t / 128;
+// one 132 KB plane, i.e. one workgroup per CU and up to 512 registers per thread).  There the two halves of a line and
+// the mirrored column -k live in different wavefronts, so the cross-spectrum fetches Z(-ky, -k) through the plane
+// (cross_write / cross_read) instead of ds_bpermute.  The text above gives the numbers of the 64x64 case.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -37,12 +42,7 @@
 namespace tpiv {
 namespace f64s {
 
-constexpr int WS = 64;          // window edge
-constexpr int M = 32;           // codelet length
-constexpr int PL = 65;          // plane pitch in doubles: conflict-free ds_read_b64 / ds_write_b64 along rows and columns
-constexpr int NDW = WS / 4;     // dwords per window row
-
-template <int K>
+template <int K, int NDW>
 TPIV_HD float byte_of(const uint32_t (&d)[NDW]) {
     return (float)((d[K >> 2] >> (8 * (K & 3))) & 0xffu);
 }
@@ -55,7 +55,12 @@ TPIV_HD float byte_of(const uint32_t (&d)[NDW]) {
 template <int OFF>
 __device__ __forceinline__ double lds_rd(unsigned addr) {
     double v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    if constexpr (OFF < 65536) {
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    } else {                  // the offset field has 16 bits (the 128x128 plane is 132 KB): second base, shared by the reads
+        const unsigned hi = addr + (unsigned)(OFF & ~0xffff);
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(hi), "n"(OFF & 0xffff));
+    }
     return v;
 }
 // wait until at most LEFT LDS operations are outstanding; the eight values become usable only behind it
@@ -75,90 +80,8 @@ inline void lds_wait(double (&)[8]) {}
 inline unsigned lds_addr(const double*) { return 0u; }
 #endif
 
-// ---- R: thread (y, h).  da / db: row y of frame a / b (64 bytes each).  The samples go in as they are: the
-// normalisation a / mean(a), b / mean(b) of B:513-514 is linear, so it is ONE factor 1 / (mean(a) mean(b)) on the whole
-// correlation map, applied where the map is shifted by its minimum (peak_shifted) -- 64 multiplies per thread and one of
-// two divisions per window less, at rounding-level differences (1e-16 relative) from scaling every sample first.
-TPIV_HD void rows_forward(const uint32_t (&da)[NDW], const uint32_t (&db)[NDW], int h, cd (&x)[M]) {
-    const float sg = h ? -1.0f : 1.0f;
-    static_for<0, M>([&](auto jc) TPIV_LAMBDA_INLINE {
-        constexpr int j = decltype(jc)::value;
-        // sums / differences of two bytes: exact in float32, converted once
-        const float sa = byte_of<j>(da) + sg * byte_of<j + M>(da);
-        const float sb = byte_of<j>(db) + sg * byte_of<j + M>(db);
-        x[j] = cd{(double)sa, (double)sb};
-    });
-    if (h) {
-        static_for<1, M>([&](auto jc) TPIV_LAMBDA_INLINE {
-            constexpr int j = decltype(jc)::value;
-            x[j] = twmul_d<j, WS, 1>(x[j]);
-        });
-    }
-    fft_inreg_d<M, 1>(x);          // X[y][2m + h] at x[FFT_POS<m, M>]
-}
-
-// ---- T1 write: component COMP (0 = real, 1 = imaginary) of X[y][2m + h]
-template <int COMP>
-TPIV_HD void t1_write(const cd (&x)[M], int y, int h, double* plane) {
-    double* row = plane + y * PL + h;
-    static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
-        constexpr int m = decltype(mc)::value;
-        row[2 * m] = COMP ? x[FFT_POS<m, M>].y : x[FFT_POS<m, M>].x;
-    });
-}
-// ---- T1 read: thread (k, g): u[i] = X[i][k] +- X[i + 32][k]
-template <int COMP>
-TPIV_HD void t1_read(cd (&u)[M], int k, int g, const double* plane) {
-    const double sg = g ? -1.0 : 1.0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned base = lds_addr(plane + k);
-    constexpr int NB = M / 4;                                   // batches of 4 rows i = 8 reads
-    double v[2][8];
-    auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
-        constexpr int b_ = decltype(bc)::value;
-        static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
-            constexpr int i = 4 * b_ + decltype(ic)::value;
-            v[b_ & 1][2 * decltype(ic)::value] = lds_rd<i * PL * 8>(base);
-            v[b_ & 1][2 * decltype(ic)::value + 1] = lds_rd<(i + M) * PL * 8>(base);
-        });
-    };
-    issue(std::integral_constant<int, 0>{});
-    static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
-        constexpr int b_ = decltype(bc)::value;
-        if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
-        lds_wait<(b_ + 1 < NB) ? 8 : 0>(v[b_ & 1]);
-        static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
-            constexpr int q = decltype(ic)::value, i = 4 * b_ + q;
-            const double r = v[b_ & 1][2 * q] + sg * v[b_ & 1][2 * q + 1];
-            if constexpr (COMP) u[i].y = r;
-            else u[i].x = r;
-        });
-    });
-#else
-    const double* col = plane + k;
-    for (int i = 0; i < M; ++i) {
-        const double r = col[i * PL] + sg * col[(i + M) * PL];
-        if (COMP) u[i].y = r;
-        else u[i].x = r;
-    }
-#endif
-}
-// ---- C: the odd half's twiddles, then the codelet: Z[2m + g][k] at u[FFT_POS<m, M>]
-TPIV_HD void cols_forward(cd (&u)[M], int g) {
-    if (g) {
-        static_for<1, M>([&](auto ic) TPIV_LAMBDA_INLINE {
-            constexpr int i = decltype(ic)::value;
-            u[i] = twmul_d<i, WS, 1>(u[i]);
-        });
-    }
-    fft_inreg_d<M, 1>(u);
-}
-
-// ---- X: cross-spectrum in place.  With Z(k) = a + ib, Z(-k) = c + id:  4 P(k) = 2 (a d + b c) + i ((c^2 - a^2) + (d^2 - b^2))
-// (the factor 0.25 / n^2 rides in the map scale, peak_shifted).  sh(value, reg, partner) returns the PARTNER thread's value of register `reg`
-// (device: ds_bpermute of `value`; the host harness looks the register up).
 // (device: an empty asm on a value keeps computations that depend on it where they are written -- left alone, the
-//  compiler hoists the squares a^2, b^2 of ALL bins out of both parity branches and spills 48 of them)
+//  compiler hoists the squares a^2, b^2 of ALL bins out of both parity branches of the cross-spectrum and spills 48 of them)
 TPIV_HD void pin(cd& z) {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(z.x), "+v"(z.y));
@@ -166,133 +89,12 @@ TPIV_HD void pin(cd& z) {
     (void)z;
 #endif
 }
+// cross-spectrum of one bin.  With Z(k) = a + ib, Z(-k) = c + id:  4 P(k) = 2 (a d + b c) + i ((c^2 - a^2) + (d^2 - b^2))
+// (P = conj(A) B of the packed transform; the factor 0.25 / n^2 rides in the map scale, peak_shifted)
 TPIV_HD cd cross_bin(cd zk, cd zm) {
     const double a_ = zk.x, b_ = zk.y, c_ = zm.x, d_ = zm.y;
     return cd{(a_ * d_ + b_ * c_) * 2.0, (c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_)};
 }
-template <int G, typename SH>
-TPIV_HD void cross_spectrum_g(cd (&z)[M], int partner, SH&& sh) {
-    // bin ky = 2m + G sits at z[FFT_POS<m>]; its mirror -ky = 2 m' + G with m' = (32 - m) % 32 (G = 0), 31 - m (G = 1)
-    constexpr int NPAIR = G ? M / 2 : M / 2 + 1;
-    static_for<0, NPAIR>([&](auto mc) TPIV_LAMBDA_INLINE {
-        constexpr int m = decltype(mc)::value;
-        constexpr int m2 = G ? M - 1 - m : (M - m) % M;
-        constexpr int p1 = FFT_POS<m, M>, p2 = FFT_POS<m2, M>;
-        cd z1 = z[p1];
-        pin(z1);
-        if constexpr (m == m2) {
-            const cd m1{sh(z1.x, p1, 0, partner), sh(z1.y, p1, 1, partner)};
-            z[p1] = cross_bin(z1, m1);
-        } else {
-            cd z2 = z[p2];
-            pin(z2);
-            const cd m1{sh(z2.x, p2, 0, partner), sh(z2.y, p2, 1, partner)};      // Z(-ky, -k)
-            const cd m2v{sh(z1.x, p1, 0, partner), sh(z1.y, p1, 1, partner)};     // Z(+ky, -k): the mirror of bin -ky
-            z[p1] = cross_bin(z1, m1);
-            z[p2] = cross_bin(z2, m2v);
-        }
-#if defined(__HIP_DEVICE_COMPILE__)
-        // keep the exchange of a bin pair together: hoisted ahead, the 8 permutes of every pair hold their results
-        // in registers next to the 128 of the spectrum
-        if constexpr (m % 2 == 1) __builtin_amdgcn_sched_barrier(0);
-#endif
-    });
-}
-
-// ---- Ci: natural-order rename, inverse codelet, decimation-in-time twiddle of the odd half: G_g[y1] at t[FFT_POS<y1, M>]
-TPIV_HD void cols_inverse(const cd (&z)[M], int g, cd (&t)[M]) {
-    static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
-        constexpr int m = decltype(mc)::value;
-        t[m] = z[FFT_POS<m, M>];
-    });
-    fft_inreg_d<M, -1>(t);
-    if (g) {
-        static_for<1, M>([&](auto yc) TPIV_LAMBDA_INLINE {
-            constexpr int y1 = decltype(yc)::value;
-            t[FFT_POS<y1, M>] = twmul_d<y1, WS, -1>(t[FFT_POS<y1, M>]);
-        });
-    }
-}
-// ---- T2 write: thread (k, g): plane[32 g + y1][k] <- G_g[y1][k]
-template <int COMP>
-TPIV_HD void t2_write(const cd (&t)[M], int k, int g, double* plane) {
-    double* col = plane + (M * g) * PL + k;
-    static_for<0, M>([&](auto yc) TPIV_LAMBDA_INLINE {
-        constexpr int y1 = decltype(yc)::value;
-        col[y1 * PL] = COMP ? t[FFT_POS<y1, M>].y : t[FFT_POS<y1, M>].x;
-    });
-}
-// ---- T2 read: thread (y, q): Y[kx] = G_0[y % 32][kx] +- G_1[y % 32][kx], kx = 0..32
-template <int COMP>
-TPIV_HD void t2_read(cd (&Y)[M + 1], int y, const double* plane) {
-    const double sg = y < M ? 1.0 : -1.0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned base = lds_addr(plane + (y & (M - 1)) * PL);
-    constexpr int NB = M / 4 + 1;                               // 8 batches of 4 columns + column 32
-    double v[2][8];
-    auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
-        constexpr int b_ = decltype(bc)::value;
-        static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
-            constexpr int kx = 4 * b_ + decltype(ic)::value;
-            if constexpr (kx <= M) {
-                v[b_ & 1][2 * decltype(ic)::value] = lds_rd<kx * 8>(base);
-                v[b_ & 1][2 * decltype(ic)::value + 1] = lds_rd<(M * PL + kx) * 8>(base);
-            }
-        });
-    };
-    issue(std::integral_constant<int, 0>{});
-    static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
-        constexpr int b_ = decltype(bc)::value;
-        if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
-        // outstanding behind this batch: the next one (8 reads, the last batch holds 2)
-        lds_wait<(b_ + 1 < NB) ? (b_ + 2 == NB ? 2 : 8) : 0>(v[b_ & 1]);
-        static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
-            constexpr int q = decltype(ic)::value, kx = 4 * b_ + q;
-            if constexpr (kx <= M) {
-                const double r = v[b_ & 1][2 * q] + sg * v[b_ & 1][2 * q + 1];
-                if constexpr (COMP) Y[kx].y = r;
-                else Y[kx].x = r;
-            }
-        });
-    });
-#else
-    const double* r0 = plane + (y & (M - 1)) * PL;
-    const double* r1 = r0 + M * PL;
-    for (int kx = 0; kx <= M; ++kx) {
-        const double r = r0[kx] + sg * r1[kx];
-        if (COMP) Y[kx].y = r;
-        else Y[kx].x = r;
-    }
-#endif
-}
-// ---- Ri: c2r pre-processing (both threads of the pair), DIF halves of the 32 packed values, 16-point inverse codelet.
-// Out: c[2n + e] = corr[y][4n + 2q + e], n = 0..15, e = 0, 1 (un-shifted column index).
-TPIV_HD void rows_inverse(cd (&Y)[M + 1], int q, double (&c)[M]) {
-    c2r_pre_d<WS>(Y);                       // h[0..32) in Y[0..32)
-    cd e[M / 2];
-    const double sq = q ? -1.0 : 1.0;
-    static_for<0, M / 2>([&](auto jc) TPIV_LAMBDA_INLINE {
-        constexpr int j = decltype(jc)::value;
-        e[j] = cd{Y[j].x + sq * Y[j + M / 2].x, Y[j].y + sq * Y[j + M / 2].y};
-    });
-    if (q) {
-        static_for<1, M / 2>([&](auto jc) TPIV_LAMBDA_INLINE {
-            constexpr int j = decltype(jc)::value;
-            e[j] = twmul_d<j, M, -1>(e[j]);
-        });
-    }
-    fft_inreg_d<M / 2, -1>(e);              // z[2n + q] at e[FFT_POS<n, 16>]
-    static_for<0, M / 2>([&](auto nc) TPIV_LAMBDA_INLINE {
-        constexpr int n = decltype(nc)::value;
-        c[2 * n] = e[FFT_POS<n, M / 2>].x;
-        c[2 * n + 1] = e[FFT_POS<n, M / 2>].y;
-    });
-}
-
-// ---- P: peak analysis in fftshift coordinates (y' = (y + 32) % 64, x' likewise).  Thread (y, q) holds
-// c[2n + e] = corr[y][x = 4n + 2q + e].
-TPIV_HD int col_of(int n, int e, int q) { return 4 * n + 2 * q + e; }
-
 // min / max of two finite doubles as ONE instruction (fmin / fmax are compiled to v_min_f64 / v_max_f64 plus a
 // canonicalising v_max_f64 x, x per operand -- sNaN quieting the map values never need: 100 float64 instructions per window)
 TPIV_HD double dmin2(double a, double b) {
@@ -313,17 +115,6 @@ TPIV_HD double dmax2(double a, double b) {
     return a > b ? a : b;
 #endif
 }
-// one pass over the raw cells gives their minimum AND their maximum: v = (c - min) + 1e-7 is monotonic in c, so the
-// maximum of the shifted cells is the shifted maximum (exactly: the same two roundings)
-TPIV_HD void peak_local_minmax(const double (&c)[M], double& mn, double& mx) {
-    mn = c[0];
-    mx = c[0];
-#pragma unroll
-    for (int i = 1; i < M; ++i) {
-        mn = dmin2(mn, c[i]);
-        mx = dmax2(mx, c[i]);
-    }
-}
 // (corr - min) + 1e-7 of B:518 / B:381 on the normalised map: `scale` = 1 / (mean(a) mean(b)) times the constant factors of
 // the transforms (rows_forward)
 TPIV_HD double peak_shifted(double c, double cmin, double scale) {
@@ -333,81 +124,358 @@ TPIV_HD double peak_shifted(double c, double cmin, double scale) {
     return (c - cmin) * scale + 1e-7;
 #endif
 }
-// v = (c - min) + 1e-7, written to the map (plane, shifted coordinates).  (No index is tracked: the arg-max position
-// comes from the map afterwards -- first the smallest row whose maximum is the global one, then the first column of that
-// row -- which keeps the scan free of compare / select chains.)
-TPIV_HD void peak_shift_and_write(double (&c)[M], double cmin, double scale, int y, int q, double* plane) {
-    const int fy = (y + WS / 2) & (WS - 1);
-    double* row = plane + fy * PL + 2 * q;
-    static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
-        constexpr int i = decltype(ic)::value;
-        constexpr int fx0 = (4 * (i >> 1) + (i & 1) + WS / 2) & (WS - 1);       // + 2 q: stays inside its group of four
-        const double v = peak_shifted(c[i], cmin, scale);
-        c[i] = v;
-        row[fx0] = v;
-    });
-}
-// second peak: the thread's maximum outside the flat-index exclusion zone of m (B:346-358): f in {clamp(m + i + 64 j),
-// |i|, |j| <= wv}: in row fy the columns mx + i (j = fy - my), mx + i + 64 (the row wrap, j = fy - my - 1) and
-// mx + i - 64 (j = fy - my + 1), plus the two clamps.  Negative if every cell of the thread is excluded (an excluded
-// cell takes part with its sign bit set: every map value is >= 1e-7).
-TPIV_HD double peak_second_local(const double (&c)[M], int y, int q, int m, int wv) {
-    const int fy = (y + WS / 2) & (WS - 1);
-    const int my = m / WS, mx = m % WS;
-    const int dj = fy - my;
-    unsigned long long ex = 0ull;                  // bit fx set = excluded
-    auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
-        lo_ = lo_ < 0 ? 0 : lo_;
-        hi_ = hi_ > WS - 1 ? WS - 1 : hi_;
-        if (lo_ > hi_) return 0ull;
-        const int len = hi_ - lo_ + 1;
-        const unsigned long long ones = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
-        return ones << lo_;
-    };
-    if (dj >= -wv && dj <= wv) ex |= span(mx - wv, mx + wv);
-    if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(mx - wv + WS, mx + wv + WS);
-    if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx - wv - WS, mx + wv - WS);
-    if (fy == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;
-    if (fy == WS - 1 && (m + wv + wv * WS) >= WS * WS - 1) ex |= 1ull << (WS - 1);
-    ex >>= 2 * q;                                  // this thread's columns: bit positions become compile-time constants
-    const unsigned exl = (unsigned)ex, exh = (unsigned)(ex >> 32);
-    double sv = -1.0;
-    static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
-        constexpr int i = decltype(ic)::value;
-        constexpr int fx0 = (4 * (i >> 1) + (i & 1) + WS / 2) & (WS - 1);
+
+// W = window edge (64 or 128); every function is the work of ONE thread
+template <int W>
+struct Split {
+    static constexpr int WS = W;
+    static constexpr int M = W / 2;          // codelet length
+    static constexpr int PL = W + 1;         // plane pitch in doubles: conflict-free ds_read_b64 / ds_write_b64 along rows and columns
+    static constexpr int NDW = W / 4;        // dwords per window row
+    static constexpr int NT = 2 * W;         // threads per window: line = t % W, half = t / W
+
+    // ---- R: thread (y, h).  da / db: row y of frame a / b.  The samples go in as they are: the normalisation a / mean(a),
+    // b / mean(b) of B:513-514 is linear, so it is ONE factor 1 / (mean(a) mean(b)) on the whole correlation map, applied
+    // where the map is shifted by its minimum (peak_shifted) -- W multiplies per thread and one of two divisions per window
+    // less, at rounding-level differences (1e-16 relative) from scaling every sample first.
+    static TPIV_HD void rows_forward(const uint32_t (&da)[NDW], const uint32_t (&db)[NDW], int h, cd (&x)[M]) {
+        const float sg = h ? -1.0f : 1.0f;
+        static_for<0, M>([&](auto jc) TPIV_LAMBDA_INLINE {
+            constexpr int j = decltype(jc)::value;
+            // sums / differences of two bytes: exact in float32, converted once
+            const float sa = byte_of<j, NDW>(da) + sg * byte_of<j + M, NDW>(da);
+            const float sb = byte_of<j, NDW>(db) + sg * byte_of<j + M, NDW>(db);
+            x[j] = cd{(double)sa, (double)sb};
+        });
+        if (h) {
+            static_for<1, M>([&](auto jc) TPIV_LAMBDA_INLINE {
+                constexpr int j = decltype(jc)::value;
+                x[j] = twmul_d<j, W, 1>(x[j]);
+            });
+        }
+        fft_inreg_d<M, 1>(x);          // X[y][2m + h] at x[FFT_POS<m, M>]
+    }
+
+    // ---- T1 write: component COMP (0 = real, 1 = imaginary) of X[y][2m + h]
+    template <int COMP>
+    static TPIV_HD void t1_write(const cd (&x)[M], int y, int h, double* plane) {
+        double* row = plane + y * PL + h;
+        static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
+            constexpr int m = decltype(mc)::value;
+            row[2 * m] = COMP ? x[FFT_POS<m, M>].y : x[FFT_POS<m, M>].x;
+        });
+    }
+    // ---- T1 read: thread (k, g): u[i] = X[i][k] +- X[i + M][k]
+    template <int COMP>
+    static TPIV_HD void t1_read(cd (&u)[M], int k, int g, const double* plane) {
+        const double sg = g ? -1.0 : 1.0;
 #if defined(__HIP_DEVICE_COMPILE__)
-        // sign-extended exclusion bit (0 / -1) -> sign bit of the value: excluded cells lose every comparison
-        const int kill = __builtin_amdgcn_sbfe((int)(fx0 < 32 ? exl : exh), fx0 & 31, 1);
-        const double v = __hiloint2double(__double2hiint(c[i]) | (kill & (int)0x80000000), __double2loint(c[i]));
+        const unsigned base = lds_addr(plane + k);
+        constexpr int NB = M / 4;                                   // batches of 4 rows i = 8 reads
+        double v[2][8];
+        auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
+            constexpr int b_ = decltype(bc)::value;
+            static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
+                constexpr int i = 4 * b_ + decltype(ic)::value;
+                v[b_ & 1][2 * decltype(ic)::value] = lds_rd<i * PL * 8>(base);
+                v[b_ & 1][2 * decltype(ic)::value + 1] = lds_rd<(i + M) * PL * 8>(base);
+            });
+        };
+        issue(std::integral_constant<int, 0>{});
+        static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
+            constexpr int b_ = decltype(bc)::value;
+            if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
+            lds_wait<(b_ + 1 < NB) ? 8 : 0>(v[b_ & 1]);
+            static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
+                constexpr int q = decltype(ic)::value, i = 4 * b_ + q;
+                const double r = v[b_ & 1][2 * q] + sg * v[b_ & 1][2 * q + 1];
+                if constexpr (COMP) u[i].y = r;
+                else u[i].x = r;
+            });
+        });
 #else
-        const bool excl = ((fx0 < 32 ? exl : exh) >> (fx0 & 31)) & 1u;
-        const double v = excl ? -c[i] : c[i];
+        const double* col = plane + k;
+        for (int i = 0; i < M; ++i) {
+            const double r = col[i * PL] + sg * col[(i + M) * PL];
+            if (COMP) u[i].y = r;
+            else u[i].x = r;
+        }
 #endif
-        sv = dmax2(sv, v);
-    });
-    return sv;
-}
-// record for finalize_kernel<true>: slot 0..7 = c[m], c[left], c[right], c[top], c[bot], c[m2], m, dead
-// (flat-index neighbours and fix-ups of B:385-392; `sv` < 0: nothing left outside the exclusion zone -- the
-// reference's second arg-max then runs over the zeroed map: c[m2] = 0, ratio = +inf)
-TPIV_HD double peak_record_slot(int slot, int m, double sv, bool dead, const double* plane) {
-    const int KD = WS * WS;
-    int left = m + 1, right = m - 1, top = m + WS, bot = m - WS;
-    if (left >= KD - 1) left = m;
-    if (right <= 0) right = m;
-    if (top >= KD - 1) top = m;
-    if (bot <= 0) bot = m;
-    int qi = m;
-    qi = slot == 1 ? left : qi;
-    qi = slot == 2 ? right : qi;
-    qi = slot == 3 ? top : qi;
-    qi = slot == 4 ? bot : qi;
-    double outv = plane[(qi / WS) * PL + (qi % WS)];
-    outv = slot == 5 ? (sv >= 0.0 ? sv : 0.0) : outv;
-    outv = slot == 6 ? (double)m : outv;
-    outv = slot == 7 ? (dead ? 1.0 : 0.0) : outv;
-    return outv;
-}
+    }
+    // ---- C: the odd half's twiddles, then the codelet: Z[2m + g][k] at u[FFT_POS<m, M>]
+    static TPIV_HD void cols_forward(cd (&u)[M], int g) {
+        if (g) {
+            static_for<1, M>([&](auto ic) TPIV_LAMBDA_INLINE {
+                constexpr int i = decltype(ic)::value;
+                u[i] = twmul_d<i, W, 1>(u[i]);
+            });
+        }
+        fft_inreg_d<M, 1>(u);
+    }
+
+    // ---- X (64x64): cross-spectrum in place with the mirrored bins fetched by ds_bpermute.  sh(value, reg, comp, partner)
+    // returns the PARTNER thread's value of register `reg` (device: ds_bpermute of `value`; the host harness looks it up).
+    // bin ky = 2m + G sits at z[FFT_POS<m>]; its mirror -ky = 2 m' + G with m' = (M - m) % M (G = 0), M - 1 - m (G = 1)
+    template <int G, typename SH>
+    static TPIV_HD void cross_spectrum_g(cd (&z)[M], int partner, SH&& sh) {
+        constexpr int NPAIR = G ? M / 2 : M / 2 + 1;
+        static_for<0, NPAIR>([&](auto mc) TPIV_LAMBDA_INLINE {
+            constexpr int m = decltype(mc)::value;
+            constexpr int m2 = G ? M - 1 - m : (M - m) % M;
+            constexpr int p1 = FFT_POS<m, M>, p2 = FFT_POS<m2, M>;
+            cd z1 = z[p1];
+            pin(z1);
+            if constexpr (m == m2) {
+                const cd m1{sh(z1.x, p1, 0, partner), sh(z1.y, p1, 1, partner)};
+                z[p1] = cross_bin(z1, m1);
+            } else {
+                cd z2 = z[p2];
+                pin(z2);
+                const cd m1{sh(z2.x, p2, 0, partner), sh(z2.y, p2, 1, partner)};      // Z(-ky, -k)
+                const cd m2v{sh(z1.x, p1, 0, partner), sh(z1.y, p1, 1, partner)};     // Z(+ky, -k): the mirror of bin -ky
+                z[p1] = cross_bin(z1, m1);
+                z[p2] = cross_bin(z2, m2v);
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            // keep the exchange of a bin pair together: hoisted ahead, the 8 permutes of every pair hold their results
+            // in registers next to the 128 of the spectrum
+            if constexpr (m % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+        });
+    }
+    // ---- X (128x128): the mirrored bins through the plane.  cross_write<COMP>: plane[ky][k] <- Z(ky, k); cross_read<COMP>:
+    // mir[m] = component of Z(-ky, -k) for the thread's bins ky = 2m + g (row (W - ky) % W, column (W - k) % W).
+    template <int COMP>
+    static TPIV_HD void cross_write(const cd (&z)[M], int k, int g, double* plane) {
+        double* col = plane + g * PL + k;
+        static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
+            constexpr int m = decltype(mc)::value;
+            col[2 * m * PL] = COMP ? z[FFT_POS<m, M>].y : z[FFT_POS<m, M>].x;
+        });
+    }
+    static TPIV_HD void cross_read(double (&mir)[M], int k, int g, const double* plane) {
+        const int mk = (W - k) & (W - 1);
+        // row of bin m: (W - 2m - g) % W = W - 2m - g for m >= 1; m = 0: (W - g) % W
+        const double* c0 = plane + mk - g * PL;                  // + (W - 2m) * PL for m >= 1
+        mir[0] = plane[((W - g) & (W - 1)) * PL + mk];
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned base = lds_addr(c0);
+        constexpr int NB = (M - 1 + 7) / 8;
+        double v[2][8];
+        auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
+            constexpr int b_ = decltype(bc)::value;
+            static_for<0, 8>([&](auto ic) TPIV_LAMBDA_INLINE {
+                constexpr int m = 1 + 8 * b_ + decltype(ic)::value;
+                if constexpr (m < M) v[b_ & 1][decltype(ic)::value] = lds_rd<(W - 2 * m) * PL * 8>(base);
+                else v[b_ & 1][decltype(ic)::value] = 0.0;
+            });
+        };
+        issue(std::integral_constant<int, 0>{});
+        static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
+            constexpr int b_ = decltype(bc)::value;
+            if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
+            constexpr int left = M - 1 - 8 * (b_ + 1);               // reads issued behind this batch
+            lds_wait<(b_ + 1 < NB) ? (left < 8 ? left : 8) : 0>(v[b_ & 1]);
+            static_for<0, 8>([&](auto ic) TPIV_LAMBDA_INLINE {
+                constexpr int m = 1 + 8 * b_ + decltype(ic)::value;
+                if constexpr (m < M) mir[m] = v[b_ & 1][decltype(ic)::value];
+            });
+        });
+#else
+        for (int m = 1; m < M; ++m) mir[m] = c0[(W - 2 * m) * PL];
+#endif
+    }
+    static TPIV_HD void cross_finish(cd (&z)[M], const double (&mre)[M], const double (&mim)[M]) {
+        static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
+            constexpr int m = decltype(mc)::value;
+            z[FFT_POS<m, M>] = cross_bin(z[FFT_POS<m, M>], cd{mre[m], mim[m]});
+        });
+    }
+
+    // ---- Ci: natural-order rename, inverse codelet, decimation-in-time twiddle of the odd half: G_g[y1] at t[FFT_POS<y1, M>]
+    static TPIV_HD void cols_inverse(const cd (&z)[M], int g, cd (&t)[M]) {
+        static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
+            constexpr int m = decltype(mc)::value;
+            t[m] = z[FFT_POS<m, M>];
+        });
+        fft_inreg_d<M, -1>(t);
+        if (g) {
+            static_for<1, M>([&](auto yc) TPIV_LAMBDA_INLINE {
+                constexpr int y1 = decltype(yc)::value;
+                t[FFT_POS<y1, M>] = twmul_d<y1, W, -1>(t[FFT_POS<y1, M>]);
+            });
+        }
+    }
+    // ---- T2 write: thread (k, g): plane[M g + y1][k] <- G_g[y1][k]
+    template <int COMP>
+    static TPIV_HD void t2_write(const cd (&t)[M], int k, int g, double* plane) {
+        double* col = plane + (M * g) * PL + k;
+        static_for<0, M>([&](auto yc) TPIV_LAMBDA_INLINE {
+            constexpr int y1 = decltype(yc)::value;
+            col[y1 * PL] = COMP ? t[FFT_POS<y1, M>].y : t[FFT_POS<y1, M>].x;
+        });
+    }
+    // ---- T2 read: thread (y, q): Y[kx] = G_0[y % M][kx] +- G_1[y % M][kx], kx = 0..M
+    template <int COMP>
+    static TPIV_HD void t2_read(cd (&Y)[M + 1], int y, const double* plane) {
+        const double sg = y < M ? 1.0 : -1.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned base = lds_addr(plane + (y & (M - 1)) * PL);
+        constexpr int NB = M / 4 + 1;                               // M / 4 batches of 4 columns + column M
+        double v[2][8];
+        auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
+            constexpr int b_ = decltype(bc)::value;
+            static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
+                constexpr int kx = 4 * b_ + decltype(ic)::value;
+                if constexpr (kx <= M) {
+                    v[b_ & 1][2 * decltype(ic)::value] = lds_rd<kx * 8>(base);
+                    v[b_ & 1][2 * decltype(ic)::value + 1] = lds_rd<(M * PL + kx) * 8>(base);
+                }
+            });
+        };
+        issue(std::integral_constant<int, 0>{});
+        static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
+            constexpr int b_ = decltype(bc)::value;
+            if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
+            // outstanding behind this batch: the next one (8 reads, the last batch holds 2)
+            lds_wait<(b_ + 1 < NB) ? (b_ + 2 == NB ? 2 : 8) : 0>(v[b_ & 1]);
+            static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
+                constexpr int q = decltype(ic)::value, kx = 4 * b_ + q;
+                if constexpr (kx <= M) {
+                    const double r = v[b_ & 1][2 * q] + sg * v[b_ & 1][2 * q + 1];
+                    if constexpr (COMP) Y[kx].y = r;
+                    else Y[kx].x = r;
+                }
+            });
+        });
+#else
+        const double* r0 = plane + (y & (M - 1)) * PL;
+        const double* r1 = r0 + M * PL;
+        for (int kx = 0; kx <= M; ++kx) {
+            const double r = r0[kx] + sg * r1[kx];
+            if (COMP) Y[kx].y = r;
+            else Y[kx].x = r;
+        }
+#endif
+    }
+    // ---- Ri: c2r pre-processing (both threads of the pair), DIF halves of the M packed values, M/2-point inverse codelet.
+    // Out: c[2n + e] = corr[y][4n + 2q + e], n = 0..M/2-1, e = 0, 1 (un-shifted column index).
+    static TPIV_HD void rows_inverse(cd (&Y)[M + 1], int q, double (&c)[M]) {
+        c2r_pre_d<W>(Y);                        // h[0..M) in Y[0..M)
+        cd e[M / 2];
+        const double sq = q ? -1.0 : 1.0;
+        static_for<0, M / 2>([&](auto jc) TPIV_LAMBDA_INLINE {
+            constexpr int j = decltype(jc)::value;
+            e[j] = cd{Y[j].x + sq * Y[j + M / 2].x, Y[j].y + sq * Y[j + M / 2].y};
+        });
+        if (q) {
+            static_for<1, M / 2>([&](auto jc) TPIV_LAMBDA_INLINE {
+                constexpr int j = decltype(jc)::value;
+                e[j] = twmul_d<j, M, -1>(e[j]);
+            });
+        }
+        fft_inreg_d<M / 2, -1>(e);              // z[2n + q] at e[FFT_POS<n, M/2>]
+        static_for<0, M / 2>([&](auto nc) TPIV_LAMBDA_INLINE {
+            constexpr int n = decltype(nc)::value;
+            c[2 * n] = e[FFT_POS<n, M / 2>].x;
+            c[2 * n + 1] = e[FFT_POS<n, M / 2>].y;
+        });
+    }
+
+    // ---- P: peak analysis in fftshift coordinates (y' = (y + W/2) % W, x' likewise).  Thread (y, q) holds
+    // c[2n + e] = corr[y][x = 4n + 2q + e].
+    // one pass over the raw cells gives their minimum AND their maximum: v = (c - min) + 1e-7 is monotonic in c, so the
+    // maximum of the shifted cells is the shifted maximum (exactly: the same two roundings)
+    static TPIV_HD void peak_local_minmax(const double (&c)[M], double& mn, double& mx) {
+        mn = c[0];
+        mx = c[0];
+#pragma unroll
+        for (int i = 1; i < M; ++i) {
+            mn = dmin2(mn, c[i]);
+            mx = dmax2(mx, c[i]);
+        }
+    }
+    // v = (c - min) + 1e-7, written to the map (plane, shifted coordinates).  (No index is tracked: the arg-max position
+    // comes from the map afterwards -- first the smallest row whose maximum is the global one, then the first column of
+    // that row -- which keeps the scan free of compare / select chains.)
+    static TPIV_HD void peak_shift_and_write(double (&c)[M], double cmin, double scale, int y, int q, double* plane) {
+        const int fy = (y + W / 2) & (W - 1);
+        double* row = plane + fy * PL + 2 * q;
+        static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int i = decltype(ic)::value;
+            constexpr int fx0 = (4 * (i >> 1) + (i & 1) + W / 2) & (W - 1);       // + 2 q: stays inside its group of four
+            const double v = peak_shifted(c[i], cmin, scale);
+            c[i] = v;
+            row[fx0] = v;
+        });
+    }
+    // second peak: the thread's maximum outside the flat-index exclusion zone of m (B:346-358): f in {clamp(m + i + W j),
+    // |i|, |j| <= wv}: in row fy the columns mx + i (j = fy - my), mx + i + W (the row wrap, j = fy - my - 1) and
+    // mx + i - W (j = fy - my + 1), plus the two clamps.  Negative if every cell of the thread is excluded (an excluded
+    // cell takes part with its sign bit set: every map value is >= 1e-7).
+    static TPIV_HD double peak_second_local(const double (&c)[M], int y, int q, int m, int wv) {
+        constexpr int NW = W / 64;
+        const int fy = (y + W / 2) & (W - 1);
+        const int my = m / W, mx = m % W;
+        const int dj = fy - my;
+        unsigned long long ex[NW] = {};                // bit fx set = excluded
+        auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
+            lo_ = lo_ < 0 ? 0 : lo_;
+            hi_ = hi_ > W - 1 ? W - 1 : hi_;
+            for (int b_ = lo_; b_ <= hi_; ++b_) ex[b_ >> 6] |= 1ull << (b_ & 63);     // at most 2 wv + 1 columns
+        };
+        if (dj >= -wv && dj <= wv) span(mx - wv, mx + wv);
+        if (dj + 1 >= -wv && dj + 1 <= wv) span(mx - wv + W, mx + wv + W);
+        if (dj - 1 >= -wv && dj - 1 <= wv) span(mx - wv - W, mx + wv - W);
+        if (fy == 0 && (m - wv - wv * W) <= 0) ex[0] |= 1ull;
+        if (fy == W - 1 && (m + wv + wv * W) >= W * W - 1) ex[NW - 1] |= 1ull << 63;
+        // this thread's columns are fx0 + 2 q: shift the mask down by 2 q, the bit positions become compile-time constants
+        unsigned word[2 * NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            unsigned long long w_ = ex[i] >> (2 * q);
+            if (i + 1 < NW && q) w_ |= ex[i + 1] << 62;
+            word[2 * i] = (unsigned)w_;
+            word[2 * i + 1] = (unsigned)(w_ >> 32);
+        }
+        double sv = -1.0;
+        static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int i = decltype(ic)::value;
+            constexpr int fx0 = (4 * (i >> 1) + (i & 1) + W / 2) & (W - 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+            // sign-extended exclusion bit (0 / -1) -> sign bit of the value: excluded cells lose every comparison
+            const int kill = __builtin_amdgcn_sbfe((int)word[fx0 >> 5], fx0 & 31, 1);
+            const double v = __hiloint2double(__double2hiint(c[i]) | (kill & (int)0x80000000), __double2loint(c[i]));
+#else
+            const bool excl = (word[fx0 >> 5] >> (fx0 & 31)) & 1u;
+            const double v = excl ? -c[i] : c[i];
+#endif
+            sv = dmax2(sv, v);
+        });
+        return sv;
+    }
+    // record for finalize_kernel<true>: slot 0..7 = c[m], c[left], c[right], c[top], c[bot], c[m2], m, dead
+    // (flat-index neighbours and fix-ups of B:385-392; `sv` < 0: nothing left outside the exclusion zone -- the
+    // reference's second arg-max then runs over the zeroed map: c[m2] = 0, ratio = +inf)
+    static TPIV_HD double peak_record_slot(int slot, int m, double sv, bool dead, const double* plane) {
+        const int KD = W * W;
+        int left = m + 1, right = m - 1, top = m + W, bot = m - W;
+        if (left >= KD - 1) left = m;
+        if (right <= 0) right = m;
+        if (top >= KD - 1) top = m;
+        if (bot <= 0) bot = m;
+        int qi = m;
+        qi = slot == 1 ? left : qi;
+        qi = slot == 2 ? right : qi;
+        qi = slot == 3 ? top : qi;
+        qi = slot == 4 ? bot : qi;
+        double outv = plane[(qi / W) * PL + (qi % W)];
+        outv = slot == 5 ? (sv >= 0.0 ? sv : 0.0) : outv;
+        outv = slot == 6 ? (double)m : outv;
+        outv = slot == 7 ? (dead ? 1.0 : 0.0) : outv;
+        return outv;
+    }
+};
 
 }  // namespace f64s
 }  // namespace tpiv
