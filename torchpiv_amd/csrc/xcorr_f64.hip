@@ -1,431 +1,42 @@
-// First pass at the reference's precision (TPIV_PREC_REFERENCE): float64 windows, transforms, map
-// and peak analysis for the power-of-two tile sizes 8..64.
+// First pass in float64 (TPIV_PREC_F64 / TPIV_PREC_REFERENCE) for the power-of-two window sizes 8 ... 128.
 //
-// The reference promotes pass 1 to float64 (PIVbackend.py:513-514: aa = a / mean(a) as float64, then
-// correalte_fft B:249-257 runs rfft2 / irfft2 in complex128, `corr - corr.min()` B:518 and
-// correlation_to_displacement B:360-422 on the float64 map).  The float32 tile kernels
-// (xcorr_tile.hpp) hold a whole line per lane in registers; a 64-point complex float64 line would
-// need 256 VGPRs, so this kernel keeps the packed tile Z = a/mean(a) + i b/mean(b) in LDS (16-byte
-// complex elements, WS = 64: 66.6 KB, two workgroups per CU) and transforms it IN PLACE:
+// The reference promotes pass 1 to float64 (PIVbackend.py:513-514: aa = a / mean(a) as float64, then correalte_fft
+// B:249-257 runs rfft2 / irfft2 in complex128, `corr - corr.min()` B:518 and correlation_to_displacement B:360-422 on
+// the float64 map).  Everything here keeps the lines of the packed tile a + i b IN REGISTERS and uses LDS only to
+// transpose between the row and the column transform, one float64 plane at a time:
 //
-//   forward  decimation in frequency, radix 8 (then 4 or 2 for what is left of the length): natural
-//            order in, digit-reversed order out -- along x, then along y; two LDS passes per
-//            dimension for WS = 64, and only the first of them carries non-trivial twiddles;
-//   spectrum the pair {k, -k} is found through the digit-reversal table and handled by ONE thread:
-//            P(k) = conj(A) B from Z(k), Z(-k) (packed real transforms), P(-k) = conj P(k);
-//   inverse  the exact inverse of the forward stages in reverse order (decimation in time, conjugate
-//            twiddles): digit-reversed in, natural order out -- along y, then along x.
+//   8 ... 32    xcorr_f64_tile_kernel    lane = one image row, the whole line (<= 32 complex float64 = 128 VGPRs) per
+//                                        lane, single-wavefront workgroups (no barriers), c2r last transform;
+//   64, 128     xcorr_f64_split_kernel   a 64- / 128-point line does not fit a lane: two threads per line, 32- / 64-point
+//                                        codelets, the radix-2 steps folded into the LDS transposes (per-thread arithmetic
+//                                        in xcorr_f64_split.hpp, which the CPU suite runs thread by thread against numpy).
 //
-// No reordering pass and no second buffer; every stage reads and writes the same four (two) cells per
-// butterfly, so only a workgroup barrier separates the stages.  Peak analysis follows the reference on
-// the float64 map (first flat index on ties, flat-index neighbours and fix-ups, 7x7 flat-index
+// The window normalisation is one factor on the correlation map (rows_forward in xcorr_f64_split.hpp).  Peak analysis
+// follows the reference on the float64 map (first flat index on ties, flat-index neighbours and fix-ups, 7x7 flat-index
 // exclusion with row wrap and clamps); the 8-double record goes to finalize_kernel<true>.
+//
+// History: the first generation (round 2) kept the 16-byte complex elements of the tile in LDS and walked radix-8 stages
+// over them -- 35.0 ms per 256 pairs for the 64x64 pass 1 of configs[1] at 43 % LDS bank conflicts and ~25 barriers per
+// window (profiles/r02), 597 us per 4096^2 pair for the 32x32 pass 1 of configs[3]; same-box A/B against this file:
+// 17.2 ms and 196 us.  128x128 windows ran the generic-size DFT kernel: 15.4 ms per pair, now 0.117 ms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "piv_kernels.h"
 #include "xcorr_tile.hpp"      // grp_reduce: wavefront reductions in the VALU (DPP / permlane swaps)
-#include "xcorr_f64_split.hpp" // 64x64: lines split over two lanes, 32-point in-register codelets (second generation)
+#include "xcorr_f64_split.hpp" // 64 / 128: lines split over two threads, 32- / 64-point in-register codelets
 
 namespace tpiv {
 
 namespace {
 
-// (the LDS-resident scheme below -- 8x8 ... 32x32 windows -- has its own 16-byte complex type)
-struct alignas(16) cz {       // 16-byte alignment: ds_read_b128 / ds_write_b128 instead of ds_read2_b64 / ds_write2_b64
-    double x, y;
-};
-__device__ __forceinline__ cz cmul(cz a, cz w) { return cz{a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x}; }
-__device__ __forceinline__ cz cmulc(cz a, cz w) { return cz{a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y}; }   // a * conj(w)
-__device__ __forceinline__ cz cadd_(cz a, cz b) { return cz{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cz csub_(cz a, cz b) { return cz{a.x - b.x, a.y - b.y}; }
-// a * (-i) for the forward transform, a * (+i) for the inverse
-template <bool FWD>
-__device__ __forceinline__ cz rot90(cz a) { return FWD ? cz{a.y, -a.x} : cz{-a.y, a.x}; }
-
-// radix of the stage that works on blocks of length L: 8 while it fits, then what is left (4 or 2)
-constexpr int radix_of(int L) { return L >= 8 ? 8 : L; }
-// position of bin k after the in-place DIF transform of length n
-constexpr int pos_of(int k, int n) {
-    if (n <= 1) return 0;
-    const int r = radix_of(n);
-    return (k % r) * (n / r) + pos_of(k / r, n / r);
-}
-
-// the closed form the cross-spectrum uses: two stages (radix R1 = min(8, n), then n / R1) make the digit
-// reversal a swap of two digits
-constexpr bool digit_swap_ok(int n) {
-    const int r1 = n >= 8 ? 8 : n, r2 = n / r1;
-    for (int k = 0; k < n; ++k)
-        if (pos_of(k, n) != (k % r1) * r2 + k / r1) return false;
-    return true;
-}
-static_assert(digit_swap_ok(8) && digit_swap_ok(16) && digit_swap_ok(32) && digit_swap_ok(64), "digit reversal closed form");
-
-template <int WS>
-struct F64Geo {
-    // threads per workgroup (one window).  64x64: 512, i.e. 16 wavefronts per CU with the two workgroups the
-    // LDS admits -- at 256 threads the two wavefronts per SIMD could not hide the LDS round trips
-    static constexpr int NT = WS >= 64 ? 512 : (WS >= 32 ? 256 : 64);
-    static constexpr int P = WS + 1;                    // tile pitch in complex elements
-    static constexpr int NW = NT / 64;                  // wavefronts
-    static constexpr int OCC = WS >= 64 ? 4 : 1;        // wavefronts per SIMD the register budget must allow
-};
-
-template <int WS>
-struct F64Shared {
-    cz z[WS * (WS + 1)];              // the packed tile a/mean(a) + i b/mean(b): 16-byte elements (ds_*_b128)
-    cz tw[WS];                        // exp(-2 pi i k / WS)
-    double redd[16];
-    int redi[8];
-    unsigned long long redu[8];
-};
-
 // Workgroup barrier for LDS exchanges only: __syncthreads() also waits for vmcnt(0), which would drain
-// the next window's pixel prefetch at the first of the ~25 barriers per window.
+// the next window's pixel prefetch at the first barrier of a window.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// ---- workgroup reductions (every thread gets the result) ------------------------------------------
-// (the wavefront step runs in the VALU -- DPP row operations and permlane swaps, xcorr_tile.hpp -- not
-//  through ds_bpermute: six dependent LDS round trips per reduction were a sixth of the window time)
-template <int NW, typename T, typename OP>
-__device__ __forceinline__ T wg_reduce(T v, OP op, T* red) {
-    v = grp_reduce<64>(v, op);
-    if constexpr (NW == 1) return v;
-    lds_barrier();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    lds_barrier();
-    T r = red[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) r = op(r, red[w]);
-    return r;
-}
-
-// R-point DFT of x[0..R) in registers, natural order in and out; FWD: exp(-2 pi i pq/R), else the conjugate kernel
-template <int R, bool FWD>
-__device__ __forceinline__ void dft_small(cz (&x)[R]) {
-    if constexpr (R == 2) {
-        const cz a = x[0], b = x[1];
-        x[0] = cadd_(a, b);
-        x[1] = csub_(a, b);
-    } else if constexpr (R == 4) {
-        const cz t0 = cadd_(x[0], x[2]), t1 = csub_(x[0], x[2]), t2 = cadd_(x[1], x[3]);
-        const cz t3 = rot90<FWD>(csub_(x[1], x[3]));
-        x[0] = cadd_(t0, t2);
-        x[1] = cadd_(t1, t3);
-        x[2] = csub_(t0, t2);
-        x[3] = csub_(t1, t3);
-    } else {
-        static_assert(R == 8, "radix 2, 4 or 8");
-        constexpr double H = 0.70710678118654752440;
-        // first layer: a_p = x_p + x_{p+4} (even outputs), b_p = (x_p - x_{p+4}) w8^p (odd outputs)
-        cz a[4], b[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            a[p] = cadd_(x[p], x[p + 4]);
-            b[p] = csub_(x[p], x[p + 4]);
-        }
-        // w8^1 = (1 -+ i)/sqrt2, w8^2 = -+i, w8^3 = (-1 -+ i)/sqrt2   (upper sign: forward)
-        b[1] = FWD ? cz{(b[1].x + b[1].y) * H, (b[1].y - b[1].x) * H} : cz{(b[1].x - b[1].y) * H, (b[1].y + b[1].x) * H};
-        b[2] = rot90<FWD>(b[2]);
-        b[3] = FWD ? cz{(b[3].y - b[3].x) * H, -(b[3].x + b[3].y) * H} : cz{-(b[3].x + b[3].y) * H, (b[3].x - b[3].y) * H};
-        dft_small<4, FWD>(a);
-        dft_small<4, FWD>(b);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            x[2 * p] = a[p];
-            x[2 * p + 1] = b[p];
-        }
-    }
-}
-
-// ---- one radix-R stage on sub-length L of every line, along x (ALONG_Y = false) or y, forward
-//      (decimation in frequency: butterfly, then twiddle) or inverse (conjugate twiddle, then butterfly).
-// Thread mapping: a line has WS / R butterflies (index t = block * (L/R) + j).  The twiddles depend on j
-// only, so a thread keeps ONE t and walks the lines: it fetches its R - 1 twiddles once per stage.
-// The LW lanes that share a t are consecutive LINES.  Along y that is LW consecutive 16-byte elements of
-// a tile row; along x it is LW consecutive rows of one column, 65 elements = 260 dwords = 4 banks
-// (mod 64) apart -- both patterns are conflict-free for ds_read/write_b128.  (Mapping the lanes of a
-// wavefront to the butterflies of one row instead cost 3 bank-conflict cycles per LDS cycle:
-// SQ_LDS_BANK_CONFLICT 2.7e10 against SQ_ACTIVE_INST_LDS 8.4e9 per launch.)
-template <int WS, int L, int R, bool ALONG_Y, bool FWD>
-__device__ __forceinline__ void stage(F64Shared<WS>& sm) {
-    using G = F64Geo<WS>;
-    constexpr int P = G::P, NT = G::NT;
-    constexpr int Q = L / R;                   // butterflies per block = stride between a butterfly's elements
-    constexpr int BPL = WS / R;                // butterflies per line
-    constexpr int TWS = WS / L;                // twiddle stride in the length-WS table
-    constexpr int LW = WS < NT * 8 / WS ? WS : NT * 8 / WS;        // lanes that share a butterfly index
-    constexpr int TPP = NT / LW;                                   // butterfly indices handled per pass
-    const int tid = threadIdx.x;
-    const int t0 = tid / LW;
-    const int line0 = tid % LW;
-    constexpr int LSTEP = LW;                                      // lines advanced per pass
-    for (int t = t0; t < BPL; t += TPP) {                          // (one iteration unless NT / LW < WS / R)
-        const int blk = t / Q, j = t % Q;
-        const int e0 = blk * L + j;
-        cz w[R];
-        if constexpr (Q > 1) {
-#pragma unroll
-            for (int q = 1; q < R; ++q) w[q] = sm.tw[(q * j * TWS) % WS];
-        }
-        constexpr int NIT = (WS + LSTEP - 1) / LSTEP;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int line = line0 + it * LSTEP;
-            if (LSTEP * NIT != WS && line >= WS) break;
-            if (WS < LSTEP && line >= WS) break;
-            cz x[R];
-#pragma unroll
-            for (int q = 0; q < R; ++q) x[q] = ALONG_Y ? sm.z[(e0 + q * Q) * P + line] : sm.z[line * P + e0 + q * Q];
-            if constexpr (FWD) {
-                dft_small<R, true>(x);
-                if constexpr (Q > 1) {
-#pragma unroll
-                    for (int q = 1; q < R; ++q) x[q] = cmul(x[q], w[q]);
-                }
-            } else {
-                if constexpr (Q > 1) {
-#pragma unroll
-                    for (int q = 1; q < R; ++q) x[q] = cmulc(x[q], w[q]);
-                }
-                dft_small<R, false>(x);
-            }
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                if constexpr (ALONG_Y) sm.z[(e0 + q * Q) * P + line] = x[q];
-                else sm.z[line * P + e0 + q * Q] = x[q];
-            }
-        }
-    }
-    lds_barrier();
-}
-
-// all stages of one dimension: forward = largest block first, inverse = the same stages in reverse order
-template <int WS, int L, bool ALONG_Y, bool FWD>
-__device__ __forceinline__ void transform(F64Shared<WS>& sm) {
-    if constexpr (L >= 2) {
-        constexpr int R = radix_of(L);
-        if constexpr (FWD) {
-            stage<WS, L, R, ALONG_Y, true>(sm);
-            transform<WS, L / R, ALONG_Y, true>(sm);
-        } else {
-            transform<WS, L / R, ALONG_Y, false>(sm);
-            stage<WS, L, R, ALONG_Y, false>(sm);
-        }
-    }
-}
-
-template <int WS>
-__global__ __launch_bounds__(F64Geo<WS>::NT, F64Geo<WS>::OCC) void xcorr_f64_kernel(PassParams p) {
-    using G = F64Geo<WS>;
-    constexpr int NT = G::NT, P = G::P, NN = WS * WS;
-    constexpr int NDW = NN / 4;                 // dwords per frame window
-    constexpr int DPT = (NDW + NT - 1) / NT;    // dwords per thread
-    __shared__ F64Shared<WS> sm;
-    const int tid = threadIdx.x;
-
-    for (int k = tid; k < WS; k += NT) {
-        double s, c;
-        sincospi(2.0 * (double)k / (double)WS, &s, &c);
-        sm.tw[k] = cz{c, -s};
-    }
-    lds_barrier();
-
-    const int N = p.n_rows * p.n_cols;
-    const long long items = (long long)p.batch * N;
-    const int st = p.ws - p.ov;
-    const int HW = p.H * p.W;
-    // XCD-aware static order: workgroups b, b+8, ... share an XCD and walk one contiguous run of windows
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const long long chunk = (items + 7) / 8;
-    const long long lo = (long long)xcd * chunk;
-    const long long hi = lo + chunk < items ? lo + chunk : items;
-
-    // the pixels of the next window are fetched while the current one is transformed (4 dwords per thread)
-    uint32_t da[DPT], db[DPT];
-    auto fetch = [&](long long it) {
-        const int pair_ = (int)(it / N), win_ = (int)(it % N);
-        const int yy0 = (win_ / p.n_cols) * st, xx0 = (win_ % p.n_cols) * st;
-        const uint8_t* __restrict__ fa = p.A + (size_t)pair_ * HW + (size_t)yy0 * p.W + xx0;
-        const uint8_t* __restrict__ fb = p.B + (size_t)pair_ * HW + (size_t)yy0 * p.W + xx0;
-#pragma unroll
-        for (int q = 0; q < DPT; ++q) {
-            const int i = tid + q * NT;
-            da[q] = 0;
-            db[q] = 0;
-            if (i < NDW) {
-                const int y = i / (WS / 4), x4 = (i % (WS / 4)) * 4;
-                __builtin_memcpy(&da[q], fa + (size_t)y * p.W + x4, 4);      // (unaligned dword loads are fine in global memory)
-                __builtin_memcpy(&db[q], fb + (size_t)y * p.W + x4, 4);
-            }
-        }
-    };
-    if (lo + slot < hi) fetch(lo + slot);
-    for (long long item = lo + slot; item < hi; item += per_xcd) {
-        const size_t fidx = (size_t)item;
-
-        // ---- stage 0: exact integer window sums of the fetched pixels
-        unsigned ia = 0, ib = 0;
-#pragma unroll
-        for (int q = 0; q < DPT; ++q) {
-            ia = __builtin_amdgcn_sad_u8(da[q], 0u, ia);
-            ib = __builtin_amdgcn_sad_u8(db[q], 0u, ib);
-        }
-        {      // both window sums in one reduction (each is below 2^21)
-            auto uadd = [](unsigned long long a, unsigned long long b) { return a + b; };
-            const unsigned long long s2 = wg_reduce<G::NW>((unsigned long long)ia | ((unsigned long long)ib << 32), uadd, sm.redu);
-            ia = (unsigned)s2;
-            ib = (unsigned)(s2 >> 32);
-        }
-        const bool dead = ia == 0u || ib == 0u;          // zero-mean window: 0/0 = NaN map in the reference
-        const double ma = (double)ia / (double)NN, mb = (double)ib / (double)NN;      // torch.mean: exact sum / n
-        // a / mean(a) (B:513-514) as one reciprocal per window plus a residual correction per pixel:
-        // q = a r, q += (a - q m) r  -- the correctly rounded quotient (the residual is exact in an fma)
-        // at a fifth of the instructions of 32 float64 divisions per thread
-        const double ra = dead ? 0.0 : 1.0 / ma, rb = dead ? 0.0 : 1.0 / mb;
-        auto quot = [](double a, double m, double r) {
-            const double q = a * r;
-            return __fma_rn(__fma_rn(-q, m, a), r, q);
-        };
-#pragma unroll
-        for (int q = 0; q < DPT; ++q) {
-            const int i = tid + q * NT;
-            if (i < NDW) {
-                const int y = i / (WS / 4), x4 = (i % (WS / 4)) * 4;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double a = (double)((da[q] >> (8 * k)) & 0xffu), b = (double)((db[q] >> (8 * k)) & 0xffu);
-                    sm.z[y * P + x4 + k] = cz{quot(a, ma, ra), quot(b, mb, rb)};
-                }
-            }
-        }
-        lds_barrier();
-        if (item + per_xcd < hi) fetch(item + per_xcd);      // in flight during the transforms
-
-        // ---- forward 2-D transform of a + i b, in place: bin (ky, kx) ends at [pos(ky)][pos(kx)]
-        transform<WS, WS, false, true>(sm);
-        transform<WS, WS, true, true>(sm);
-
-        // ---- cross-spectrum P = conj(A) B / n^2 of the packed transform; one thread per pair {k, -k}
-        {
-            constexpr double SC = 0.25 / (double)NN;       // 1/4 of the un-packing, 1/n^2 of the inverse (exact)
-            // digit reversal in closed form (two stages: radix R1 = 8, then WS / 8): bin <-> position are digit
-            // swaps, so the partner cell needs no table look-up (four dependent LDS reads per element before)
-            constexpr int R1 = WS >= 8 ? 8 : WS, R2 = WS / R1;
-            auto bin_of = [](int p_) { return (p_ % R2) * R1 + p_ / R2; };
-            auto pos_of_ = [](int k_) { return (k_ % R1) * R2 + k_ / R1; };
-            for (int e = tid; e < NN; e += NT) {
-                const int py = e / WS, px = e % WS;
-                const int ky = bin_of(py), kx = bin_of(px);
-                const int qy = pos_of_((WS - ky) % WS), qx = pos_of_((WS - kx) % WS);
-                const int e2 = qy * WS + qx;
-                if (e2 < e) continue;                      // the partner's thread writes both cells
-                const int a1 = py * P + px, a2 = qy * P + qx;
-                const cz zk = sm.z[a1], zm = sm.z[a2];
-                const double a_ = zk.x, b_ = zk.y, c_ = zm.x, d_ = zm.y;
-                // Z(k) = a + ib, Z(-k) = c + id:  4 P(k) = 2 (a d + b c) + i ((c^2 - a^2) + (d^2 - b^2))
-                const double pr = (a_ * d_ + b_ * c_) * (2.0 * SC);
-                const double pi = ((c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_)) * SC;
-                sm.z[a1] = cz{pr, pi};
-                if (e2 != e) sm.z[a2] = cz{pr, -pi};       // P(-k) = conj P(k)
-            }
-            lds_barrier();
-        }
-
-        // ---- inverse 2-D transform: natural order out; the map is the real plane
-        transform<WS, WS, true, false>(sm);
-        transform<WS, WS, false, false>(sm);
-
-        // ---- peak analysis in fftshift coordinates (y' = (y + WS/2) % WS, x' likewise), float64.
-        //      A thread's cells (e = tid + k NT) stay in registers through the three scans: one read of the
-        //      real parts and one write of the finished map instead of four passes over the tile.
-        auto dmin = [](double a, double b) { return a < b ? a : b; };
-        constexpr int CPT = (NN + NT - 1) / NT;            // cells per thread
-        double cv[CPT];
-        double cmin = 1.7e308;
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int e = tid + k * NT;
-            cv[k] = e < NN ? sm.z[(e / WS) * P + e % WS].x : 1.7e308;
-            cmin = dmin(cmin, cv[k]);
-        }
-        cmin = wg_reduce<G::NW>(cmin, dmin, sm.redd);
-        double bv = -1.0;
-        int bf = NN;
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int e = tid + k * NT;
-            if (e >= NN) break;
-            const int y = e / WS, x = e % WS;
-            const double v = __dadd_rn(__dsub_rn(cv[k], cmin), 1e-7);      // B:518, B:381
-            cv[k] = v;
-            sm.z[y * P + x].x = v;
-            const int f = ((y + WS / 2) % WS) * WS + (x + WS / 2) % WS;
-            if (v > bv || (v == bv && f < bf)) {
-                bv = v;
-                bf = f;
-            }
-        }
-        const double gmax = wg_reduce<G::NW>(bv, [](double a, double b) { return a > b ? a : b; }, sm.redd + 8);
-        auto imin = [](int a, int b) { return a < b ? a : b; };
-        const int m = wg_reduce<G::NW>(bv == gmax ? bf : NN, imin, sm.redi);           // first flat index (B:383)
-        // (two cheap VALU reductions; a fused (value, index) key would need a three-dword exchange per step)
-        // (the reductions above also order the map writes before the neighbour reads below)
-        const int wv = p.val_win;
-        const int my = m / WS, mx = m % WS;
-        double sv = -1.0;
-#pragma unroll
-        for (int k = 0; k < CPT; ++k) {
-            const int e = tid + k * NT;
-            if (e >= NN) break;
-            const int y = e / WS, x = e % WS;
-            const int fy = (y + WS / 2) % WS, fx = (x + WS / 2) % WS;
-            const int f = fy * WS + fx;
-            // f in {clamp(m + i + WS j), |i|, |j| <= wv} (B:352-357): in row fy the columns mx + i (j = fy - my),
-            // mx + i + WS (j = fy - my - 1 ... the row wrap) and mx + i - WS, plus the two clamps
-            const int dj = fy - my;
-            bool excl = false;
-            if (dj >= -wv && dj <= wv) excl |= (fx >= mx - wv && fx <= mx + wv);
-            if (dj + 1 >= -wv && dj + 1 <= wv) excl |= (fx >= mx - wv + WS && fx <= mx + wv + WS);
-            if (dj - 1 >= -wv && dj - 1 <= wv) excl |= (fx >= mx - wv - WS && fx <= mx + wv - WS);
-            if (f == 0 && (m - wv - wv * WS) <= 0) excl = true;
-            if (f == NN - 1 && (m + wv + wv * WS) >= NN - 1) excl = true;
-            if (!excl && cv[k] > sv) sv = cv[k];
-        }
-        sv = wg_reduce<G::NW>(sv, [](double a, double b) { return a > b ? a : b; }, sm.redd);
-        if (tid < 8) {
-            int left = m + 1, right = m - 1, top = m + WS, bot = m - WS;      // B:385-392 (flat index)
-            if (left >= NN - 1) left = m;
-            if (right <= 0) right = m;
-            if (top >= NN - 1) top = m;
-            if (bot <= 0) bot = m;
-            int q = m;
-            q = (tid == 1) ? left : q;
-            q = (tid == 2) ? right : q;
-            q = (tid == 3) ? top : q;
-            q = (tid == 4) ? bot : q;
-            const int ys = q / WS, xs = q % WS;                               // shifted -> stored coordinates
-            double outv = sm.z[((ys + WS / 2) % WS) * P + (xs + WS / 2) % WS].x;
-            // nothing left outside the exclusion zone: the reference's second arg-max runs over the zeroed
-            // map, whose float64 storage `cor` aliases in pass 1 (B:382): c[m2] = 0, ratio = +inf
-            outv = (tid == 5) ? (sv >= 0.0 ? sv : 0.0) : outv;
-            outv = (tid == 6) ? (double)m : outv;
-            outv = (tid == 7) ? (dead ? 1.0 : 0.0) : outv;
-            reinterpret_cast<double*>(p.peak_raw)[fidx * 8 + tid] = outv;
-        }
-        lds_barrier();                                   // planes free for the next window
-    }
-}
-
-
 // =====================================================================================================
-// 64x64 windows, second generation: every 64-point line split over two lanes, 32-point in-register codelets,
-// the radix-2 steps folded into planar LDS transposes (scheme and per-thread arithmetic: xcorr_f64_split.hpp,
-// which the CPU suite runs thread by thread against numpy).  One window per 128-thread workgroup, one 33 KB
-// float64 plane, four workgroups per CU (two wavefronts per SIMD, <= 256 VGPRs).  The first generation above
-// kept the 16-byte elements in LDS and walked radix-8 stages over them: 35 ms per 256 pairs at 43 % LDS bank
-// conflicts and ~25 barriers per window (profiles/r02); it still serves 8 ... 32 pixel windows.
+// 64x64 and 128x128 windows: every line split over two threads, 32- / 64-point in-register codelets, the radix-2
+// steps folded into planar LDS transposes (scheme and per-thread arithmetic: xcorr_f64_split.hpp).
 // =====================================================================================================
 template <int W>
 struct F64SplitShared {
@@ -683,7 +294,7 @@ static hipError_t launch_f64_split(const PassParams& p, int n_cu, hipStream_t st
 }
 
 // =====================================================================================================
-// 8 ... 32 pixel windows, second generation: lane = one image row of a window, the whole line (WS complex float64
+// 8 ... 32 pixel windows: lane = one image row of a window, the whole line (WS complex float64
 // samples, frame a in the real part, frame b in the imaginary part) in registers -- the float32 tile kernel's scheme
 // (xcorr_tile.hpp) in float64.  A workgroup is ONE wavefront = 64 / WS windows: no barriers anywhere; LDS only
 // transposes between the row and the column transform, one float64 plane of WS x (WS + 1) per window at a time
@@ -995,34 +606,14 @@ static hipError_t launch_f64_tile(const PassParams& p, int n_cu, hipStream_t str
     return hipGetLastError();
 }
 
-template <int WS>
-hipError_t launch_f64(const PassParams& p, int n_cu, hipStream_t stream) {
-    const long long items = (long long)p.batch * p.n_rows * p.n_cols;
-    if (items <= 0) return hipErrorInvalidValue;
-    const int per_cu = WS == 64 ? 2 : (WS == 32 ? 8 : 16);      // LDS: 67.7 KB / 17.5 KB / ... per workgroup
-    long long blocks = items < (long long)n_cu * per_cu ? items : (long long)n_cu * per_cu;
-    blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((xcorr_f64_kernel<WS>), dim3((unsigned)blocks), dim3(F64Geo<WS>::NT), 0, stream, p);
-    return hipGetLastError();
-}
-
 }  // namespace
-
-// TPIV_F64_GEN1=1: the first-generation LDS-resident kernel (A/B runs)
-static bool gen1() {
-    static const bool v = [] {
-        const char* e = getenv("TPIV_F64_GEN1");
-        return e && e[0] == '1';
-    }();
-    return v;
-}
 
 hipError_t launch_xcorr_f64(const PassParams& p, int n_cu, hipStream_t stream) {
     switch (p.ws) {
-        case 8: return gen1() ? launch_f64<8>(p, n_cu, stream) : launch_f64_tile<8>(p, n_cu, stream);
-        case 16: return gen1() ? launch_f64<16>(p, n_cu, stream) : launch_f64_tile<16>(p, n_cu, stream);
-        case 32: return gen1() ? launch_f64<32>(p, n_cu, stream) : launch_f64_tile<32>(p, n_cu, stream);
-        case 64: return gen1() ? launch_f64<64>(p, n_cu, stream) : launch_f64_split<64>(p, n_cu, stream);
+        case 8: return launch_f64_tile<8>(p, n_cu, stream);
+        case 16: return launch_f64_tile<16>(p, n_cu, stream);
+        case 32: return launch_f64_tile<32>(p, n_cu, stream);
+        case 64: return launch_f64_split<64>(p, n_cu, stream);
         case 128: return launch_f64_split<128>(p, n_cu, stream);
         default: return hipErrorInvalidValue;
     }
