@@ -22,8 +22,8 @@
 //                        Y[y1 + 32 c][k] = G_0[y1] +- w64^-y1 G_1[y1]; the g = 1 threads multiply by w64^-y1
 //   T2  transposition    plane[32 g + y1][k] <- G; thread (y = lane, q = wv) reads spectrum columns 0..32 of its row
 //                        (the row is real: Hermitian spectrum) as G_0 +- G_1
-//   Ri  rows inverse     real 64-point row from a 32-point complex transform (c2r), itself split over the thread pair:
-//                        DIF halves of the 32 packed values, 16-point codelet: thread q holds corr[y][4n + 2q + {0, 1}]
+//   Ri  rows inverse     the real 64-point row split over the thread pair by output parity: the even / odd samples are
+//                        real 32-point rows themselves (c2r through a 16-point codelet): thread q holds corr[y][2n + q]
 //   P   peak analysis    on the float64 map (B:346-358, B:381-392, B:518), 8-double record for finalize_kernel<true>
 //
 // The odd halves carry 30 twiddle products per stage; the parities are assigned so that wave 0 takes them in the
@@ -358,32 +358,45 @@ struct Split {
         }
 #endif
     }
-    // ---- Ri: c2r pre-processing (both threads of the pair), DIF halves of the M packed values, M/2-point inverse codelet.
-    // Out: c[2n + e] = corr[y][4n + 2q + e], n = 0..M/2-1, e = 0, 1 (un-shifted column index).
-    static TPIV_HD void rows_inverse(cd (&Y)[M + 1], int q, double (&c)[M]) {
-        c2r_pre_d<W>(Y);                        // h[0..M) in Y[0..M)
-        cd e[M / 2];
+    // ---- Ri: the real W-point row from its Hermitian half spectrum Y[0..M], split over the thread pair by OUTPUT parity
+    // (decimation in time): with w = exp(2 pi i / W),
+    //     even samples  r[2n]   = IDFT_M(E)[n],  E[k] = Y[k] + Y[k + M]          = Y[k] + conj(Y[M - k])
+    //     odd  samples  r[2n+1] = IDFT_M(O)[n],  O[k] = (Y[k] - Y[k + M]) w^k    = (Y[k] - conj(Y[M - k])) w^k
+    // and E, O are Hermitian over length M again, i.e. each half is a real M-point row: c2r through an M/2-point complex
+    // codelet from the bins 0 .. M/2 (c2r_pre_d<M>).  Thread q takes the samples of parity q -- 90 float64 instructions
+    // per thread fewer than a W-point c2r pre-processing done by both threads followed by a split M-point transform.
+    // Out: c[2n + e] = corr[y][4n + 2e + q], n = 0..M/2-1, e = 0, 1 (un-shifted column index).
+    static TPIV_HD void rows_inverse(const cd (&Y)[M + 1], int q, double (&c)[M]) {
+        constexpr int H = M / 2;
+        cd g[H + 1];
         const double sq = q ? -1.0 : 1.0;
-        static_for<0, M / 2>([&](auto jc) TPIV_LAMBDA_INLINE {
-            constexpr int j = decltype(jc)::value;
-            e[j] = cd{Y[j].x + sq * Y[j + M / 2].x, Y[j].y + sq * Y[j + M / 2].y};
+        static_for<0, H + 1>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int k = decltype(kc)::value;
+            // Y[k] +- conj(Y[M - k])
+            g[k] = cd{Y[k].x + sq * Y[M - k].x, Y[k].y - sq * Y[M - k].y};
         });
         if (q) {
-            static_for<1, M / 2>([&](auto jc) TPIV_LAMBDA_INLINE {
-                constexpr int j = decltype(jc)::value;
-                e[j] = twmul_d<j, M, -1>(e[j]);
+            static_for<1, H + 1>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                g[k] = twmul_d<k, W, -1>(g[k]);
             });
         }
-        fft_inreg_d<M / 2, -1>(e);              // z[2n + q] at e[FFT_POS<n, M/2>]
-        static_for<0, M / 2>([&](auto nc) TPIV_LAMBDA_INLINE {
+        c2r_pre_d<M>(g);                        // packed values in g[0..H)
+        cd e[H];
+        static_for<0, H>([&](auto jc) TPIV_LAMBDA_INLINE {
+            constexpr int j = decltype(jc)::value;
+            e[j] = g[j];
+        });
+        fft_inreg_d<H, -1>(e);                  // r_q[2m] + i r_q[2m + 1] at e[FFT_POS<m, H>],  r_q[n] = corr[y][2n + q]
+        static_for<0, H>([&](auto nc) TPIV_LAMBDA_INLINE {
             constexpr int n = decltype(nc)::value;
-            c[2 * n] = e[FFT_POS<n, M / 2>].x;
-            c[2 * n + 1] = e[FFT_POS<n, M / 2>].y;
+            c[2 * n] = e[FFT_POS<n, H>].x;
+            c[2 * n + 1] = e[FFT_POS<n, H>].y;
         });
     }
 
     // ---- P: peak analysis in fftshift coordinates (y' = (y + W/2) % W, x' likewise).  Thread (y, q) holds
-    // c[2n + e] = corr[y][x = 4n + 2q + e].
+    // c[2n + e] = corr[y][x = 4n + 2e + q].
     // one pass over the raw cells gives their minimum AND their maximum: v = (c - min) + 1e-7 is monotonic in c, so the
     // maximum of the shifted cells is the shifted maximum (exactly: the same two roundings)
     static TPIV_HD void peak_local_minmax(const double (&c)[M], double& mn, double& mx) {
@@ -400,10 +413,10 @@ struct Split {
     // that row -- which keeps the scan free of compare / select chains.)
     static TPIV_HD void peak_shift_and_write(double (&c)[M], double cmin, double scale, int y, int q, double* plane) {
         const int fy = (y + W / 2) & (W - 1);
-        double* row = plane + fy * PL + 2 * q;
+        double* row = plane + fy * PL + q;
         static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
             constexpr int i = decltype(ic)::value;
-            constexpr int fx0 = (4 * (i >> 1) + (i & 1) + W / 2) & (W - 1);       // + 2 q: stays inside its group of four
+            constexpr int fx0 = (4 * (i >> 1) + 2 * (i & 1) + W / 2) & (W - 1);   // + q: stays inside its pair
             const double v = peak_shifted(c[i], cmin, scale);
             c[i] = v;
             row[fx0] = v;
@@ -429,19 +442,19 @@ struct Split {
         if (dj - 1 >= -wv && dj - 1 <= wv) span(mx - wv - W, mx + wv - W);
         if (fy == 0 && (m - wv - wv * W) <= 0) ex[0] |= 1ull;
         if (fy == W - 1 && (m + wv + wv * W) >= W * W - 1) ex[NW - 1] |= 1ull << 63;
-        // this thread's columns are fx0 + 2 q: shift the mask down by 2 q, the bit positions become compile-time constants
+        // this thread's columns are fx0 + q: shift the mask down by q, the bit positions become compile-time constants
         unsigned word[2 * NW];
 #pragma unroll
         for (int i = 0; i < NW; ++i) {
-            unsigned long long w_ = ex[i] >> (2 * q);
-            if (i + 1 < NW && q) w_ |= ex[i + 1] << 62;
+            unsigned long long w_ = ex[i] >> q;
+            if (i + 1 < NW && q) w_ |= ex[i + 1] << 63;
             word[2 * i] = (unsigned)w_;
             word[2 * i + 1] = (unsigned)(w_ >> 32);
         }
         double sv = -1.0;
         static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
             constexpr int i = decltype(ic)::value;
-            constexpr int fx0 = (4 * (i >> 1) + (i & 1) + W / 2) & (W - 1);
+            constexpr int fx0 = (4 * (i >> 1) + 2 * (i & 1) + W / 2) & (W - 1);
 #if defined(__HIP_DEVICE_COMPILE__)
             // sign-extended exclusion bit (0 / -1) -> sign bit of the value: excluded cells lose every comparison
             const int kill = __builtin_amdgcn_sbfe((int)word[fx0 >> 5], fx0 & 31, 1);
