@@ -93,7 +93,15 @@ TPIV_HD void pin(cd& z) {
 // (P = conj(A) B of the packed transform; the factor 0.25 / n^2 rides in the map scale, peak_shifted)
 TPIV_HD cd cross_bin(cd zk, cd zm) {
     const double a_ = zk.x, b_ = zk.y, c_ = zm.x, d_ = zm.y;
-    return cd{(a_ * d_ + b_ * c_) * 2.0, (c_ * c_ - a_ * a_) + (d_ * d_ - b_ * b_)};
+    // imaginary part as |Z(-k)|^2 - |Z(k)|^2: one multiply and three fused multiply-adds
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double n1 = __fma_rn(a_, a_, b_ * b_);
+    const double im = __fma_rn(c_, c_, __fma_rn(d_, d_, -n1));
+#else
+    const double im = (c_ * c_ + d_ * d_) - (a_ * a_ + b_ * b_);
+#endif
+    const double re = a_ * d_ + b_ * c_;
+    return cd{re + re, im};
 }
 // min / max of two finite doubles as ONE instruction (fmin / fmax are compiled to v_min_f64 / v_max_f64 plus a
 // canonicalising v_max_f64 x, x per operand -- sNaN quieting the map values never need: 100 float64 instructions per window)
