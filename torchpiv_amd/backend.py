@@ -432,10 +432,11 @@ class OfflinePIV:
         done.record()
         return done, host, (u, v, cls, counts)          # (the device tensors stay referenced until collected)
 
-    def _post_collect(self, ticket):
-        """Host half: drop decisions from the census, host triangulation for the pairs that hold an
-        ambiguous or wide hole (counted).  Returns one entry per pair: None (dropped) or (u, v) numpy
-        arrays before the flip / scaling."""
+    def _post_extract(self, ticket):
+        """Host half, first stage: drop decisions from the census; for the pairs that hold an ambiguous or wide hole
+        (counted) the ring points, their values and the hole cells are cut out of the batch in one sweep and handed to the
+        triangulation -- asynchronously when a worker pool is on (fill_workers > 0): the result is picked up by
+        _post_complete, normally a batch later.  Returns the state _post_complete takes."""
         done, host, _keep_alive = ticket
         done.synchronize()
         cnt = host[0].numpy().astype(np.int64)                       # [n, 4] holes, ring, ambiguous, general
@@ -450,17 +451,14 @@ class OfflinePIV:
         st["pairs"] += n
         st["dropped_no_invalid"] += int(no_ring.sum())
         st["dropped_too_many"] += int(too_many.sum())
+        st["device_complete"] += int((keep & ~need_host).sum())
         for _ in range(2 * int(too_many.sum())):                  # once for u, once for v (B:306, B:889-890)
             print(TOO_MANY_MSG)
-        out = [None] * n
-        for i in np.flatnonzero(keep & ~need_host):
-            st["device_complete"] += 1
-            out[int(i)] = (uk[i], vk[i])
-        need = np.flatnonzero(need_host)
-        if need.size:
-            # ring points, their values and the hole cells of ALL pairs of the batch that need the triangulation, in one
-            # sweep (np.argwhere over the stack lists pair after pair, row-major inside a pair: the reference's order)
-            holes = (ck[need] >= 1) & (ck[need] <= 4)
+        state = {"uk": uk, "vk": vk, "keep": keep, "need": np.flatnonzero(need_host), "host": host, "pending": None}
+        if state["need"].size:
+            # (np.argwhere over the stack lists pair after pair, row-major inside a pair: the reference's order)
+            holes = (ck >= 1) & (ck <= 4)
+            holes[~need_host] = False
             rings = np.zeros_like(holes)
             rings[:, 1:, :] |= holes[:, :-1, :]
             rings[:, :-1, :] |= holes[:, 1:, :]
@@ -468,48 +466,96 @@ class OfflinePIV:
             rings[:, :, :-1] |= holes[:, :, 1:]
             rings &= ~holes
             hp, rp = np.argwhere(holes), np.argwhere(rings)
-            vals = np.stack([uk[need][rings], vk[need][rings]], axis=1)
-            h_cut = np.searchsorted(hp[:, 0], np.arange(need.size + 1))
-            r_cut = np.searchsorted(rp[:, 0], np.arange(need.size + 1))
+            vals = np.stack([uk[rings], vk[rings]], axis=1)
+            edges = np.append(state["need"], n)
+            h_cut, r_cut = np.searchsorted(hp[:, 0], edges), np.searchsorted(rp[:, 0], edges)
             jobs = [(rp[r_cut[k]:r_cut[k + 1], 1:], vals[r_cut[k]:r_cut[k + 1]], hp[h_cut[k]:h_cut[k + 1], 1:])
-                    for k in range(need.size)]
+                    for k in range(state["need"].size)]
+            state["hp"], state["h_cut"] = hp, h_cut
             pool = self._fill_pool()
             if pool is not None:
                 per = max(1, -(-len(jobs) // (2 * self.fill_workers)))          # two tasks per worker and batch
-                chunks = [jobs[k:k + per] for k in range(0, len(jobs), per)]
-                sols = [s_ for part in pool.map(qhull_fill_many, chunks) for s_ in part]
+                state["pending"] = pool.map_async(qhull_fill_many, [jobs[k:k + per] for k in range(0, len(jobs), per)])
             else:
-                sols = qhull_fill_many(jobs)
+                state["sols"] = qhull_fill_many(jobs)
+        return state
+
+    def _post_complete(self, state):
+        """Second stage: the triangulation's values go into the fields.  Returns one entry per pair: None (dropped) or
+        (u, v) numpy views before the flip / scaling."""
+        uk, vk, keep, need = state["uk"], state["vk"], state["keep"], state["need"]
+        out = [(uk[i], vk[i]) if keep[i] else None for i in range(uk.shape[0])]
+        if need.size:
+            sols = state["sols"] if state["pending"] is None else [s_ for part in state["pending"].get() for s_ in part]
+            hp, h_cut, st = state["hp"], state["h_cut"], self.stats
             for k, vals_k in enumerate(sols):
                 i = int(need[k])
                 st["host_fallback"] += 1
                 if vals_k is None:
                     st["dropped_by_qhull"] += 1
+                    out[i] = None
                     continue
                 cells = hp[h_cut[k]:h_cut[k + 1], 1:]
                 uk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 0]
                 vk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 1]
-                out[i] = (uk[i], vk[i])
         return out
+
+    def _post_collect(self, ticket):
+        """Both host stages at once (the one-pair path)."""
+        return self._post_complete(self._post_extract(ticket))
 
     def _post_validate_batch(self, u, v, inv):
         return self._post_collect(self._post_submit(u, v, inv))
 
+    def _post_pipeline(self, x, y):
+        """The host side of batched() as a three-stage pipeline: push(meta, ticket) after every launch returns the finished
+        entries [(meta, per-pair results)] that have come out at the other end -- while the GPU works on batch k, the
+        census / extraction of batch k-1 runs here and the worker pool triangulates it; its values are filled in, flipped
+        and scaled one push later.  flush() drains."""
+        stage1, stage2 = [], []          # tickets waiting for _post_extract / states waiting for _post_complete
+
+        def step():
+            out = []
+            if stage2:
+                meta, state = stage2.pop(0)
+                out.append((meta, self._finish_batch(self._post_complete(state), x, y) if state is not None else []))
+            if stage1:
+                meta, ticket = stage1.pop(0)
+                stage2.append((meta, self._post_extract(ticket) if ticket is not None else None))
+            return out
+
+        class Pipe:
+            def push(_, meta, ticket):
+                out = step()
+                stage1.append((meta, ticket))
+                return out
+
+            def flush(_):
+                out = []
+                while stage1 or stage2:
+                    out += step()
+                return out
+        return Pipe()
+
     def _finish_batch(self, outs, x, y):
-        """Flip and unit scaling of B:894-898 for the pairs of one batch at once.  `outs` is what _post_collect returned:
-        per pair None or (u, v) views into the batch's [n, n_rows, n_cols] arrays; the reference's expressions
-        (u * scale / dt * 1000: three roundings, in that order) are applied to the whole stack -- one numpy pass each instead
-        of five small ones per pair.  Returns per pair None or (x, y, u, v); x, y are one pair of read-only arrays per batch
-        (the reference makes fresh copies per pair; a caller that wants to write into them copies first)."""
+        """Flip and unit scaling of B:894-898 for the pairs of one batch at once.  `outs` is what _post_complete returned:
+        per pair None or (u, v) views into the batch's [n, n_rows, n_cols] arrays.  The reference's expressions (u = flip(u);
+        v = -flip(v); u * scale / dt * 1000: three roundings, in that order) are applied to the whole stack IN PLACE after
+        one flipping copy -- fresh 4 MB temporaries cost more in page faults than the arithmetic.  Returns per pair None or
+        (x, y, u, v); x, y are one pair of read-only arrays per batch (the reference makes fresh copies per pair; a caller
+        that wants to write into them copies first)."""
+        if outs is None:
+            return []
         kept = [k for k, uv in enumerate(outs) if uv is not None]
         if not kept:
             return [None] * len(outs)
-        U = np.stack([outs[k][0] for k in kept]) if len(kept) > 1 else outs[kept[0]][0][None]
-        V = np.stack([outs[k][1] for k in kept]) if len(kept) > 1 else outs[kept[0]][1][None]
-        U = np.flip(U, axis=1)
-        V = -np.flip(V, axis=1)
-        U = U * self._scale / self._dt * 1000
-        V = V * self._scale / self._dt * 1000
+        U = np.stack([outs[k][0][::-1] for k in kept])
+        V = np.stack([outs[k][1][::-1] for k in kept])
+        np.negative(V, out=V)
+        for arr in (U, V):
+            np.multiply(arr, self._scale, out=arr)
+            np.divide(arr, self._dt, out=arr)
+            np.multiply(arr, 1000, out=arr)
         xs, ys = x * self._scale, y * self._scale
         xs.flags.writeable = False
         ys.flags.writeable = False
@@ -671,14 +717,16 @@ class OfflinePIV:
         dev = self._device
         pending = None
 
-        def drain(pend):
-            """Results of a finished batch in dataset order; the pairs that were not staged run now."""
-            order, chunk, ticket = pend
-            res = iter(self._finish_batch(self._post_collect(ticket), x, y)) if chunk else iter(())
-            for i, staged in order:
-                out = next(res) if staged else self._one(i)
-                if out is not None:
-                    yield (i,) + out
+        pipe = self._post_pipeline(x, y)
+
+        def emit(finished):
+            """Results of finished batches in dataset order; the pairs that were not staged run now."""
+            for (order, chunk), res in finished:
+                res = iter(res)
+                for i, staged in order:
+                    out = next(res) if staged else self._one(i)
+                    if out is not None:
+                        yield (i,) + out
 
         try:
             while True:
@@ -697,15 +745,12 @@ class OfflinePIV:
                     frames = engine.bmp_unpack(raw_d.view(-1), desc_d, lut_d, H, W)      # [2n, H, W]: a_0..a_n-1, b_0..b_n-1
                     u, v, inv = plan.run(frames[:n], frames[n:])
                     ticket = self._post_submit(u, v, inv)
-                # the host work of the PREVIOUS batch runs while the GPU works on this one
-                if pending is not None:
-                    yield from drain(pending)
-                pending = (order, chunk, ticket)
+                # the host work of the PREVIOUS batches runs while the GPU works on this one
+                yield from emit(pipe.push((order, chunk), ticket))
                 if chunk:
                     up.synchronize()                  # staging buffer may be refilled now
                 free[buf].set()
-            if pending is not None:
-                yield from drain(pending)
+            yield from emit(pipe.flush())
         finally:
             # consumer finished, raised, or abandoned the generator (GeneratorExit lands here): release the
             # loader -- it may sit in a full queue or wait for a staging buffer -- and let it end
@@ -756,7 +801,14 @@ class ResidentPIV(OfflinePIV):
         w, o, _, _ = plan.geometry[-1]
         x, y = get_coordinates((H, W), w, o)
         contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
-        pending = None
+        pipe = self._post_pipeline(x, y)
+
+        def emit(finished):
+            for chunk_ids, res in finished:
+                for i, out in zip(chunk_ids, res):
+                    if out is not None:
+                        yield (i,) + out
+
         for s in range(0, len(idx), batch_size):
             chunk = idx[s:s + batch_size]
             if contiguous:
@@ -765,16 +817,9 @@ class ResidentPIV(OfflinePIV):
                 sel = torch.tensor(chunk, device=self._device)
                 A, B = self._A.index_select(0, sel), self._B.index_select(0, sel)
             u, v, inv = plan.run(A, B)
-            ticket = self._post_submit(u, v, inv)
-            if pending is not None:          # host work of the previous batch overlaps this batch's kernels
-                for i, out in zip(pending[0], self._finish_batch(self._post_collect(pending[1]), x, y)):
-                    if out is not None:
-                        yield (i,) + out
-            pending = (chunk, ticket)
-        if pending is not None:
-            for i, out in zip(pending[0], self._finish_batch(self._post_collect(pending[1]), x, y)):
-                if out is not None:
-                    yield (i,) + out
+            # host work of the previous batches overlaps this batch's kernels
+            yield from emit(pipe.push(chunk, self._post_submit(u, v, inv)))
+        yield from emit(pipe.flush())
 
     def __call__(self) -> Generator:
         for _, x, y, u, v in self.batched(1):
