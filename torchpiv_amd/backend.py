@@ -420,17 +420,23 @@ class OfflinePIV:
         self._single_plans = {}
 
     def _post_submit(self, u, v, inv):
-        """Device half of B:884-892 for a batch of final fields (u, v float64 [n, nr, nc], modified in
-        place; inv uint8): tpiv_postval, then ASYNCHRONOUS copies of the census, the fields and the
-        class map into pinned memory.  Nothing here waits for the GPU: the caller may enqueue the next
-        batch before it collects this one."""
+        """Device half of B:884-898 for a batch of final fields (u, v float64 [n, nr, nc], modified in
+        place; inv uint8): tpiv_postval, the flip and the unit scaling of B:894-898 (the reference's own float64
+        expressions -- u * scale / dt * 1000, three correctly rounded operations -- evaluated by the device on the whole
+        batch: bit-identical, and the host is spared five passes over every field), then ASYNCHRONOUS copies of the census,
+        the raw fields (the triangulation of the hole fill works on the unscaled ring values, like the reference), the
+        finished fields and the class map into pinned memory.  Nothing here waits for the GPU: the caller may enqueue the
+        next batch before it collects this one."""
         cls, counts = engine.postval(u, v, inv)
-        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in (counts, u, v, cls)]
-        for h, t in zip(host, (counts, u, v, cls)):
+        fu = torch.flip(u, dims=(1,)) * self._scale / self._dt * 1000
+        fv = -torch.flip(v, dims=(1,)) * self._scale / self._dt * 1000
+        src = (counts, u, v, cls, fu, fv)
+        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in src]
+        for h, t in zip(host, src):
             h.copy_(t, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return done, host, (u, v, cls, counts)          # (the device tensors stay referenced until collected)
+        return done, host, src          # (the device tensors stay referenced until collected)
 
     def _post_extract(self, ticket):
         """Host half, first stage: drop decisions from the census; for the pairs that hold an ambiguous or wide hole
@@ -475,94 +481,87 @@ class OfflinePIV:
             pool = self._fill_pool()
             if pool is not None:
                 per = max(1, -(-len(jobs) // (2 * self.fill_workers)))          # two tasks per worker and batch
-                state["pending"] = pool.map_async(qhull_fill_many, [jobs[k:k + per] for k in range(0, len(jobs), per)])
+                # (synchronous: with map_async the pool's handler threads compete with this thread for the GIL and
+                #  the whole host side got slower -- 6.5 k -> 4.8 k pairs/s)
+                state["sols"] = [s_ for part in pool.map(qhull_fill_many, [jobs[k:k + per] for k in range(0, len(jobs), per)])
+                                 for s_ in part]
             else:
                 state["sols"] = qhull_fill_many(jobs)
         return state
 
     def _post_complete(self, state):
-        """Second stage: the triangulation's values go into the fields.  Returns one entry per pair: None (dropped) or
-        (u, v) numpy views before the flip / scaling."""
-        uk, vk, keep, need = state["uk"], state["vk"], state["keep"], state["need"]
-        out = [(uk[i], vk[i]) if keep[i] else None for i in range(uk.shape[0])]
+        """Second stage: the triangulation's values go into the raw fields and -- flipped and scaled with the reference's
+        expressions, cell by cell -- into the finished ones.  Returns the per-pair keep flags (False: dropped)."""
+        uk, vk, keep, need = state["uk"], state["vk"], state["keep"].copy(), state["need"]
         if need.size:
             sols = state["sols"] if state["pending"] is None else [s_ for part in state["pending"].get() for s_ in part]
             hp, h_cut, st = state["hp"], state["h_cut"], self.stats
+            fu, fv = state["host"][4].numpy(), state["host"][5].numpy()
+            nr = uk.shape[1]
             for k, vals_k in enumerate(sols):
                 i = int(need[k])
                 st["host_fallback"] += 1
                 if vals_k is None:
                     st["dropped_by_qhull"] += 1
-                    out[i] = None
+                    keep[i] = False
                     continue
                 cells = hp[h_cut[k]:h_cut[k + 1], 1:]
                 uk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 0]
                 vk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 1]
-        return out
+                fu[i][nr - 1 - cells[:, 0], cells[:, 1]] = vals_k[:, 0] * self._scale / self._dt * 1000
+                fv[i][nr - 1 - cells[:, 0], cells[:, 1]] = -vals_k[:, 1] * self._scale / self._dt * 1000
+        state["keep_final"] = keep
+        return state
 
     def _post_collect(self, ticket):
-        """Both host stages at once (the one-pair path)."""
-        return self._post_complete(self._post_extract(ticket))
+        """Both host stages at once; per pair None (dropped) or the raw (u, v) before the flip / scaling."""
+        state = self._post_complete(self._post_extract(ticket))
+        return [(state["uk"][i], state["vk"][i]) if state["keep_final"][i] else None for i in range(state["uk"].shape[0])]
 
     def _post_validate_batch(self, u, v, inv):
         return self._post_collect(self._post_submit(u, v, inv))
 
     def _post_pipeline(self, x, y):
-        """The host side of batched() as a three-stage pipeline: push(meta, ticket) after every launch returns the finished
-        entries [(meta, per-pair results)] that have come out at the other end -- while the GPU works on batch k, the
-        census / extraction of batch k-1 runs here and the worker pool triangulates it; its values are filled in, flipped
-        and scaled one push later.  flush() drains."""
-        stage1, stage2 = [], []          # tickets waiting for _post_extract / states waiting for _post_complete
+        """The host side of batched() as a two-stage pipeline: push(meta, ticket) after every launch returns the finished
+        entries [(meta, per-pair results)] of the batch pushed before -- while the GPU works on batch k, the census, the
+        triangulations (worker pool) and the patching of batch k-1 run here.  flush() drains."""
+        waiting = []
 
         def step():
             out = []
-            if stage2:
-                meta, state = stage2.pop(0)
-                out.append((meta, self._finish_batch(self._post_complete(state), x, y) if state is not None else []))
-            if stage1:
-                meta, ticket = stage1.pop(0)
-                stage2.append((meta, self._post_extract(ticket) if ticket is not None else None))
+            if waiting:
+                meta, ticket = waiting.pop(0)
+                res = self._finish_batch(self._post_complete(self._post_extract(ticket)), x, y) if ticket is not None else []
+                out.append((meta, res))
             return out
 
         class Pipe:
             def push(_, meta, ticket):
                 out = step()
-                stage1.append((meta, ticket))
+                waiting.append((meta, ticket))
                 return out
 
             def flush(_):
                 out = []
-                while stage1 or stage2:
+                while waiting:
                     out += step()
                 return out
         return Pipe()
 
-    def _finish_batch(self, outs, x, y):
-        """Flip and unit scaling of B:894-898 for the pairs of one batch at once.  `outs` is what _post_complete returned:
-        per pair None or (u, v) views into the batch's [n, n_rows, n_cols] arrays.  The reference's expressions (u = flip(u);
-        v = -flip(v); u * scale / dt * 1000: three roundings, in that order) are applied to the whole stack IN PLACE after
-        one flipping copy -- fresh 4 MB temporaries cost more in page faults than the arithmetic.  Returns per pair None or
+    def _finish_batch(self, state, x, y):
+        """The finished tuples of a batch: the device has flipped and scaled the fields (_post_submit), the host stage has
+        patched the filled cells (_post_complete); what is left is ONE copy of the two stacks out of the pinned staging
+        memory (so that results a caller keeps do not pin pages) and the per-pair views.  Returns per pair None or
         (x, y, u, v); x, y are one pair of read-only arrays per batch (the reference makes fresh copies per pair; a caller
         that wants to write into them copies first)."""
-        if outs is None:
-            return []
-        kept = [k for k, uv in enumerate(outs) if uv is not None]
-        if not kept:
-            return [None] * len(outs)
-        U = np.stack([outs[k][0][::-1] for k in kept])
-        V = np.stack([outs[k][1][::-1] for k in kept])
-        np.negative(V, out=V)
-        for arr in (U, V):
-            np.multiply(arr, self._scale, out=arr)
-            np.divide(arr, self._dt, out=arr)
-            np.multiply(arr, 1000, out=arr)
+        keep = state["keep_final"]
+        if not keep.any():
+            return [None] * keep.size
+        U, V = np.array(state["host"][4].numpy()), np.array(state["host"][5].numpy())
         xs, ys = x * self._scale, y * self._scale
         xs.flags.writeable = False
         ys.flags.writeable = False
-        res = [None] * len(outs)
-        for j, k in enumerate(kept):
-            res[k] = (xs, ys, U[j], V[j])
-        return res
+        return [(xs, ys, U[k], V[k]) if keep[k] else None for k in range(keep.size)]
 
     def _finish(self, uv, x, y):
         """Flip and unit scaling of B:894-898 (numpy, the reference's own expressions)."""
