@@ -195,6 +195,14 @@ int tpiv_ensemble_moments(const double* u_dev, const double* v_dev, int n, long 
 int tpiv_bmp_unpack(const uint8_t* raw_dev, const int64_t* desc_dev, const uint8_t* lut_dev, int n_files,
                     int H, int W, uint8_t* out_dev, void* stream);
 
+/* Host side of the ingest (no GPU involved): reads n_files files into dst + i * slot_bytes (page-locked staging memory
+ * of the caller, at most slot_bytes each) with up to n_threads native reader threads -- what PIVDataset.__getitem__
+ * (B:129-144) does file by file with np.fromfile, here for a whole batch without the interpreter in the loop.
+ * sizes[i] = bytes read, or -1 when the file cannot be opened / read or does not fit the slot (the caller then takes
+ * its per-file path, which skips an undecodable pair like B:138-139).  Returns TPIV_OK (per-file failures are not errors). */
+int tpiv_read_files(const char* const* paths, int n_files, uint8_t* dst, size_t slot_bytes, int n_threads,
+                    int64_t* sizes);
+
 /* ---- measurement ------------------------------------------------------------------ */
 
 /* Per-kernel timing with hipEvents recorded on the run's own stream (torch.cuda.Event only

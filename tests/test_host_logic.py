@@ -335,3 +335,36 @@ def test_fast_hole_fill_is_the_reference_interpolator_bit_for_bit():
         n_nan += int(np.isnan(ref).sum())
     print(f"  {n_masks} masks, {n_vals} filled values bit-identical ({n_nan} NaN outside the hull), {n_refused} rings refused by Qhull")
     assert n_masks > 500 and n_nan > 0 and n_refused > 0
+
+
+def test_batch_reader_agrees_with_the_per_file_path(tmp_path):
+    """tpiv_read_files + the vectorised header sweep (io.stage_batch) against io.stage_raw file by file: same bytes
+    in the slot, same layout and grey table for the plain BMPs; everything else is handed back (None)."""
+    from PIL import Image
+
+    from torchpiv_amd import io as pio
+    rng = np.random.default_rng(5)
+    H, W = 37, 50
+    paths = []
+    for i in range(5):
+        Image.fromarray(rng.integers(0, 256, size=(H, W)).astype(np.uint8), "L").save(tmp_path / f"f{i}.bmp")
+        paths.append(str(tmp_path / f"f{i}.bmp"))
+    pal = Image.fromarray(rng.integers(0, 256, size=(H, W)).astype(np.uint8), "P")
+    pal.putpalette(list(rng.integers(0, 256, size=768)))
+    pal.save(tmp_path / "p.bmp")
+    Image.fromarray(rng.integers(0, 256, size=(H, W, 3)).astype(np.uint8), "RGB").save(tmp_path / "c.bmp")
+    Image.fromarray(rng.integers(0, 256, size=(H + 1, W)).astype(np.uint8), "L").save(tmp_path / "other_shape.bmp")
+    (tmp_path / "bad.bmp").write_bytes(b"BMnot")
+    Image.fromarray(rng.integers(0, 256, size=(H, W)).astype(np.uint8), "L").save(tmp_path / "x.png")
+    paths += [str(tmp_path / n) for n in ("p.bmp", "c.bmp", "other_shape.bmp", "bad.bmp", "x.png", "missing.bmp")]
+    cap = 8192
+    raw, raw2 = np.zeros((len(paths), cap), np.uint8), np.zeros((len(paths), cap), np.uint8)
+    lays = pio.stage_batch(paths, raw, H, W, threads=3)
+    assert [lay is not None for lay in lays] == [True] * 7 + [False] * 4
+    for j in range(7):
+        ref = pio.stage_raw(paths[j], raw2[j], H, W)
+        assert lays[j][:4] == ref[:4] and np.array_equal(lays[j][4], ref[4])
+        assert np.array_equal(raw[j], raw2[j])
+    # a slot smaller than the file: handed back, nothing written past the slot
+    small = np.zeros((1, 1024), np.uint8)
+    assert pio.stage_batch(paths[:1], small, H, W) == [None]

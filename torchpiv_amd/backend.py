@@ -626,7 +626,7 @@ class OfflinePIV:
         the current batch (double buffered).  Yields (pair_index, x, y, u, v); dropped pairs yield nothing."""
         import queue
         import threading
-        from .io import stage_raw
+        from .io import stage_batch, stage_raw
         idx = list(range(len(self._dataset))) if indices is None else list(indices)
         if not idx:
             return
@@ -669,43 +669,48 @@ class OfflinePIV:
 
         def loader():
             from concurrent.futures import ThreadPoolExecutor
+            readers = ThreadPoolExecutor(max_workers=self.read_threads)       # host decode of the non-BMP files only
             try:
-                # file reads release the GIL (readinto straight into pinned memory): a few reader threads
-                # overlap the page-cache / disk copies of a batch
-                with ThreadPoolExecutor(max_workers=self.read_threads) as ex:
-                    for n, s0 in enumerate(range(0, len(idx), batch_size)):
-                        buf = n % 2
-                        while not free[buf].wait(0.2):
-                            if stop.is_set():
-                                return
+                for n, s0 in enumerate(range(0, len(idx), batch_size)):
+                    buf = n % 2
+                    while not free[buf].wait(0.2):
                         if stop.is_set():
                             return
-                        free[buf].clear()
-                        raw = stage[buf].numpy()
-                        ids = idx[s0:s0 + batch_size]
-                        tasks = []
-                        for k, i in enumerate(ids):
-                            pa, pb = self._dataset.img_pairs[i][0], self._dataset.img_pairs[i][-1]
-                            tasks += [(pb, raw[2 * k + 1]), (pa, raw[2 * k])]       # (the reference reads b first)
-                        lays = list(ex.map(lambda t: stage_raw(t[0], t[1], H, W), tasks))
-                        chunk, desc_a, desc_b, lut_a, lut_b, order = [], [], [], [], [], []
-                        for k, i in enumerate(ids):
-                            lb, la = lays[2 * k], lays[2 * k + 1]
-                            order.append((i, la is not None and lb is not None))
-                            if la is None or lb is None:
-                                # not stageable (undecodable, or a frame shape other than the batch's): the pair
-                                # takes the one-pair path when its turn comes -- which skips an undecodable
-                                # pair like B:138-139 and gives another shape its own plan
-                                continue
-                            desc_a.append([2 * k * cap, la[0], la[1], la[2], la[3], 0])
-                            desc_b.append([(2 * k + 1) * cap, lb[0], lb[1], lb[2], lb[3], 0])
-                            lut_a.append(la[4])
-                            lut_b.append(lb[4])
-                            chunk.append(i)
-                        # unpacked frame order: every a of the batch, then every b (two contiguous stacks)
-                        if not put((buf, len(ids), chunk, desc_a + desc_b, lut_a + lut_b, order)):
-                            return
+                    if stop.is_set():
+                        return
+                    free[buf].clear()
+                    raw = stage[buf].numpy()
+                    ids = idx[s0:s0 + batch_size]
+                    # slot 2k: frame a of pair k, slot 2k + 1: frame b.  One native call reads the whole batch (reader
+                    # threads of the library, GIL released) and the headers are parsed in one numpy sweep; files that are
+                    # not plain uncompressed BMPs of the batch's shape take the per-file path (host decode)
+                    paths = []
+                    for i in ids:
+                        paths += [self._dataset.img_pairs[i][0], self._dataset.img_pairs[i][-1]]
+                    lays = stage_batch(paths, raw[:len(paths)], H, W, threads=self.read_threads)
+                    rest = [j for j, lay in enumerate(lays) if lay is None]
+                    if rest:
+                        for j, lay in zip(rest, readers.map(lambda j: stage_raw(paths[j], raw[j], H, W), rest)):
+                            lays[j] = lay
+                    chunk, desc_a, desc_b, lut_a, lut_b, order = [], [], [], [], [], []
+                    for k, i in enumerate(ids):
+                        la, lb = lays[2 * k], lays[2 * k + 1]
+                        order.append((i, la is not None and lb is not None))
+                        if la is None or lb is None:
+                            # not stageable (undecodable, or a frame shape other than the batch's): the pair
+                            # takes the one-pair path when its turn comes -- which skips an undecodable
+                            # pair like B:138-139 and gives another shape its own plan
+                            continue
+                        desc_a.append([2 * k * cap, la[0], la[1], la[2], la[3], 0])
+                        desc_b.append([(2 * k + 1) * cap, lb[0], lb[1], lb[2], lb[3], 0])
+                        lut_a.append(la[4])
+                        lut_b.append(lb[4])
+                        chunk.append(i)
+                    # unpacked frame order: every a of the batch, then every b (two contiguous stacks)
+                    if not put((buf, len(ids), chunk, desc_a + desc_b, lut_a + lut_b, order)):
+                        return
             finally:
+                readers.shutdown(wait=False)
                 put(None)
 
         th = threading.Thread(target=loader, daemon=True)

@@ -5,10 +5,16 @@
 
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "piv_kernels.h"
@@ -790,6 +796,43 @@ int tpiv_bmp_unpack(const uint8_t* raw, const int64_t* desc, const uint8_t* lut,
     if (!raw || !desc || !lut || !out) return fail(TPIV_EINVAL, "tpiv_bmp_unpack: null pointer");
     HIP_TRY(tpiv::launch_bmp_unpack(raw, reinterpret_cast<const long long*>(desc), lut, n_files, H, W, out,
                                     (hipStream_t)stream));
+    return TPIV_OK;
+}
+
+int tpiv_read_files(const char* const* paths, int n_files, uint8_t* dst, size_t slot_bytes, int n_threads,
+                    int64_t* sizes) {
+    if (n_files < 0 || (n_files > 0 && (!paths || !dst || !sizes)) || slot_bytes == 0)
+        return fail(TPIV_EINVAL, "tpiv_read_files: bad arguments");
+    if (n_files == 0) return TPIV_OK;
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_files) n_threads = n_files;
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_files) return;
+            sizes[i] = -1;
+            const int fd = paths[i] ? ::open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
+            if (fd < 0) continue;
+            struct stat st;
+            if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size <= slot_bytes) {
+                uint8_t* out = dst + (size_t)i * slot_bytes;
+                size_t got = 0;
+                const size_t want = (size_t)st.st_size;
+                while (got < want) {
+                    const ssize_t r = ::read(fd, out + got, want - got);
+                    if (r <= 0) break;
+                    got += (size_t)r;
+                }
+                if (got == want) sizes[i] = (int64_t)want;
+            }
+            ::close(fd);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
     return TPIV_OK;
 }
 

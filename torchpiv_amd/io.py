@@ -112,6 +112,41 @@ def stage_raw(path: str, slot: np.ndarray, H: int, W: int):
     return 0, W, 1, 0, IDENTITY_LUT
 
 
+def stage_batch(paths, raw: np.ndarray, H: int, W: int, threads: int = 8):
+    """stage_raw for a whole batch without the interpreter in the loop: the files are read into the slots raw[i] (uint8
+    [n, cap], page-locked) by native reader threads (tpiv_read_files; the GIL is released for the duration) and the BMP
+    headers of all of them are parsed in one numpy sweep.  Returns a list with one (data_off, stride, bytes_pp, flip, lut)
+    per file, or None where the file needs the per-file path (stage_raw: other formats, odd headers, read errors)."""
+    import ctypes as C
+
+    from ._lib import check, lib
+    n, cap = raw.shape
+    arr = (C.c_char_p * n)(*[os.fsencode(p_) for p_ in paths])
+    sizes = np.empty(n, dtype=np.int64)
+    check(lib.tpiv_read_files(arr, n, raw.ctypes.data_as(C.c_void_p), cap, int(threads),
+                              sizes.ctypes.data_as(C.POINTER(C.c_longlong))))
+    out = [None] * n
+    ok = sizes >= 54 + 1024
+    if not ok.any():
+        return out
+    hdr = np.ascontiguousarray(raw[:, :54 + 1024])
+    u32 = lambda off: hdr[:, off:off + 4].copy().view("<u4")[:, 0].astype(np.int64)      # noqa: E731
+    i32 = lambda off: hdr[:, off:off + 4].copy().view("<i4")[:, 0].astype(np.int64)      # noqa: E731
+    u16 = lambda off: hdr[:, off:off + 2].copy().view("<u2")[:, 0].astype(np.int64)      # noqa: E731
+    data_off, hsz, w, h, bpp, comp, ncol = u32(10), u32(14), i32(18), i32(22), u16(28), u32(30), u32(46)
+    stride = ((w * bpp + 31) // 32) * 4
+    # the common camera file: BITMAPINFOHEADER, uncompressed, 8 / 24 / 32 bit, full palette right behind the header
+    plain = ok & (hdr[:, 0] == 0x42) & (hdr[:, 1] == 0x4D) & (hsz == 40) & ((comp == 0) | (comp == 3)) & (w == W) & \
+        (np.abs(h) == H) & np.isin(bpp, (8, 24, 32)) & (data_off + stride * H <= sizes) & ((bpp != 8) | (ncol == 0) | (ncol == 256))
+    if plain.any():
+        pal = hdr[:, 54:54 + 1024].reshape(n, 256, 4)
+        luts = _bgr_to_gray(pal[..., 0], pal[..., 1], pal[..., 2])
+        for i in np.flatnonzero(plain):
+            lut = luts[i] if bpp[i] == 8 else IDENTITY_LUT
+            out[i] = (int(data_off[i]), int(stride[i]), int(bpp[i] // 8), int(h[i] > 0), lut)
+    return out
+
+
 def imdecode_gray(path: str):
     """Grayscale uint8 [H, W] image or None when the file cannot be decoded
     (the reference then skips the pair, PIVbackend.py:138-139)."""
