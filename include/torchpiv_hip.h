@@ -203,6 +203,20 @@ int tpiv_bmp_unpack(const uint8_t* raw_dev, const int64_t* desc_dev, const uint8
 int tpiv_read_files(const char* const* paths, int n_files, uint8_t* dst, size_t slot_bytes, int n_threads,
                     int64_t* sizes);
 
+/* Read-ahead form of the same for a whole run (the loader of OfflinePIV.batched): the file list is handed over once;
+ * n_threads reader threads fill the caller's n_bufs page-locked staging buffers batch after batch -- batch k (files
+ * [k * files_per_batch, (k + 1) * files_per_batch), file j of it at bufs[k % n_bufs] + j * slot_bytes) -- running at most
+ * n_bufs batches ahead of the consumer.  tpiv_reader_next blocks until the next batch is complete and gives its number
+ * of files in *n_files (0: end of the list) with *buf_index and sizes[j] (bytes, or -1 as for tpiv_read_files);
+ * tpiv_reader_release hands the OLDEST outstanding batch's buffer back for refilling (call it once the upload of that
+ * buffer is through); tpiv_reader_close stops the threads (also mid-run) and frees the handle. */
+typedef struct tpiv_reader tpiv_reader;
+tpiv_reader* tpiv_reader_open(const char* const* paths, int64_t n_files, int files_per_batch, uint8_t* const* bufs,
+                              int n_bufs, size_t slot_bytes, int n_threads);
+int tpiv_reader_next(tpiv_reader* reader, int* n_files, int* buf_index, int64_t* sizes);
+int tpiv_reader_release(tpiv_reader* reader);
+void tpiv_reader_close(tpiv_reader* reader);
+
 /* ---- measurement ------------------------------------------------------------------ */
 
 /* Per-kernel timing with hipEvents recorded on the run's own stream (torch.cuda.Event only

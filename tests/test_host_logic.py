@@ -368,3 +368,57 @@ def test_batch_reader_agrees_with_the_per_file_path(tmp_path):
     # a slot smaller than the file: handed back, nothing written past the slot
     small = np.zeros((1, 1024), np.uint8)
     assert pio.stage_batch(paths[:1], small, H, W) == [None]
+
+
+def test_read_ahead_ring(tmp_path):
+    """tpiv_reader_*: batches arrive in order and complete, never more than len(bufs) ahead; a short last batch; unreadable
+    files are -1; closing mid-run stops the threads."""
+    from torchpiv_amd import io as pio
+    rng = np.random.default_rng(9)
+    blobs, paths = [], []
+    for i in range(23):
+        blob = rng.integers(0, 256, size=int(rng.integers(100, 3000)), dtype=np.uint8).tobytes()
+        if i == 7:
+            paths.append(str(tmp_path / "nope.bin"))
+            blobs.append(None)
+            continue
+        if i == 11:
+            blob = bytes(5000)                      # larger than a slot
+        (tmp_path / f"f{i}.bin").write_bytes(blob)
+        paths.append(str(tmp_path / f"f{i}.bin"))
+        blobs.append(blob)
+    cap, per = 4096, 4
+    bufs = [np.zeros((per, cap), np.uint8) for _ in range(3)]
+    rd = pio.ReadAhead(paths, per, [b.ctypes.data for b in bufs], cap, threads=5)
+    seen = 0
+    held = 0
+    while True:
+        got = rd.next()
+        if got is None:
+            break
+        k, sizes = got
+        assert k == (seen // per) % 3 and len(sizes) == min(per, 23 - seen)
+        for j, sz in enumerate(sizes):
+            blob = blobs[seen + j]
+            if blob is None or len(blob) > cap:
+                assert sz == -1
+            else:
+                assert sz == len(blob) and bufs[k][j, :sz].tobytes() == blob
+        seen += len(sizes)
+        held += 1
+        if held == 2:                               # hold two buffers at a time, hand the oldest back
+            rd.release()
+            held -= 1
+    assert seen == 23
+    rd.close()
+    rd.close()
+    # every buffer held: next() must refuse instead of waiting for ever
+    rd = pio.ReadAhead(paths, per, [b.ctypes.data for b in bufs[:1]], cap, threads=2)
+    assert rd.next() is not None
+    with pytest.raises(ValueError):
+        rd.next()
+    rd.close()                                      # mid-run: threads waiting for a buffer are released
+    # read=False: nothing is read, every file is handed to the per-file path
+    rd = pio.ReadAhead(paths, per, [b.ctypes.data for b in bufs], cap, read=False)
+    k, sizes = rd.next()
+    assert k == 0 and list(sizes) == [-1] * per

@@ -48,9 +48,12 @@ def rate(gen, n):
     return n / dt, k
 
 
-def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True, budget_s=None, precision="f64"):
-    """Rates in pairs/s per case; `files` adds the BMP cases (skipped once `budget_s` seconds are spent)."""
-    out = {"precision": precision}
+def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True, budget_s=None, precision="f64", reps=8):
+    """Rates in pairs/s per case; `files` adds the BMP cases (skipped once `budget_s` seconds are spent).  Every case
+    streams n * reps pairs (the n distinct pairs `reps` times over: 128 pairs alone last some 20 ms, which measures the
+    pipeline's fill and drain, not its rate); the file cases hard-link the n pairs' files under n * reps names."""
+    out = {"precision": precision, "pairs_streamed": n * reps}
+    order = list(range(n)) * reps
     t_start = time.perf_counter()
     for kind in ("clean", "runs", "spots"):
         A, B = make_frames(n, H, W, kind)
@@ -58,32 +61,35 @@ def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True,
         piv.fill_workers = workers
         rate(piv.batched(batch), n)                      # warm-up: plan creation
         piv.reset_stats()
-        r, k = rate(piv.batched(batch), n)
+        r, k = rate(piv.batched(batch, indices=order), n * reps)
         out[kind] = r
         out.setdefault("stats", {})[kind] = dict(piv.stats, yielded=k)
-        print(f"resident {kind:6s}: {r:8.1f} pairs/s ({k} of {n} yielded)  {piv.stats}")
+        print(f"resident {kind:6s}: {r:8.1f} pairs/s ({k} of {n * reps} yielded)  {piv.stats}")
         over = budget_s is not None and time.perf_counter() - t_start > budget_s
         if kind == "spots" and files and not over:
             from PIL import Image
             d = tempfile.mkdtemp()
             for i in range(n):
-                Image.fromarray(A[i].cpu().numpy(), "L").save(os.path.join(d, f"img{i:04d}_a.bmp"))
-                Image.fromarray(B[i].cpu().numpy(), "L").save(os.path.join(d, f"img{i:04d}_b.bmp"))
+                Image.fromarray(A[i].cpu().numpy(), "L").save(os.path.join(d, f"img{i:05d}_a.bmp"))
+                Image.fromarray(B[i].cpu().numpy(), "L").save(os.path.join(d, f"img{i:05d}_b.bmp"))
+                for r_ in range(1, reps):
+                    for s_ in "ab":
+                        os.link(os.path.join(d, f"img{i:05d}_{s_}.bmp"), os.path.join(d, f"img{i + r_ * n:05d}_{s_}.bmp"))
             fp = T.OfflinePIV(d, "cuda:0", "bmp", 64, 32, multipass=2, multipass_mode="CWS", precision=precision)
             fp.fill_workers = workers
             if read_threads:
                 fp.read_threads = read_threads
-            rate(fp.batched(batch), n)
+            rate(fp.batched(batch, indices=range(n)), n)
             fp.reset_stats()
-            r, k = rate(fp.batched(batch), n)
+            r, k = rate(fp.batched(batch), n * reps)
             out["files"] = r
-            print(f"files    {kind:6s}: {r:8.1f} pairs/s ({k} of {n} yielded; 8-bit BMP in the page cache)  {fp.stats}")
-            r, k = rate(fp(), n)
+            print(f"files    {kind:6s}: {r:8.1f} pairs/s ({k} of {n * reps} yielded; 8-bit BMP in the page cache)  {fp.stats}")
+            r, k = rate(fp(), n * reps)
             out["files_call"] = r
             print(f"files    __call__ (the reference's generator API; reads ahead {fp.call_batch} pairs per launch): {r:8.1f} pairs/s")
             if budget_s is None:
                 fp.call_batch = 1
-                r, k = rate(fp(), n)
+                r, k = rate(fp(), n * reps)
                 print(f"files    __call__ with call_batch = 1 (one pair per launch, host decode): {r:8.1f} pairs/s")
             fp.close()
             import shutil

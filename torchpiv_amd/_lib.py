@@ -71,6 +71,10 @@ SIGNATURES = {
     "tpiv_ensemble_moments": (C.c_int, [_f64p, _f64p, _int, C.c_longlong, _f64p, _vp]),
     "tpiv_bmp_unpack": (C.c_int, [_u8p, _vp, _u8p, _int, _int, _int, _u8p, _vp]),
     "tpiv_read_files": (C.c_int, [C.POINTER(C.c_char_p), _int, C.c_void_p, C.c_size_t, _int, C.POINTER(C.c_longlong)]),
+    "tpiv_reader_open": (C.c_void_p, [C.POINTER(C.c_char_p), C.c_longlong, _int, C.POINTER(C.c_void_p), _int, C.c_size_t, _int]),
+    "tpiv_reader_next": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    "tpiv_reader_release": (C.c_int, [C.c_void_p]),
+    "tpiv_reader_close": (None, [C.c_void_p]),
     "tpiv_plan_set_timing": (C.c_int, [C.c_void_p, _int]),
     "tpiv_plan_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), _int, C.POINTER(C.c_int)]),
     "tpiv_plan_debug_predict": (C.c_int, [C.c_void_p, _int, _int, _f64p, _f64p, _u8p, _f64p, _f64p, _f64p,

@@ -414,7 +414,12 @@ class OfflinePIV:
         if getattr(self, "_plan", None) is not None:
             self._plan.close()
             self._plan = None
+        rd = getattr(self, "_reader", None)
+        if rd is not None:
+            rd.close()
+            self._reader = None
         self._stage, self._stage_key = None, None
+        self._raw_dev, self._raw_dev_key = None, None
         for pl in getattr(self, "_single_plans", {}).values():
             pl.close()
         self._single_plans = {}
@@ -619,14 +624,12 @@ class OfflinePIV:
                 print(f"Batch finished in {(end_time - start):.3f} sec")
 
     def batched(self, batch_size: int = 32, indices=None) -> Generator:
-        """Like __call__, but reads, uploads and processes `batch_size` pairs per launch.  A loader
-        thread puts the next batch's files into pinned staging memory -- uncompressed BMPs as their RAW
+        """Like __call__, but reads, uploads and processes `batch_size` pairs per launch.  Native reader
+        threads (io.ReadAhead) put the next batches' files into pinned staging memory -- uncompressed BMPs as their RAW
         FILE BYTES (no host decode: header skip, row flip, padding strip and palette / gray conversion
         run on the device, tpiv_bmp_unpack), other formats decoded on the host -- while the GPU works on
-        the current batch (double buffered).  Yields (pair_index, x, y, u, v); dropped pairs yield nothing."""
-        import queue
-        import threading
-        from .io import stage_batch, stage_raw
+        the current batch (triple-buffered staging, uploads on their own stream).  Yields (pair_index, x, y, u, v); dropped pairs yield nothing."""
+        from .io import ReadAhead, parse_bmp_headers, stage_raw
         idx = list(range(len(self._dataset))) if indices is None else list(indices)
         if not idx:
             return
@@ -647,80 +650,28 @@ class OfflinePIV:
         cap = (max(sizes) + 4095) // 4096 * 4096
         # (page-locking half a gigabyte takes a tenth of a second: the staging buffers are kept for the next call)
         key = (batch_size, cap)
-        prev = getattr(self, "_loader", None)            # (a loader that outlived its generator still owns the buffers)
-        if getattr(self, "_stage_key", None) != key or (prev is not None and prev.is_alive()):
-            self._stage = [torch.empty(2 * batch_size, cap, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        prev = getattr(self, "_reader", None)            # a reader that outlived its (abandoned) generator still fills the buffers
+        if prev is not None:
+            prev.close()
+        if getattr(self, "_stage_key", None) != key:
+            # three staging buffers: one being read into, one uploading, one of slack
+            self._stage = [torch.empty(2 * batch_size, cap, dtype=torch.uint8).pin_memory() for _ in range(3)]
             self._stage_key = key
         stage = self._stage
-        free = [threading.Event(), threading.Event()]
-        for e in free:
-            e.set()
-        q = queue.Queue(maxsize=2)
-        stop = threading.Event()         # set when the consumer is done or gone: the loader must not block for ever
-
-        def put(item):
-            while not stop.is_set():
-                try:
-                    q.put(item, timeout=0.2)
-                    return True
-                except queue.Full:
-                    continue
-            return False
-
-        def loader():
-            from concurrent.futures import ThreadPoolExecutor
-            readers = ThreadPoolExecutor(max_workers=self.read_threads)       # host decode of the non-BMP files only
-            try:
-                for n, s0 in enumerate(range(0, len(idx), batch_size)):
-                    buf = n % 2
-                    while not free[buf].wait(0.2):
-                        if stop.is_set():
-                            return
-                    if stop.is_set():
-                        return
-                    free[buf].clear()
-                    raw = stage[buf].numpy()
-                    ids = idx[s0:s0 + batch_size]
-                    # slot 2k: frame a of pair k, slot 2k + 1: frame b.  One native call reads the whole batch (reader
-                    # threads of the library, GIL released) and the headers are parsed in one numpy sweep; files that are
-                    # not plain uncompressed BMPs of the batch's shape take the per-file path (host decode)
-                    paths = []
-                    for i in ids:
-                        paths += [self._dataset.img_pairs[i][0], self._dataset.img_pairs[i][-1]]
-                    lays = stage_batch(paths, raw[:len(paths)], H, W, threads=self.read_threads)
-                    rest = [j for j, lay in enumerate(lays) if lay is None]
-                    if rest:
-                        for j, lay in zip(rest, readers.map(lambda j: stage_raw(paths[j], raw[j], H, W), rest)):
-                            lays[j] = lay
-                    chunk, desc_a, desc_b, lut_a, lut_b, order = [], [], [], [], [], []
-                    for k, i in enumerate(ids):
-                        la, lb = lays[2 * k], lays[2 * k + 1]
-                        order.append((i, la is not None and lb is not None))
-                        if la is None or lb is None:
-                            # not stageable (undecodable, or a frame shape other than the batch's): the pair
-                            # takes the one-pair path when its turn comes -- which skips an undecodable
-                            # pair like B:138-139 and gives another shape its own plan
-                            continue
-                        desc_a.append([2 * k * cap, la[0], la[1], la[2], la[3], 0])
-                        desc_b.append([(2 * k + 1) * cap, lb[0], lb[1], lb[2], lb[3], 0])
-                        lut_a.append(la[4])
-                        lut_b.append(lb[4])
-                        chunk.append(i)
-                    # unpacked frame order: every a of the batch, then every b (two contiguous stacks)
-                    if not put((buf, len(ids), chunk, desc_a + desc_b, lut_a + lut_b, order)):
-                        return
-            finally:
-                readers.shutdown(wait=False)
-                put(None)
-
-        th = threading.Thread(target=loader, daemon=True)
-        th.start()
-        self._loader = th
+        pairs = self._dataset.img_pairs
+        paths = []
+        for i in idx:                       # slot 2k: frame a of the batch's pair k, slot 2k + 1: frame b
+            paths += [pairs[i][0], pairs[i][-1]]
+        # the loader is native (tpiv_reader_*): reader threads of the library stream the run's files into the staging
+        # buffers ahead of this loop, which only blocks -- without the GIL -- for the next complete batch.  Formats the
+        # device cannot unpack are not read here at all: they take the per-file path (host decode) below
+        rd = ReadAhead(paths, 2 * batch_size, [t.data_ptr() for t in stage], cap, threads=self.read_threads,
+                       read=str(paths[0]).lower().endswith(".bmp"))
+        self._reader = rd
+        decoders = None
         w, o, _, _ = plan.geometry[-1]
         x, y = get_coordinates((H, W), w, o)
         dev = self._device
-        pending = None
-
         pipe = self._post_pipeline(x, y)
 
         def emit(finished):
@@ -732,41 +683,87 @@ class OfflinePIV:
                     if out is not None:
                         yield (i,) + out
 
+        # uploads run on their own stream into a double-buffered device copy of the staging slots, so that the PCIe
+        # transfer of batch n + 1 (4 MP: 268 MB, ~5 ms) overlaps the passes of batch n (~3 ms) instead of preceding them
+        cur = torch.cuda.current_stream(dev)
+        up_stream = torch.cuda.Stream(dev)
+        key_d = (batch_size, cap, str(dev))
+        if getattr(self, "_raw_dev_key", None) != key_d:
+            self._raw_dev = [torch.empty(2 * batch_size, cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+            self._raw_dev_key = key_d
+        raw_dev = self._raw_dev
+        consumed = [None, None]             # event: the unpack kernel that read raw_dev[k] has run
+        release = None                      # upload event of the batch before (its staging buffer is still held)
+        n_up = 0
+
+        def let_go(rel):
+            if rel is not None:
+                if rel[0] is not None:
+                    rel[0].synchronize()              # its upload is through: the readers may refill the staging buffer
+                rd.release()
+
         try:
-            while True:
-                item = q.get()
-                if item is None:
+            for s0 in range(0, len(idx), batch_size):
+                got = rd.next()
+                if got is None:
                     break
-                buf, n_slots, chunk, desc, luts, order = item
-                ticket = None
+                buf, sizes = got
+                ids = idx[s0:s0 + batch_size]
+                raw = stage[buf].numpy()
+                lays = parse_bmp_headers(raw[:len(sizes)], sizes, H, W)
+                rest = [j for j, lay in enumerate(lays) if lay is None]
+                if rest:
+                    if decoders is None:
+                        from concurrent.futures import ThreadPoolExecutor
+                        decoders = ThreadPoolExecutor(max_workers=self.read_threads)
+                    for j, lay in zip(rest, decoders.map(lambda j: stage_raw(paths[2 * s0 + j], raw[j], H, W), rest)):
+                        lays[j] = lay
+                chunk, desc_a, desc_b, lut_a, lut_b, order = [], [], [], [], [], []
+                for k, i in enumerate(ids):
+                    la, lb = lays[2 * k], lays[2 * k + 1]
+                    order.append((i, la is not None and lb is not None))
+                    if la is None or lb is None:
+                        # not stageable (undecodable, or a frame shape other than the batch's): the pair takes the
+                        # one-pair path when its turn comes -- which skips an undecodable pair like B:138-139 and
+                        # gives another shape its own plan
+                        continue
+                    desc_a.append([2 * k * cap, la[0], la[1], la[2], la[3], 0])
+                    desc_b.append([(2 * k + 1) * cap, lb[0], lb[1], lb[2], lb[3], 0])
+                    lut_a.append(la[4])
+                    lut_b.append(lb[4])
+                    chunk.append(i)
+                ticket, up = None, None
                 if chunk:
-                    n = len(chunk)
-                    raw_d = stage[buf][:2 * n_slots].to(dev, non_blocking=True)
-                    up = torch.cuda.Event()
-                    up.record()
-                    desc_d = torch.tensor(desc, dtype=torch.int64).to(dev, non_blocking=True)
-                    lut_d = torch.from_numpy(np.stack(luts)).to(dev, non_blocking=True)
+                    n, n_slots = len(chunk), len(ids)
+                    dbuf, n_up = n_up % 2, n_up + 1
+                    with torch.cuda.stream(up_stream):
+                        if consumed[dbuf] is not None:
+                            up_stream.wait_event(consumed[dbuf])
+                        raw_d = raw_dev[dbuf][:2 * n_slots]
+                        raw_d.copy_(stage[buf][:2 * n_slots], non_blocking=True)
+                        up = torch.cuda.Event()
+                        up.record(up_stream)
+                    # unpacked frame order: every a of the batch, then every b (two contiguous stacks)
+                    desc_d = torch.tensor(desc_a + desc_b, dtype=torch.int64).to(dev, non_blocking=True)
+                    lut_d = torch.from_numpy(np.stack(lut_a + lut_b)).to(dev, non_blocking=True)
+                    cur.wait_event(up)
                     frames = engine.bmp_unpack(raw_d.view(-1), desc_d, lut_d, H, W)      # [2n, H, W]: a_0..a_n-1, b_0..b_n-1
+                    consumed[dbuf] = torch.cuda.Event()
+                    consumed[dbuf].record(cur)
                     u, v, inv = plan.run(frames[:n], frames[n:])
                     ticket = self._post_submit(u, v, inv)
+                let_go(release)
+                release = (up,)
                 # the host work of the PREVIOUS batches runs while the GPU works on this one
                 yield from emit(pipe.push((order, chunk), ticket))
-                if chunk:
-                    up.synchronize()                  # staging buffer may be refilled now
-                free[buf].set()
+            let_go(release)
+            release = None
             yield from emit(pipe.flush())
         finally:
-            # consumer finished, raised, or abandoned the generator (GeneratorExit lands here): release the
-            # loader -- it may sit in a full queue or wait for a staging buffer -- and let it end
-            stop.set()
-            for e in free:
-                e.set()
-            try:
-                while True:
-                    q.get_nowait()
-            except queue.Empty:
-                pass
-            th.join(timeout=5.0)
+            # consumer finished, raised, or abandoned the generator (GeneratorExit lands here): stop the reader threads
+            rd.close()
+            if decoders is not None:
+                decoders.shutdown(wait=False)
 
 
 class ResidentPIV(OfflinePIV):

@@ -9,7 +9,10 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -799,6 +802,135 @@ int tpiv_bmp_unpack(const uint8_t* raw, const int64_t* desc, const uint8_t* lut,
     return TPIV_OK;
 }
 
+namespace {
+// One file into a slot of at most slot_bytes: bytes read, or -1 (cannot open / not a regular file / too big / short read).
+int64_t read_one_file(const char* path, uint8_t* out, size_t slot_bytes) {
+    const int fd = path ? ::open(path, O_RDONLY | O_CLOEXEC) : -1;
+    if (fd < 0) return -1;
+    int64_t res = -1;
+    struct stat st;
+    if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size <= slot_bytes) {
+        size_t got = 0;
+        const size_t want = (size_t)st.st_size;
+        while (got < want) {
+            const ssize_t r = ::read(fd, out + got, want - got);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        if (got == want) res = (int64_t)want;
+    }
+    ::close(fd);
+    return res;
+}
+}  // namespace
+
+// Read-ahead ring of the file path: the whole run's file list is handed over once, reader threads fill the caller's
+// staging buffers batch by batch (in order, up to n_bufs batches ahead of the consumer) and the consumer blocks in
+// tpiv_reader_next without holding any interpreter lock.
+struct tpiv_reader {
+    std::vector<std::string> paths;
+    std::vector<uint8_t*> bufs;
+    std::vector<int64_t> sizes;          // per file
+    std::vector<int> done;               // per batch: files finished
+    size_t slot_bytes = 0;
+    long files_per_batch = 0, n_batches = 0;
+    std::atomic<long> next_file{0};
+    long released = 0;                   // batches handed back by the consumer (in order)
+    long cursor = 0;                     // next batch tpiv_reader_next hands out
+    bool stop = false;
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<std::thread> pool;
+
+    long files_in(long b) const {
+        const long n = (long)paths.size();
+        return std::min(files_per_batch, n - b * files_per_batch);
+    }
+    void work() {
+        const long n = (long)paths.size();
+        for (;;) {
+            const long i = next_file.fetch_add(1);
+            if (i >= n) return;
+            const long b = i / files_per_batch;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || b < released + (long)bufs.size(); });
+                if (stop) return;
+            }
+            uint8_t* out = bufs[b % (long)bufs.size()] + (size_t)(i - b * files_per_batch) * slot_bytes;
+            const int64_t got = read_one_file(paths[i].c_str(), out, slot_bytes);
+            std::lock_guard<std::mutex> lk(m);
+            sizes[i] = got;
+            if (++done[b] == files_in(b)) cv.notify_all();
+        }
+    }
+};
+
+tpiv_reader* tpiv_reader_open(const char* const* paths, int64_t n_files, int files_per_batch, uint8_t* const* bufs,
+                              int n_bufs, size_t slot_bytes, int n_threads) {
+    if (n_files < 0 || files_per_batch < 1 || n_bufs < 1 || slot_bytes == 0 || !bufs || (n_files > 0 && !paths)) {
+        fail(TPIV_EINVAL, "tpiv_reader_open: bad arguments");
+        return nullptr;
+    }
+    auto* r = new tpiv_reader;
+    for (int64_t i = 0; i < n_files; ++i) r->paths.emplace_back(paths[i] ? paths[i] : "");
+    for (int k = 0; k < n_bufs; ++k) {
+        if (!bufs[k]) {
+            delete r;
+            fail(TPIV_EINVAL, "tpiv_reader_open: null staging buffer");
+            return nullptr;
+        }
+        r->bufs.push_back(bufs[k]);
+    }
+    r->slot_bytes = slot_bytes;
+    r->files_per_batch = files_per_batch;
+    r->n_batches = (long)((n_files + files_per_batch - 1) / files_per_batch);
+    r->sizes.assign((size_t)n_files, -1);
+    r->done.assign((size_t)r->n_batches, 0);
+    if (n_threads < 1) n_threads = 1;
+    for (int t = 0; t < n_threads; ++t) r->pool.emplace_back([r] { r->work(); });
+    return r;
+}
+
+int tpiv_reader_next(tpiv_reader* r, int* n_files, int* buf_index, int64_t* sizes) {
+    if (!r || !n_files || !buf_index || !sizes) return fail(TPIV_EINVAL, "tpiv_reader_next: null argument");
+    std::unique_lock<std::mutex> lk(r->m);
+    *n_files = 0;
+    if (r->cursor >= r->n_batches) return TPIV_OK;
+    const long b = r->cursor;
+    const long cnt = r->files_in(b);
+    if (b >= r->released + (long)r->bufs.size())
+        return fail(TPIV_EINVAL, "tpiv_reader_next: every staging buffer is held (release one first)");
+    r->cv.wait(lk, [&] { return r->done[b] == cnt; });
+    for (long k = 0; k < cnt; ++k) sizes[k] = r->sizes[(size_t)(b * r->files_per_batch + k)];
+    *buf_index = (int)(b % (long)r->bufs.size());
+    *n_files = (int)cnt;
+    r->cursor = b + 1;
+    return TPIV_OK;
+}
+
+int tpiv_reader_release(tpiv_reader* r) {
+    if (!r) return fail(TPIV_EINVAL, "tpiv_reader_release: null reader");
+    {
+        std::lock_guard<std::mutex> lk(r->m);
+        if (r->released >= r->cursor) return fail(TPIV_EINVAL, "tpiv_reader_release: nothing handed out");
+        ++r->released;
+    }
+    r->cv.notify_all();
+    return TPIV_OK;
+}
+
+void tpiv_reader_close(tpiv_reader* r) {
+    if (!r) return;
+    {
+        std::lock_guard<std::mutex> lk(r->m);
+        r->stop = true;
+    }
+    r->cv.notify_all();
+    for (auto& t : r->pool) t.join();
+    delete r;
+}
+
 int tpiv_read_files(const char* const* paths, int n_files, uint8_t* dst, size_t slot_bytes, int n_threads,
                     int64_t* sizes) {
     if (n_files < 0 || (n_files > 0 && (!paths || !dst || !sizes)) || slot_bytes == 0)
@@ -811,22 +943,7 @@ int tpiv_read_files(const char* const* paths, int n_files, uint8_t* dst, size_t 
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n_files) return;
-            sizes[i] = -1;
-            const int fd = paths[i] ? ::open(paths[i], O_RDONLY | O_CLOEXEC) : -1;
-            if (fd < 0) continue;
-            struct stat st;
-            if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size <= slot_bytes) {
-                uint8_t* out = dst + (size_t)i * slot_bytes;
-                size_t got = 0;
-                const size_t want = (size_t)st.st_size;
-                while (got < want) {
-                    const ssize_t r = ::read(fd, out + got, want - got);
-                    if (r <= 0) break;
-                    got += (size_t)r;
-                }
-                if (got == want) sizes[i] = (int64_t)want;
-            }
-            ::close(fd);
+            sizes[i] = read_one_file(paths[i], dst + (size_t)i * slot_bytes, slot_bytes);
         }
     };
     std::vector<std::thread> pool;

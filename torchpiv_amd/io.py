@@ -112,19 +112,11 @@ def stage_raw(path: str, slot: np.ndarray, H: int, W: int):
     return 0, W, 1, 0, IDENTITY_LUT
 
 
-def stage_batch(paths, raw: np.ndarray, H: int, W: int, threads: int = 8):
-    """stage_raw for a whole batch without the interpreter in the loop: the files are read into the slots raw[i] (uint8
-    [n, cap], page-locked) by native reader threads (tpiv_read_files; the GIL is released for the duration) and the BMP
-    headers of all of them are parsed in one numpy sweep.  Returns a list with one (data_off, stride, bytes_pp, flip, lut)
-    per file, or None where the file needs the per-file path (stage_raw: other formats, odd headers, read errors)."""
-    import ctypes as C
-
-    from ._lib import check, lib
-    n, cap = raw.shape
-    arr = (C.c_char_p * n)(*[os.fsencode(p_) for p_ in paths])
-    sizes = np.empty(n, dtype=np.int64)
-    check(lib.tpiv_read_files(arr, n, raw.ctypes.data_as(C.c_void_p), cap, int(threads),
-                              sizes.ctypes.data_as(C.POINTER(C.c_longlong))))
+def parse_bmp_headers(raw: np.ndarray, sizes: np.ndarray, H: int, W: int):
+    """Headers of a batch of files sitting in the slots raw[i] (uint8 [n, cap]; sizes[i] bytes each, -1: not read) in
+    one numpy sweep.  Returns a list with one (data_off, stride, bytes_pp, flip, lut) per file -- what stage_raw returns
+    -- or None where the file needs the per-file path (other formats, odd headers, another frame shape, read errors)."""
+    n = raw.shape[0]
     out = [None] * n
     ok = sizes >= 54 + 1024
     if not ok.any():
@@ -145,6 +137,73 @@ def stage_batch(paths, raw: np.ndarray, H: int, W: int, threads: int = 8):
             lut = luts[i] if bpp[i] == 8 else IDENTITY_LUT
             out[i] = (int(data_off[i]), int(stride[i]), int(bpp[i] // 8), int(h[i] > 0), lut)
     return out
+
+
+def stage_batch(paths, raw: np.ndarray, H: int, W: int, threads: int = 8):
+    """stage_raw for a whole batch without the interpreter in the loop: the files are read into the slots raw[i] (uint8
+    [n, cap], page-locked) by native reader threads (tpiv_read_files; the GIL is released for the duration) and the BMP
+    headers of all of them are parsed in one numpy sweep (parse_bmp_headers)."""
+    import ctypes as C
+
+    from ._lib import check, lib
+    n, cap = raw.shape
+    arr = (C.c_char_p * n)(*[os.fsencode(p_) for p_ in paths])
+    sizes = np.empty(n, dtype=np.int64)
+    check(lib.tpiv_read_files(arr, n, raw.ctypes.data_as(C.c_void_p), cap, int(threads),
+                              sizes.ctypes.data_as(C.POINTER(C.c_longlong))))
+    return parse_bmp_headers(raw, sizes, H, W)
+
+
+class ReadAhead:
+    """The run's files streamed into page-locked staging buffers by native reader threads (tpiv_reader_*): batch k of
+    `files_per_batch` files lands in bufs[k % len(bufs)], at most len(bufs) batches ahead of the consumer.  next()
+    blocks without the GIL until the next batch is complete -> (buffer index, sizes) or None at the end; release() hands
+    the oldest outstanding buffer back.  read=False marks every file unread (sizes -1) without touching the disk -- for
+    formats the device cannot unpack, which take the per-file path anyway."""
+
+    def __init__(self, paths, files_per_batch: int, bufs, slot_bytes: int, threads: int = 8, read: bool = True):
+        import ctypes as C
+
+        from ._lib import lib
+        self._C, self._lib = C, lib
+        self._n, self._fpb, self._read, self._k, self._nb = len(paths), int(files_per_batch), read, 0, len(bufs)
+        self._h = None
+        if read:
+            arr = (C.c_char_p * len(paths))(*[os.fsencode(p_) for p_ in paths])
+            ptrs = (C.c_void_p * len(bufs))(*[int(b_) for b_ in bufs])
+            self._h = lib.tpiv_reader_open(arr, len(paths), self._fpb, ptrs, len(bufs), int(slot_bytes), int(threads))
+            if not self._h:
+                raise ValueError(lib.tpiv_last_error().decode("utf-8", "replace"))
+        self._sizes = np.empty(self._fpb, dtype=np.int64)
+        self._idx, self._cnt = C.c_int(0), C.c_int(0)
+
+    def next(self):
+        if not self._read:
+            if self._k * self._fpb >= self._n:
+                return None
+            cnt = min(self._fpb, self._n - self._k * self._fpb)
+            self._k += 1
+            return (self._k - 1) % self._nb, np.full(cnt, -1, dtype=np.int64)
+        from ._lib import check
+        C = self._C
+        check(self._lib.tpiv_reader_next(self._h, C.byref(self._cnt), C.byref(self._idx),
+                                         self._sizes.ctypes.data_as(C.POINTER(C.c_longlong))))
+        cnt = self._cnt.value
+        if cnt == 0:
+            return None
+        return self._idx.value, self._sizes[:cnt].copy()
+
+    def release(self):
+        if self._h:
+            from ._lib import check
+            check(self._lib.tpiv_reader_release(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.tpiv_reader_close(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def imdecode_gray(path: str):
