@@ -29,6 +29,8 @@ if __name__ == "__main__":
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     threads = int(sys.argv[3]) if len(sys.argv) > 3 else 8
     kind = sys.argv[4] if len(sys.argv) > 4 else "spots"
+    depth = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+    batch = int(sys.argv[6]) if len(sys.argv) > 6 else 32
     from PIL import Image
     A, Bf = E.make_frames(n, 2048, 2048, kind)
     d = tempfile.mkdtemp()
@@ -40,12 +42,17 @@ if __name__ == "__main__":
                 os.link(os.path.join(d, f"img{i:05d}_{s_}.bmp"), os.path.join(d, f"img{i + r_ * n:05d}_{s_}.bmp"))
     del A, Bf
     piv = T.OfflinePIV(d, "cuda:0", "bmp", 64, 32, multipass=2, multipass_mode="CWS")
-    piv.fill_workers, piv.read_threads = workers, threads
-    sum(1 for _ in piv.batched(32, indices=range(64)))
+    piv.fill_workers, piv.read_threads, piv.pipeline_depth = workers, threads, depth
+    sum(1 for _ in piv.batched(batch, indices=range(2 * batch)))
     timed(pio.ReadAhead, "next", "reader.next (wait)")
     timed(pio, "parse_bmp_headers")
     timed(piv, "_post_submit")
-    timed(piv, "_post_collect")
+    timed(piv, "_post_extract")
+    timed(piv, "_post_complete")
+    timed(piv._plan, "run", "plan.run")
+    timed(torch.Tensor, "copy_", "Tensor.copy_")
+    timed(torch.Tensor, "to", "Tensor.to")
+    timed(torch, "tensor", "torch.tensor")
     timed(piv, "_finish_batch")
     timed(engine, "bmp_unpack")
     pool = piv._fill_pool()
@@ -61,11 +68,11 @@ if __name__ == "__main__":
     N = n * reps
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    k = sum(1 for _ in piv.batched(32))
+    k = sum(1 for _ in piv.batched(batch))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"workers {workers} read threads {threads} {kind}: {N / dt:.0f} pairs/s, {dt * 1e3 / (N / 32):.2f} ms per batch of 32, yielded {k}")
+    print(f"workers {workers} read threads {threads} depth {depth} batch {batch} {kind}: {N / dt:.0f} pairs/s, {dt * 1e3 / (N / batch):.2f} ms per batch of {batch}, yielded {k}")
     for key in T_:
-        print(f"  {key:20s} {T_[key] * 1e3 / (N / 32):7.2f} ms per batch  ({N_[key]} calls)")
+        print(f"  {key:20s} {T_[key] * 1e3 / (N / batch):7.2f} ms per batch  ({N_[key]} calls)")
     piv.close()
     shutil.rmtree(d, ignore_errors=True)

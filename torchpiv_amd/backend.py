@@ -391,6 +391,7 @@ class OfflinePIV:
                       "host_fallback": 0, "dropped_by_qhull": 0}
 
     fill_workers = 0         # > 0: the host triangulations of a batch run in that many worker processes
+    pipeline_depth = 2       # batched() over files: launches in flight before a batch's results are collected
     read_threads = 8         # file reader threads of batched() (a page-cache read into pinned memory runs at ~3 GB/s per thread)
 
     def _fill_pool(self):
@@ -526,10 +527,12 @@ class OfflinePIV:
     def _post_validate_batch(self, u, v, inv):
         return self._post_collect(self._post_submit(u, v, inv))
 
-    def _post_pipeline(self, x, y):
-        """The host side of batched() as a two-stage pipeline: push(meta, ticket) after every launch returns the finished
-        entries [(meta, per-pair results)] of the batch pushed before -- while the GPU works on batch k, the census, the
-        triangulations (worker pool) and the patching of batch k-1 run here.  flush() drains."""
+    def _post_pipeline(self, x, y, depth=1):
+        """The host side of batched() as a pipeline: push(meta, ticket) after every launch returns the finished
+        entries [(meta, per-pair results)] of the batch pushed `depth` launches before -- while the GPU works on batch k,
+        the census, the triangulations (worker pool) and the patching of batch k - depth run here.  The file path uses
+        depth 2: a batch's upload (longer than its passes) then overlaps the passes of the batch before instead of being
+        waited for.  flush() drains."""
         waiting = []
 
         def step():
@@ -542,7 +545,7 @@ class OfflinePIV:
 
         class Pipe:
             def push(_, meta, ticket):
-                out = step()
+                out = step() if len(waiting) >= depth else []
                 waiting.append((meta, ticket))
                 return out
 
@@ -672,7 +675,7 @@ class OfflinePIV:
         w, o, _, _ = plan.geometry[-1]
         x, y = get_coordinates((H, W), w, o)
         dev = self._device
-        pipe = self._post_pipeline(x, y)
+        pipe = self._post_pipeline(x, y, depth=self.pipeline_depth)
 
         def emit(finished):
             """Results of finished batches in dataset order; the pairs that were not staged run now."""
