@@ -422,3 +422,29 @@ def test_read_ahead_ring(tmp_path):
     rd = pio.ReadAhead(paths, per, [b.ctypes.data for b in bufs], cap, read=False)
     k, sizes = rd.next()
     assert k == 0 and list(sizes) == [-1] * per
+
+
+def test_qhull_diamond_choice_is_not_a_local_rule():
+    """Why the isolated invalid vector stays a (counted) host triangulation: its four ring points are co-circular, both
+    diagonals are Delaunay, and the one SciPy/Qhull takes -- hence the value, (N + S) / 2 or (E + W) / 2 -- changes with
+    a SECOND hole 20-40 cells away, i.e. it is not a function of any neighbourhood of the hole (PIVbackend.py:284-308;
+    tools/research/qhull_diamonds.py).  The product therefore hands such pairs to the same Qhull (torchpiv_amd/_qhull.py)."""
+    from torchpiv_amd._qhull import qhull_fill
+    nr = nc = 63
+    rng = np.random.default_rng(3)
+    field = rng.standard_normal((nr, nc))
+    seen = {}
+    for far in ((5, 5), (5, 23), (11, 29), (5, 41), (47, 47), (41, 11)):
+        hole = np.zeros((nr, nc), bool)
+        hole[20, 20] = hole[far] = True
+        ring = np.zeros_like(hole)
+        ring[1:] |= hole[:-1]
+        ring[:-1] |= hole[1:]
+        ring[:, 1:] |= hole[:, :-1]
+        ring[:, :-1] |= hole[:, 1:]
+        ring &= ~hole
+        val = qhull_fill(np.argwhere(ring), field[ring][:, None], np.array([[20, 20]]))[0, 0]
+        ns, ew = (field[19, 20] + field[21, 20]) / 2, (field[20, 19] + field[20, 21]) / 2
+        assert min(abs(val - ns), abs(val - ew)) < 1e-15
+        seen["NS" if abs(val - ns) < abs(val - ew) else "EW"] = far
+    assert set(seen) == {"NS", "EW"}, seen
