@@ -1,23 +1,27 @@
 #!/bin/bash
 # Round profile on the GPU box.  Everything the bench line quotes can be re-derived from these outputs:
-#   bench lines (config 1 fast = the headline, with live PMC counters and the CPU baseline; config 1 at
-#   reference precision; configs[2] stream; 2-rank gloo rehearsals of --gpus 2),
-#   rocprofv3 --kernel-trace --stats of the headline command,
-#   configs[3] / configs[4]: quick_bench lines, kernel stats and SQ counters of their kernels,
-#   the end-to-end generator line.
-# Outputs: gpurun_out/$1/ ; copy what is to be judged into profiles/<round>/.
+#   bench_n1.json               the driver's command (configs[1], float64 pass 1 = the headline, with the all-float32
+#                               run, the end_to_end block, live PMC counters and the CPU baseline)
+#   bench_n1_reference.json     the same at precision "reference" (reference-order CWS staging)
+#   bench_n1_config2.json       configs[2] stream
+#   bench_gloo2_*.json          2-rank gloo launch rehearsals of --gpus 2 (two ranks time-slicing ONE GPU: not a measurement)
+#   rocprofv3_kernel_stats.csv  rocprofv3 --kernel-trace --stats of the headline command
+#   other_configs/              configs[3] / configs[4] at both precisions: quick_bench lines, kernel stats, SQ counters
+#   stamps_f64.txt              per-phase cycle shares of the float64 pass-1 kernel (stamped diagnostic build)
+#   files_profile.txt           where the file path spends its time
+# Outputs: gpurun_out/$1/ ; tools/collect_profile.py copies what is to be judged into profiles/<round>/.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT/other_configs
 export TMPDIR=/tmp
 R="--kernel-include-regex xcorr|predict|finalize|postval"
 python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { tail $OUT/bench_n1.err; exit 1; }
-python3 bench.py --precision reference --no-cpu-baseline > $OUT/bench_n1_reference.json 2> $OUT/bench_ref.err || exit 1
-python3 bench.py --config 2 --no-cpu-baseline > $OUT/bench_n1_config2.json 2> $OUT/bench_c2.err || exit 1
+python3 bench.py --precision reference --no-cpu-baseline --no-fast --no-e2e > $OUT/bench_n1_reference.json 2> $OUT/bench_ref.err || exit 1
+python3 bench.py --config 2 --no-cpu-baseline --no-e2e > $OUT/bench_n1_config2.json 2> $OUT/bench_c2.err || exit 1
 TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 2 --batch 64 --pmc off > $OUT/bench_gloo2_config1.json 2> $OUT/g2.err || exit 1
 TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --config 2 --steps 3 --stream 1000 --batch 250 --pmc off > $OUT/bench_gloo2_config2.json 2> $OUT/g2c2.err || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv $R -d $OUT/stats -- python3 bench.py --steps 50 --warmup 5 --pmc off --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv $R -d $OUT/stats -- python3 bench.py --steps 50 --warmup 5 --pmc off --no-cpu-baseline --no-e2e > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/rocprofv3_kernel_stats.csv && rm -rf $OUT/stats
 cfg() {   # name, quick_bench args
     local name=$1; shift
@@ -25,20 +29,22 @@ cfg() {   # name, quick_bench args
     rocprofv3 --kernel-trace --stats --output-format csv $R -d $OUT/other_configs/$name.prof -- python3 tools/quick_bench.py "$@" > /dev/null 2> $OUT/other_configs/$name.err
     cp $OUT/other_configs/$name.prof/*/*_kernel_stats.csv $OUT/other_configs/${name}_kernel_stats.csv; rm -rf $OUT/other_configs/$name.prof
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv --kernel-include-regex "xcorr|predict" -d $OUT/other_configs/$name.pmc -- python3 tools/quick_bench.py "$@" --iters 2 > /dev/null 2>> $OUT/other_configs/$name.err
-    # matrix-core utilisation of the predictor kernels (predict_mfma.hip)
-    rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv --kernel-include-regex "predict" -d $OUT/other_configs/$name.pmc2 -- python3 tools/quick_bench.py "$@" --iters 2 > /dev/null 2>> $OUT/other_configs/$name.err
-    python3 tools/pmc_summary.py $OUT/other_configs/$name.pmc $OUT/other_configs/$name.pmc2 > $OUT/other_configs/${name}_pmc.txt; rm -rf $OUT/other_configs/$name.pmc $OUT/other_configs/$name.pmc2
+    python3 tools/pmc_summary.py $OUT/other_configs/$name.pmc > $OUT/other_configs/${name}_pmc.txt; rm -rf $OUT/other_configs/$name.pmc
     cat $OUT/other_configs/$name.txt
 }
-cfg cfg3_4096_32_16_8 --size 4096 --ws 32 --passes 3 --mode CWS --batch 16
-cfg cfg4_128_64 --size 2048 --ws 128 --passes 2 --mode CWS --batch 64
-python3 bench.py --e2e > $OUT/bench_e2e.json 2> $OUT/e2e.err || tail $OUT/e2e.err
+cfg cfg3_4096_32_16_8_fast --size 4096 --ws 32 --passes 3 --mode CWS --batch 16
+cfg cfg3_4096_32_16_8_f64 --size 4096 --ws 32 --passes 3 --mode CWS --batch 16 --precision f64
+cfg cfg4_128_64_fast --size 2048 --ws 128 --passes 2 --mode CWS --batch 64
+cfg cfg4_128_64_f64 --size 2048 --ws 128 --passes 2 --mode CWS --batch 64 --precision f64
+TPIV_LIB=tools/diag/libtorchpiv_hip_stamps.so python3 tools/stamp_f64.py > $OUT/stamps_f64.txt 2> $OUT/stamps.err || tail -3 $OUT/stamps.err
+python3 tools/dev/files_profile.py 8 8 8 spots 2 32 2> /dev/null | grep -v amdgpu.ids > $OUT/files_profile.txt
 python3 - $OUT <<'PY'
 import json, sys, glob, os
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):
     try:
         r = json.loads(open(f).read().strip().splitlines()[-1])
-        print(os.path.basename(f), "n_gpus", r.get("n_gpus"), round(r["value"]), r["unit"], r.get("dtype"), (r.get("roofline") or {}).get("kernel"), round((r.get("roofline") or {}).get("frac", 0), 4))
+        print(os.path.basename(f), "n_gpus", r.get("n_gpus"), round(r["value"]), r["unit"], r.get("dtype"), (r.get("roofline") or {}).get("kernel"), round((r.get("roofline") or {}).get("frac", 0), 4),
+              "fast", round((r.get("fast") or {}).get("value", 0)))
     except Exception as e:
         print(f, "unreadable", e)
 PY
