@@ -256,7 +256,9 @@ def e2e_block(r, log, n, workers):
                     "fallbacks + flip/scale + yield (ResidentPIV / OfflinePIV.batched)",
             "resident_clean_all_dropped": r.get("clean"), "resident_straight_runs": r.get("runs"),
             "resident_isolated_spots": r.get("spots"), "bmp_files_isolated_spots": r.get("files"),
-            "bmp_files_generator_call": r.get("files_call"), "post_validation": r.get("stats"), "log": log}
+            "bmp_files_generator_call": r.get("files_call"), "trials": r.get("trials"),
+            "note": "every figure is the median of three runs of pairs_per_case pairs (the distinct pairs streamed repeatedly)",
+            "post_validation": r.get("stats"), "log": log}
 
 
 def e2e_mode(args):

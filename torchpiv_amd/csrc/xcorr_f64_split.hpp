@@ -10,8 +10,9 @@
 //   workgroup = 128 threads = one window; thread t: lane = t & 63, wave wv = t >> 6
 //   R   rows forward     thread (y = lane, h = wv) loads the whole image row y of both frames, forms the DIF halves
 //                        u[j] = x[j] + x[j+32]  (h = 0)   /   (x[j] - x[j+32]) w64^j  (h = 1),  j = 0..31
-//                        (integer sums / differences of the bytes, exact), scales by 1/mean (B:513-514) and
-//                        transforms: X[y][2m + h] at x[fft_pos(m, 32)]
+//                        (integer sums / differences of the bytes, exact; a / mean, b / mean of B:513-514 are applied
+//                        later as ONE factor on the map, see rows_forward) and transforms: X[y][2m + h] at
+//                        x[fft_pos(m, 32)]
 //   T1  transposition    plane[y][kx] <- X, one float64 component at a time (64 x 65 doubles = 33 KB: four
 //                        workgroups per CU); thread (k = lane, g = 1 - wv) reads column k as the DIF halves over
 //                        the rows: u[i] = X[i][k] +- X[i+32][k], the odd half times w64^i
