@@ -7,7 +7,7 @@
 // trivial twiddles (1, -i, -1, i) cost nothing.  The output is left in
 // digit-reversed order: output bin k sits at fft_pos(k, N).
 //
-// The header also compiles as plain host C++ (tests/test_fft_codelets.py builds
+// The header also compiles as plain host C++ (tests/test_host_logic.py::test_fft_codelets_on_host builds
 // it with g++ and checks it against numpy.fft).
 #pragma once
 #include <type_traits>
