@@ -281,3 +281,41 @@ def test_generator_reads_ahead_like_the_one_pair_loop(tmp_path):
         assert len(got) == len(ref)
         for g_, r_ in zip(got, ref):
             assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(g_, r_)), cb
+
+
+@pytest.mark.gpu
+def test_batched_over_png_files_and_abandoned_generators(tmp_path):
+    """Formats the device cannot unpack never enter the native read-ahead ring (ReadAhead(read=False)): every file is
+    decoded on the host and the batch still runs as one launch -- same tuples as the one-pair loop.  A generator that
+    is abandoned half way must stop its reader threads (close()), and the next run over the same object starts clean."""
+    from PIL import Image
+    import torchpiv_amd as T
+    from torchpiv_amd import synth
+    for i in range(7):
+        a, b = synth.make_pair(256, 320, 90 + i, kind=("wavy", "vortex", "shear")[i % 3], noise=2.0)
+        a, b = a.numpy().copy(), b.numpy().copy()
+        a[100:130, 90:160] = 0
+        b[100:130, 90:160] = 0
+        for fmt in ("png", "bmp"):
+            Image.fromarray(a, "L").save(tmp_path / f"im{i:02d}_a.{fmt}")
+            Image.fromarray(b, "L").save(tmp_path / f"im{i:02d}_b.{fmt}")
+    kw = dict(wind_size=32, overlap=16, multipass=2, multipass_mode="DWS")
+    out = {}
+    for fmt in ("png", "bmp"):
+        piv = T.OfflinePIV(str(tmp_path), "cuda:0", fmt, **kw)
+        piv.call_batch = 1
+        ref = [tuple(np.array(t) for t in r) for r in piv()]
+        gen = piv.batched(3)
+        first = next(gen)                                   # abandon the generator with batches still to come
+        gen.close()
+        rd = piv._reader
+        assert rd._h is None                                # reader threads stopped and joined
+        got = [tuple(np.array(t) for t in r[1:]) for r in piv.batched(3)]
+        assert len(got) == len(ref) >= 5 and np.array_equal(first[3], ref[0][2], equal_nan=True)
+        for g_, r_ in zip(got, ref):
+            assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(g_, r_)), fmt
+        out[fmt] = got
+        piv.close()
+    # and the two formats hold the same pixels, so they give the same fields
+    for g_, r_ in zip(out["png"], out["bmp"]):
+        assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(g_, r_))

@@ -1,0 +1,19 @@
+"""Resident generator rate against the batch size (development aid)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torchpiv_amd as T
+import e2e_generator as E
+
+if __name__ == "__main__":
+    n, reps = 128, 8
+    for kind in ("spots", "clean"):
+        A, B = E.make_frames(n, 2048, 2048, kind)
+        for batch in (32, 64):
+            for workers in (8,):
+                piv = T.ResidentPIV(A, B, 64, 32, multipass=2, multipass_mode="CWS")
+                piv.fill_workers = workers
+                E.rate(piv.batched(batch), n)
+                r, k, rs = E.rate3(lambda: piv.batched(batch, indices=list(range(n)) * reps), n * reps)
+                print(f"{kind} batch {batch:3d} workers {workers:2d}: {r:8.1f} pairs/s  {rs}", flush=True)
+                piv.close()

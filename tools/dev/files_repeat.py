@@ -20,11 +20,13 @@ if __name__ == "__main__":
     del A, B
     fp = T.OfflinePIV(d, "cuda:0", "bmp", 64, 32, multipass=2, multipass_mode="CWS")
     fp.fill_workers = 8
-    E.rate(fp.batched(32, indices=range(n)), n)
-    for rnd in range(3):
-        r, k = E.rate(fp.batched(32), n * reps)
-        print(f"round {rnd} batched(32): {r:8.1f} pairs/s, yielded {k}")
-        r, k = E.rate(fp(), n * reps)
-        print(f"round {rnd} __call__   : {r:8.1f} pairs/s, yielded {k}")
+    for batch in (32, 64):
+        fp.call_batch = batch
+        E.rate(fp.batched(batch, indices=range(n)), n)
+        for rnd in range(3):
+            r, k = E.rate(fp.batched(batch), n * reps)
+            print(f"round {rnd} batched({batch}): {r:8.1f} pairs/s, yielded {k}", flush=True)
+            r, k = E.rate(fp(), n * reps)
+            print(f"round {rnd} __call__ ({batch}): {r:8.1f} pairs/s, yielded {k}", flush=True)
     fp.close()
     shutil.rmtree(d, ignore_errors=True)

@@ -21,6 +21,7 @@
 // 17.2 ms and 196 us.  128x128 windows ran the generic-size DFT kernel: 15.4 ms per pair, now 0.117 ms.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "piv_kernels.h"
 #include "xcorr_tile.hpp"      // grp_reduce: wavefront reductions in the VALU (DPP / permlane swaps)
@@ -286,7 +287,9 @@ template <int W>
 static hipError_t launch_f64_split(const PassParams& p, int n_cu, hipStream_t stream) {
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
     if (items <= 0) return hipErrorInvalidValue;
-    const int per_cu = W == 64 ? 4 : 1;              // LDS: 33.4 KB / 132.3 KB per workgroup
+    // LDS: 33.4 KB / 132.3 KB per workgroup  (TPIV_F64_PER_CU: A/B runs of the residency)
+    static const int per_cu_env = [] { const char* e_ = getenv("TPIV_F64_PER_CU"); return e_ ? atoi(e_) : 0; }();
+    const int per_cu = W == 64 ? (per_cu_env > 0 ? per_cu_env : 4) : 1;
     long long blocks = items < (long long)n_cu * per_cu ? items : (long long)n_cu * per_cu;
     blocks = (blocks + 7) / 8 * 8;
     hipLaunchKernelGGL((xcorr_f64_split_kernel<W>), dim3((unsigned)blocks), dim3(2 * W), 0, stream, p);
