@@ -16,6 +16,9 @@ MUTANT = os.path.join(ROOT, "tools", "diag", "libtorchpiv_hip_mutant.so")
 
 
 def test_parity_gates_catch_a_perturbed_lerp():
+    if not os.path.exists(MUTANT):          # normally built by `make` (build()); a bare checkout builds it here
+        subprocess.run(["make", "-C", os.path.join(ROOT, "torchpiv_amd", "csrc"), "-j", "8", "mutant"], check=True,
+                       timeout=1200)
     assert os.path.exists(MUTANT), "build the mutant library first (make -C torchpiv_amd/csrc)"
     env = dict(os.environ, TPIV_LIB=MUTANT)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "mutant_probe.py")], env=env, capture_output=True,
