@@ -36,22 +36,24 @@ constexpr int BH = 64;                // codelet length
 
 struct BigShared {
     float plane[BW * BP];
-    float redf[8];
-    int redi[8];
+    float redf[8];                  // (min, raw max) of the map
+    int redi[8];                    // row of the maximum / second peak
+    unsigned long long redu[4];     // window sums
 };
 
 // Workgroup barrier for LDS exchanges only: __syncthreads() also waits for vmcnt(0), which would
 // drain the next window's prefetch at every one of the ~30 barriers per window.
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// reduction over the 256 threads of the workgroup; every thread gets the result
+// Reduction over the 256 threads of the workgroup with ONE barrier; every thread gets the result.  Every call site has
+// its own four slots, which are written again a whole window later (many barriers on), so no barrier is needed in
+// front of the write.
 template <typename T, typename OP>
-__device__ __forceinline__ T block_reduce(T v, OP op, T* red, int wave, int lane) {
+__device__ __forceinline__ T block_reduce(T v, OP op, T* slots, int wave, int lane) {
     v = grp_reduce<64>(v, op);
+    if (lane == 0) slots[wave] = v;
     wg_barrier();
-    if (lane == 0) red[wave] = v;
-    wg_barrier();
-    return op(op(red[0], red[1]), op(red[2], red[3]));
+    return op(op(slots[0], slots[1]), op(slots[2], slots[3]));
 }
 
 // ---- stage 7 of the 128x128 kernel: peak analysis of one window's map (B:346-358, B:381-392, B:518).
@@ -68,28 +70,48 @@ __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[B
         asm volatile("" : "+v"(tq));
         const int ys = ((tq & 127) + 64) & 127;
         const int KD = BW * BW;
-        float cmin = 3.4e38f;
+        // one pass over the raw cells gives their minimum AND their maximum: v = (c - min) + 1e-7 is monotonic in c,
+        // so the maximum of the shifted cells is the shifted raw maximum (the same two roundings)
+        float cmin = c[0], rraw = c[0];
 #pragma unroll
-        for (int j = 0; j < BH; ++j) cmin = fminf(cmin, c[j]);
+        for (int j = 1; j < BH; ++j) {
+            cmin = fminf(cmin, c[j]);
+            rraw = fmaxf(rraw, c[j]);
+        }
         prefetch();
         auto fmin_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fminf(a, b); };
         auto fmax_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); };
         auto imin_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
         auto imax_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a > b ? a : b; };
-        cmin = block_reduce(cmin, fmin_, sm.redf, wave, lane);       // (also: plane reads of stage 6 done)
-        float rmax = 0.f;
+        float graw;
+        {   // (min, raw max) with one barrier  (also: plane reads of stage 6 done)
+            const float mn = grp_reduce<64>(cmin, fmin_), mx = grp_reduce<64>(rraw, fmax_);
+            if (lane == 0) {
+                sm.redf[wave] = mn;
+                sm.redf[4 + wave] = mx;
+            }
+            wg_barrier();
+            cmin = fminf(fminf(sm.redf[0], sm.redf[1]), fminf(sm.redf[2], sm.redf[3]));
+            graw = fmaxf(fmaxf(sm.redf[4], sm.redf[5]), fmaxf(sm.redf[6], sm.redf[7]));
+        }
+        const float gmax = __fadd_rn(__fsub_rn(graw, cmin), 1e-7f);
         static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
             constexpr int j = decltype(jc)::value;
             constexpr int xe = (2 * j + 64) & 127;
             const float v = __fadd_rn(__fsub_rn(c[j], cmin), 1e-7f);       // B:518, B:381
             c[j] = v;
             plane[ys * BP + xe + par] = v;
-            rmax = fmaxf(rmax, v);
         });
-        const float gmax = block_reduce(rmax, fmax_, sm.redf + 4, wave, lane);
-        const int ywin = block_reduce(rmax == gmax ? ys : BW - 1, imin_, sm.redi, wave, lane);   // map complete
-        const int xwin = block_reduce((t < BW && plane[ywin * BP + (t & 127)] == gmax) ? t : BW - 1, imin_,
-                                      sm.redi + 4, wave, lane);
+        const float rmax = __fadd_rn(__fsub_rn(rraw, cmin), 1e-7f);
+        // arg-max = FIRST flat index holding the maximum (B:383): the smallest row whose maximum is the global one, then
+        // the first column of that row -- every wavefront looks the row up itself (ballots), no further exchange
+        const int ywin = block_reduce(rmax == gmax ? ys : BW - 1, imin_, sm.redi, wave, lane);   // (also: map complete)
+        int xwin = BW - 1;
+#pragma unroll
+        for (int part = 1; part >= 0; --part) {
+            const unsigned long long hit = __ballot(plane[ywin * BP + 64 * part + lane] == gmax);
+            xwin = hit ? 64 * part + (int)__builtin_ctzll(hit) : xwin;
+        }
         const int m = ywin * BW + xwin;
         if (p.dbg_corr != nullptr) {
             float* d = p.dbg_corr + fidx * KD + ys * BW + par;
@@ -131,7 +153,7 @@ __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[B
                 smax = cand > smax ? cand : smax;
             });
         }
-        smax = block_reduce(smax, imax_, sm.redi, wave, lane);
+        smax = block_reduce(smax, imax_, sm.redi + 4, wave, lane);
         const float second_v = smax > 0 ? __int_as_float(smax) : gmax;
         if (t < 8) {
             int left = m + 1, right = m - 1, top = m + BW, bot = m - BW;     // B:385-392 (flat index)
@@ -219,8 +241,12 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                 x[j].x = byte_f<2 * j, 32>(da);
                 x[j].y = byte_f<2 * j, 32>(db);
             });
-            sa = (float)ia;
-            sb = (float)ib;
+            // window sums: exact integers (< 2^24), both in one reduction with one barrier
+            auto uadd = [](unsigned long long a, unsigned long long b) TPIV_LAMBDA_INLINE { return a + b; };
+            const unsigned long long s2_ =
+                block_reduce((unsigned long long)ia | ((unsigned long long)ib << 32), uadd, sm.redu, wave, lane);
+            sa = (float)(unsigned)s2_;
+            sb = (float)(unsigned)(s2_ >> 32);
         }
         if (p.dbg_win != nullptr) {       // test hook: the staged window
             float* d = p.dbg_win + fidx * 2 * BW * BW + line * BW + par;
@@ -230,9 +256,6 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                 d[BW * BW + 2 * j] = x[j].y;
             }
         }
-        auto fadd = [](float a, float b) TPIV_LAMBDA_INLINE { return a + b; };
-        sa = block_reduce(sa, fadd, sm.redf, wave, lane);          // exact: integers below 2^24
-        sb = block_reduce(sb, fadd, sm.redf + 4, wave, lane);
         const bool dead = (sa == 0.f) || (sb == 0.f);   // zero-mean window: 0/0 = NaN map in the reference
         {
             constexpr float PRE = 0.5f / (float)BW;     // 1/n^2 and the 1/4 of the cross-spectrum, exact
