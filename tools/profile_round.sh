@@ -4,7 +4,8 @@
 #                               run, the end_to_end block, live PMC counters and the CPU baseline)
 #   bench_n1_reference.json     the same at precision "reference" (reference-order CWS staging)
 #   bench_n1_config2.json       configs[2] stream
-#   bench_gloo2_*.json          2-rank gloo launch rehearsals of --gpus 2 (two ranks time-slicing ONE GPU: not a measurement)
+#   bench_gloo{2,4}_*.json      2- / 4-rank gloo launch rehearsals of --gpus N (the ranks time-slice ONE GPU: not a measurement)
+#   bench_soak2000.json         2000 timed steps of the headline workload
 #   rocprofv3_kernel_stats.csv  rocprofv3 --kernel-trace --stats of the headline command
 #   other_configs/              configs[3] / configs[4] at both precisions: quick_bench lines, kernel stats, SQ counters
 #   stamps_f64.txt              per-phase cycle shares of the float64 pass-1 kernel (stamped diagnostic build)
@@ -21,6 +22,9 @@ python3 bench.py --precision reference --no-cpu-baseline --no-fast --no-e2e > $O
 python3 bench.py --config 2 --no-cpu-baseline --no-e2e > $OUT/bench_n1_config2.json 2> $OUT/bench_c2.err || exit 1
 TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 2 --batch 64 --pmc off > $OUT/bench_gloo2_config1.json 2> $OUT/g2.err || exit 1
 TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --config 2 --steps 3 --stream 1000 --batch 250 --pmc off > $OUT/bench_gloo2_config2.json 2> $OUT/g2c2.err || exit 1
+TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 4 --steps 10 --warmup 2 --batch 32 --pmc off > $OUT/bench_gloo4_config1.json 2> $OUT/g4.err || exit 1
+# soak: 2000 timed steps of the headline workload (stability of the rate; no counters, no side measurements)
+python3 bench.py --steps 2000 --warmup 5 --pmc off --no-cpu-baseline --no-e2e --no-fast > $OUT/bench_soak2000.json 2> $OUT/soak.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv $R -d $OUT/stats -- python3 bench.py --steps 50 --warmup 5 --pmc off --no-cpu-baseline --no-e2e > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/rocprofv3_kernel_stats.csv && rm -rf $OUT/stats
 cfg() {   # name, quick_bench args
