@@ -127,13 +127,13 @@ __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[B
         {
             const int dj = ys - ywin;
             unsigned long long exl = 0ull, exh = 0ull;     // excluded columns 0..63 / 64..127 of this row
-            auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
+            auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {      // columns lo_ .. hi_, clipped to the row (closed form)
                 lo_ = lo_ < 0 ? 0 : lo_;
                 hi_ = hi_ > BW - 1 ? BW - 1 : hi_;
-                for (int q = lo_; q <= hi_; ++q) {         // at most 2 wv + 1 columns
-                    if (q < 64) exl |= 1ull << q;
-                    else exh |= 1ull << (q - 64);
-                }
+                const int ll = lo_, hl = hi_ < 63 ? hi_ : 63;               // low word
+                if (ll <= hl) exl |= (~0ull >> (63 - (hl - ll))) << ll;
+                const int lh = (lo_ > 64 ? lo_ : 64) - 64, hh = hi_ - 64;   // high word
+                if (lh <= hh) exh |= (~0ull >> (63 - (hh - lh))) << lh;
             };
             if (dj >= -wv && dj <= wv) span(xwin - wv, xwin + wv);
             if (dj + 1 >= -wv && dj + 1 <= wv) span(xwin - wv + BW, xwin + wv + BW);
