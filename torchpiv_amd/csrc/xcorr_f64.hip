@@ -61,6 +61,21 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
     __shared__ F64SplitShared<W> sm;
     double* const plane = sm.plane;
     const int tid = threadIdx.x;
+    // The thread index at the point of use.  128x128: lane id (two VALU instructions) + the wavefront's base in an SGPR --
+    // a copy of threadIdx.x kept across the loop is spilled and re-loaded from scratch in front of every phase there
+    // (7.14 -> 7.05 ms per 64 pairs).  64x64: an opaque copy of the register (the recomputation costs more than the
+    // re-loads: 16.40 vs 16.48 ms per 256 pairs, same box).
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    auto thread_index = [&]() TPIV_LAMBDA_INLINE {
+        if constexpr (W == 64) {
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            return t_;
+        } else {
+            return fresh_lane() | wave_base;
+        }
+    };
+#define TPIV_F64_TID() thread_index()
 
     const int N = p.n_rows * p.n_cols;
     const long long items = (long long)p.batch * N;
@@ -78,7 +93,8 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
     auto fetch = [&](long long it) TPIV_LAMBDA_INLINE {
         const int pair_ = (int)(it / N), win_ = (int)(it % N);
         const int yy0 = (win_ / p.n_cols) * st, xx0 = (win_ % p.n_cols) * st;
-        const size_t off = (size_t)pair_ * HW + (size_t)(yy0 + (tid & (W - 1))) * p.W + xx0;
+        const int t_ = W == 64 ? tid : TPIV_F64_TID();
+        const size_t off = (size_t)pair_ * HW + (size_t)(yy0 + (t_ & (W - 1))) * p.W + xx0;
         load_dwords<NDW>(p.A + off, da);
         load_dwords<NDW>(p.B + off, db);
     };
@@ -86,7 +102,11 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
     // window later, many barriers on)
     auto exchange = [&](auto v, auto op, auto* slots) TPIV_LAMBDA_INLINE {
         v = grp_reduce<64>(v, op);
-        if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = v;
+        if constexpr (W == 64) {
+            if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = v;
+        } else {
+            if (fresh_lane() == 0) slots[wave_base >> 6] = v;
+        }
         lds_barrier();
         auto r = slots[0];
 #pragma unroll
@@ -100,9 +120,8 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
 #ifdef TPIV_STAMPS
         ++st_iter;
 #endif
-        // (lane-derived values are re-made from an opaque copy of the thread index at every phase, so that the
+        // (lane-derived values are re-made from the thread index at every phase -- TPIV_F64_TID() -- so that the
         //  loop-invariant LDS addresses are not hoisted out of the item loop into registers)
-#define TPIV_F64_TID() [&]() TPIV_LAMBDA_INLINE { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; }()
         // ---- window sums: exact integers.  64x64: every wavefront holds all 64 rows (no exchange); 128x128: the rows of
         //      wavefronts 0 and 1 together
         unsigned ia = 0, ib = 0;
@@ -115,7 +134,7 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
             auto uadd = [](unsigned long long a, unsigned long long b) TPIV_LAMBDA_INLINE { return a + b; };
             unsigned long long s2 = grp_reduce<64>((unsigned long long)ia | ((unsigned long long)ib << 32), uadd);
             if constexpr (W == 128) {
-                if ((threadIdx.x & 63) == 0) sm.redu[threadIdx.x >> 6] = s2;
+                if (fresh_lane() == 0) sm.redu[wave_base >> 6] = s2;
                 lds_barrier();
                 s2 = sm.redu[0] + sm.redu[1];
             }
@@ -276,7 +295,10 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
             const int t_ = TPIV_F64_TID();
             sv = exchange(S::peak_second_local(c, t_ & (W - 1), t_ >> LB, m, p.val_win), dmax, sm.redd + 8);
         }
-        if (tid < 8) reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + tid] = S::peak_record_slot(tid, m, sv, dead, plane);
+        {
+            const int t_ = W == 64 ? tid : TPIV_F64_TID();
+            if (t_ < 8) reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + t_] = S::peak_record_slot(t_, m, sv, dead, plane);
+        }
         TPIV_STAMP(7);      // peak analysis incl. the issue of the next window's loads
 #undef TPIV_F64_TID
     }
