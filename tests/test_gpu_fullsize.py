@@ -73,6 +73,21 @@ def test_cfg3_geometry_against_oracle(mode):
         assert counts[-1][-1] == 255 * 383
 
 
+@pytest.mark.skipif(__import__("os").environ.get("TPIV_FULLSIZE") != "1",
+                    reason="opt-in (TPIV_FULLSIZE=1): several minutes of oracle time; output kept in profiles/r03/fullsize_cfg3.txt")
+def test_cfg3_full_size_against_oracle():
+    """configs[3] LITERALLY: one 4096 x 4096 pair, 32/16 -> 16/8 -> 8/4, 3-pass CWS, 1 046 529 final vectors, against
+    the oracle by the same three gates, at the default precision and at fast."""
+    from torchpiv_amd import engine, synth
+    from test_gpu_parity import cascade_check
+    a, b = synth.make_pair(4096, 4096, 987, kind="wavy", noise=2.0)
+    geo = [(32, 16), (16, 8), (8, 4)]
+    g = _oracle_fields(a.numpy(), b.numpy(), geo, "CWS", "cfg3full")
+    for precision in ("f64", "fast"):
+        counts = cascade_check(engine, g, "cfg3full", "CWS", precision, geo, max_differing=[8, 32, 128])
+        assert counts[-1][-1] == 1023 * 1023
+
+
 def test_large_windows_invariances():
     """128x128 pass 1: bit-identical fields wherever a pair sits in a batch, and cropping both frames
     by one grid step (64 px) moves the field by exactly one cell."""
