@@ -164,10 +164,34 @@ def cpu_baseline(H, W, ws, ov, n_pass, mode, n_kernels=8, n_e2e=4):
     # end to end like OfflinePIV.__call__ (B:873-901): the passes plus NaN-out, border interpolation,
     # Delaunay hole fill, flip and scaling (frames already decoded, as for the GPU figure)
     t1 = time.perf_counter()
-    n_yield = sum(1 for _ in O.offline_piv([pairs[k % len(pairs)] for k in range(n_e2e)], ws, ov, multipass=n_pass, mode=mode))
+    ref_out = list(O.offline_piv([pairs[k % len(pairs)] for k in range(n_e2e)], ws, ov, multipass=n_pass, mode=mode))
     dt2 = time.perf_counter() - t1
+    n_yield = len(ref_out)
+    # ... and the same pairs through the drop-in's generator on the GPU, compared tuple by tuple: a live parity datum at
+    # the BASELINE size in the driver's own record (reported, never gating; the gates are the -m gpu tests)
+    check = None
+    try:
+        import numpy as np
+        import torchpiv_amd as T
+        A = torch.stack([torch.from_numpy(pairs[k % len(pairs)][0]) for k in range(n_e2e)]).cuda()
+        B = torch.stack([torch.from_numpy(pairs[k % len(pairs)][1]) for k in range(n_e2e)]).cuda()
+        piv = T.ResidentPIV(A, B, ws, ov, multipass=n_pass, multipass_mode=mode)
+        got = list(piv())
+        piv.close()
+        check = {"gpu_yielded": len(got), "oracle_yielded": n_yield}
+        if len(got) == n_yield and n_yield:
+            # (the tuples carry u * scale / dt * 1000 with scale = dt = 1: back to pixels)
+            d_uv = max(float(np.nanmax(np.abs(g_[k_] - r_[k_]))) for g_, r_ in zip(got, ref_out) for k_ in (2, 3)) / 1000.0
+            d_xy = max(float(np.abs(g_[k_] - r_[k_]).max()) for g_, r_ in zip(got, ref_out) for k_ in (0, 1))
+            cells = sum(g_[2].size for g_ in got)
+            off = sum(int(((np.abs(g_[2] - r_[2]) > 1.0) | (np.abs(g_[3] - r_[3]) > 1.0)).sum()) for g_, r_ in zip(got, ref_out))
+            check.update({"max_abs_diff_uv_px": d_uv, "max_abs_diff_xy": d_xy, "cells": cells, "cells_beyond_1e-3_px": off,
+                          "nan_pattern_equal": all(np.array_equal(np.isnan(g_[2]), np.isnan(r_[2])) for g_, r_ in zip(got, ref_out))})
+    except Exception as exc:            # noqa: BLE001 -- a report, not a gate
+        check = {"error": repr(exc)}
     return {"value": n_kernels / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "end_to_end": {"value": n_e2e / dt2, "unit": "pairs/s", "pairs": n_e2e, "yielded": n_yield,
+                           "checked_against_the_gpu_generator": check,
                            "what": "oracle offline_piv on resident frames: passes + NaN-out + border interpolation + "
                                    "Delaunay hole fill + flip/scale (PIVbackend.py:873-901)"},
             "sample": f"{n_kernels} pairs (kernels only) + {n_e2e} pairs (end to end) of the same {H}x{W} {n_pass}-pass {mode} "
