@@ -52,6 +52,10 @@ def test_committed_bench_line_keeps_the_contract():
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == line["unit"] and c["sample"]
     assert c["end_to_end"]["pairs"] >= 4
+    chk = c["end_to_end"].get("checked_against_the_gpu_generator")
+    if chk is not None:               # the oracle's end-to-end tuples against the drop-in's generator, same pairs
+        assert "error" not in chk and chk["gpu_yielded"] == chk["oracle_yielded"]
+        assert chk.get("cells_beyond_1e-3_px", 0) == 0 and chk.get("nan_pattern_equal", True)
     # the all-float32 run and the generator end to end ride on the same line
     assert line["fast"]["dtype"] == "f32" and line["fast"]["value"] > line["value"]
     assert {"resident_isolated_spots", "bmp_files_generator_call", "post_validation"} <= set(line["end_to_end"])
