@@ -88,6 +88,60 @@ def test_cfg3_full_size_against_oracle():
         assert counts[-1][-1] == 1023 * 1023
 
 
+@pytest.mark.skipif(__import__("os").environ.get("TPIV_FULLSIZE") != "1",
+                    reason="opt-in (TPIV_FULLSIZE=1): renders a 4000-pair stream; output kept in profiles/r03/fullsize_cfg2.txt")
+def test_cfg2_stream_literally():
+    """configs[2] LITERALLY on one GPU: a 4000-pair stream of 2048 x 2048 frames, 64/32 -> 32/16 2-pass DWS, in 500-pair shards.
+    Size-independent properties over the WHOLE stream -- a pair's field does not depend on the shard it sits in (the
+    stream re-cut into 256-pair launches and 16 pairs re-run alone give the same bits) and a checksum of checksums is
+    stable across runs -- and a direct comparison of 12 pairs spread over the stream with the oracle."""
+    from torchpiv_amd import engine, synth
+    n, H, W, distinct = 4000, 2048, 2048, 200
+    # (rendering a pair takes ~0.1 s: 200 distinct pairs, laid out 20 times over in a shuffled order = 33 GB of frames)
+    A0, B0 = synth.make_batch(distinct, H, W, first_index=5000, noise=2.0, device="cuda")
+    print(f"  cfg2 stream: {distinct} distinct pairs rendered", flush=True)
+    order = torch.from_numpy(np.random.default_rng(4).permutation(n) % distinct).cuda()
+    A, B = A0[order], B0[order]
+    del A0, B0
+    plan = engine.Plan(H, W, 64, 32, n_pass=2, mode="DWS", max_batch=500, precision="f64")
+
+    def stream(step):
+        us, vs, ivs = [], [], []
+        for s0 in range(0, n, step):
+            u, v, inv = plan.run(A[s0:s0 + step], B[s0:s0 + step])
+            us.append(u.clone()), vs.append(v.clone()), ivs.append(inv.clone())
+        return torch.cat(us), torch.cat(vs), torch.cat(ivs)
+
+    u5, v5, i5 = stream(500)
+    print("  cfg2 stream: 500-pair shards done", flush=True)
+    u2, v2, i2 = stream(256)
+    assert torch.equal(u5, u2) and torch.equal(v5, v2) and torch.equal(i5, i2)
+    sums = (u5.view(torch.int64).sum(dim=(1, 2)) ^ v5.view(torch.int64).sum(dim=(1, 2))).cpu().numpy()
+    print(f"  cfg2 stream: {n} pairs, shards of 500 and 256 bit-identical; checksum of checksums {int(np.sum(sums * (np.arange(n, dtype=np.int64) * 2 + 1))) & 0xffffffffffffffff:#x}; "
+          f"invalid vectors {int(i5.sum())} of {i5.numel()}")
+    u5b, v5b, _ = stream(500)
+    assert torch.equal(u5, u5b) and torch.equal(v5, v5b)                       # run to run
+    one = engine.Plan(H, W, 64, 32, n_pass=2, mode="DWS", max_batch=1, precision="f64")
+    picks = [0, 1, 499, 500, 777, 1234, 1999, 2000, 2718, 3141, 3998, 3999]
+    worst = 0.0
+    for k in picks:
+        u1, v1, i1 = one.run(A[k], B[k])
+        assert torch.equal(u1[0], u5[k]) and torch.equal(v1[0], v5[k]) and torch.equal(i1[0], i5[k])
+        an, bn = A[k].cpu().numpy(), B[k].cpu().numpy()
+        ou, ov_, x, y, oval = O.pass1(an, bn, 64, 32, validate=True)
+        ou, ov_, x, y, oval = O.ITER["DWS"](an.shape, 32, 16)(an, bn, x, y, ou, ov_, oval)
+        gu, gv, gi = u5[k].cpu().numpy(), v5[k].cpu().numpy(), i5[k].cpu().numpy().astype(bool)
+        differ = (np.abs(gu - ou) > 1e-3) | (np.abs(gv - ov_) > 1e-3) | (gi != oval)
+        same = ~differ
+        worst = max(worst, float(np.maximum(np.abs(gu - ou), np.abs(gv - ov_))[same].max()))
+        print(f"  cfg2 stream pair {k}: {int(differ.sum())} of {differ.size} vectors differ from the oracle; max |d| elsewhere "
+              f"{float(np.maximum(np.abs(gu - ou), np.abs(gv - ov_))[same].max()):.2e} px")
+        assert differ.sum() <= 8                                                   # observed: 0
+    print(f"  cfg2 stream: worst |d| over {len(picks)} pairs {worst:.2e} px")
+    plan.close()
+    one.close()
+
+
 def test_large_windows_invariances():
     """128x128 pass 1: bit-identical fields wherever a pair sits in a batch, and cropping both frames
     by one grid step (64 px) moves the field by exactly one cell."""
