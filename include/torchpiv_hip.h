@@ -174,6 +174,18 @@ int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u_dev, doubl
 int tpiv_postval(double* u_dev, double* v_dev, const uint8_t* invalid_dev, int batch, int n_rows, int n_cols,
                  uint8_t* cls_dev, int32_t* counts_dev, void* stream);
 
+/* What fillMissingValues (B:296-302) hands to the interpolator, cut out of a batch on the device after tpiv_postval: for
+ * every pair that is kept (ring > 0, 4 ring < cells) AND holds an ambiguous or general hole, the ring cells
+ * (np.argwhere(neighbours), B:298: row-major order -- Qhull's triangulation depends on the insertion order, so the
+ * compaction preserves it) with their values, and all hole cells (np.argwhere(invalid_mask), B:297), packed pair after
+ * pair into flat lists:
+ *   offsets_dev [2, batch + 1] int32: row 0 = start of every pair's ring cells (last entry: total), row 1 = holes;
+ *   ring_rc_dev [total ring, 2] int32 (row, column), ring_uv_dev [total ring, 2] float64 (u, v), hole_rc_dev
+ *   [total holes, 2] int32.  The caller sizes ring_* for batch * ceil(cells / 4) entries and hole_rc for batch * cells. */
+int tpiv_postval_compact(const double* u_dev, const double* v_dev, const uint8_t* cls_dev, const int32_t* counts_dev,
+                         int batch, int n_rows, int n_cols, int32_t* offsets_dev, int32_t* ring_rc_dev,
+                         double* ring_uv_dev, int32_t* hole_rc_dev, void* stream);
+
 /* ---- ensemble statistics (workers.py:85-96 of the reference's job runner) ------------ */
 
 /* Mean and two-pass central moments of n stacked fields u_dev, v_dev [n, cells] float64 (dataset

@@ -272,6 +272,60 @@ def test_postval_device_vs_host(eng, golden):
     assert np.array_equal(got[~hole], g["pv_borders"][~hole])
 
 
+def test_postval_compact_lists_are_argwhere_lists(eng):
+    """tpiv_postval_compact: for every pair that needs the host triangulation the packed ring cells, their values and
+    the hole cells are np.argwhere's lists of the class map (row-major: Qhull's insertion order) -- bit for bit; pairs
+    that are dropped or complete on the device take no room.  And the generator gives the same tuples when the lists do
+    not fit the asynchronous copy (RING_CAP = 1: the synchronous overflow fetch)."""
+    rng = np.random.default_rng(8)
+    nr, nc = 37, 41
+    names, us, vs, ms = [], [], [], []
+    for rep in range(3):
+        for name, m in _random_masks(rng, nr, nc):
+            names.append(name)
+            us.append(rng.standard_normal((nr, nc)))
+            vs.append(rng.standard_normal((nr, nc)))
+            ms.append(m)
+    U = torch.from_numpy(np.stack(us)).cuda()
+    V = torch.from_numpy(np.stack(vs)).cuda()
+    M = torch.from_numpy(np.stack(ms).astype(np.uint8)).cuda()
+    cls, counts = eng.postval(U, V, M)
+    off, rc, uv, hc = (t.cpu().numpy() for t in eng.postval_compact(U, V, cls, counts))
+    cls_h, cnt, Uh, Vh = cls.cpu().numpy(), counts.cpu().numpy().astype(np.int64), U.cpu().numpy(), V.cpu().numpy()
+    B = len(names)
+    n_need = 0
+    for k in range(B):
+        need = cnt[k, 1] > 0 and 4 * cnt[k, 1] < nr * nc and cnt[k, 2] + cnt[k, 3] > 0
+        r0, r1, h0, h1 = off[0, k], off[0, k + 1], off[1, k], off[1, k + 1]
+        if not need:
+            assert r0 == r1 and h0 == h1, names[k]
+            continue
+        n_need += 1
+        ring, hole = cls_h[k] == 5, (cls_h[k] >= 1) & (cls_h[k] <= 4)
+        assert np.array_equal(rc[r0:r1], np.argwhere(ring)), names[k]
+        assert np.array_equal(hc[h0:h1], np.argwhere(hole)), names[k]
+        assert np.array_equal(uv[r0:r1, 0], Uh[k][ring]) and np.array_equal(uv[r0:r1, 1], Vh[k][ring]), names[k]
+    assert n_need >= 6 and off[0, B] == off[0, B - 1] + (off[0, B] - off[0, B - 1])
+    # overflow path of the generator
+    import torchpiv_amd as T
+    from torchpiv_amd import synth
+    A, Bf = synth.make_batch(6, 256, 320, first_index=40, noise=2.0, device="cuda")
+    for i in range(6):
+        for (y, x) in ((60, 70), (150, 200), (200, 90)):
+            A[i, y:y + 40, x:x + 40 + 8 * i] = 0
+            Bf[i, y:y + 40, x:x + 40 + 8 * i] = 0
+    outs = []
+    for cap in (256, 1):
+        piv = T.ResidentPIV(A, Bf, 32, 16, multipass=2, multipass_mode="CWS")
+        piv.RING_CAP = cap
+        outs.append([tuple(np.array(t) for t in r) for r in piv.batched(4)])
+        assert piv.stats["host_fallback"] >= 4
+        piv.close()
+    assert len(outs[0]) == len(outs[1]) >= 4
+    for g_, r_ in zip(*outs):
+        assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(g_, r_))
+
+
 def test_postval_single_row_or_column_grid(eng):
     """A final grid with ONE row or column (a short frame under a large window): tpiv_postval accepts it and the
     census drops the pair like the reference does (its interpolator has no usable ring: Qhull refuses collinear

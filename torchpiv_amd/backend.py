@@ -425,21 +425,31 @@ class OfflinePIV:
             pl.close()
         self._single_plans = {}
 
-    def _post_submit(self, u, v, inv):
+    RING_CAP = 256           # ring / hole cells per pair (batch average) that ride on the first, asynchronous copy
+
+    def _post_submit(self, u, v, inv, want_raw=False):
         """Device half of B:884-898 for a batch of final fields (u, v float64 [n, nr, nc], modified in
-        place; inv uint8): tpiv_postval, the flip and the unit scaling of B:894-898 (the reference's own float64
-        expressions -- u * scale / dt * 1000, three correctly rounded operations -- evaluated by the device on the whole
-        batch: bit-identical, and the host is spared five passes over every field), then ASYNCHRONOUS copies of the census,
-        the raw fields (the triangulation of the hole fill works on the unscaled ring values, like the reference), the
-        finished fields and the class map into pinned memory.  Nothing here waits for the GPU: the caller may enqueue the
-        next batch before it collects this one."""
+        place; inv uint8): tpiv_postval (NaN-out, border interpolation, census, triangulation-free fills),
+        tpiv_postval_compact (the ring points with their values and the hole cells of the pairs that need Qhull, cut out
+        and packed in np.argwhere order on the device), the flip and the unit scaling of B:894-898 (the reference's own
+        float64 expressions -- u * scale / dt * 1000, three correctly rounded operations -- evaluated by the device on
+        the whole batch: bit-identical, and the host is spared five passes over every field), then ASYNCHRONOUS copies of
+        the census, the packed lists and the finished fields into pinned memory, on a stream of their own.  Nothing here
+        waits for the GPU: the caller may enqueue the next batch before it collects this one.  want_raw: also the raw
+        (unflipped, unscaled) fields, for callers of the function-level API."""
         cls, counts = engine.postval(u, v, inv)
+        offsets, ring_rc, ring_uv, hole_rc = engine.postval_compact(u, v, cls, counts)
         fu = torch.flip(u, dims=(1,)) * self._scale / self._dt * 1000
         fv = -torch.flip(v, dims=(1,)) * self._scale / self._dt * 1000
-        src = (counts, u, v, cls, fu, fv)
-        host = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for t in src]
-        # the copies (16 MB per batch of 32 at 4 MP) go down on a stream of their own, behind an event of the compute
-        # stream: the next batch's passes start while they run
+        n = u.shape[0]
+        cap_r, cap_h = min(ring_rc.shape[0], n * self.RING_CAP), min(hole_rc.shape[0], n * self.RING_CAP)
+        src = {"counts": counts, "offsets": offsets, "ring_rc": ring_rc[:cap_r], "ring_uv": ring_uv[:cap_r],
+               "hole_rc": hole_rc[:cap_h], "fu": fu, "fv": fv}
+        if want_raw:
+            src["u"], src["v"] = u, v
+        host = {k: torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for k, t in src.items()}
+        # the copies go down on a stream of their own, behind an event of the compute stream: the next batch's passes
+        # start while they run
         cur = torch.cuda.current_stream(u.device)
         down = getattr(self, "_down_stream", None)
         if down is None or down.device != u.device:
@@ -448,22 +458,22 @@ class OfflinePIV:
         ready.record(cur)
         with torch.cuda.stream(down):
             down.wait_event(ready)
-            for h, t in zip(host, src):
-                h.copy_(t, non_blocking=True)
+            for k, t in src.items():
+                host[k].copy_(t, non_blocking=True)
             done = torch.cuda.Event()
             done.record(down)
-        return done, host, src          # (the device tensors stay referenced until collected, i.e. past `done`)
+        # (the device tensors stay referenced until collected, i.e. past `done`; the full lists for the overflow path)
+        return done, host, (src, ring_rc, ring_uv, hole_rc, u, v)
 
     def _post_extract(self, ticket):
-        """Host half, first stage: drop decisions from the census; for the pairs that hold an ambiguous or wide hole
-        (counted) the ring points, their values and the hole cells are cut out of the batch in one sweep and handed to the
-        triangulation -- asynchronously when a worker pool is on (fill_workers > 0): the result is picked up by
-        _post_complete, normally a batch later.  Returns the state _post_complete takes."""
-        done, host, _keep_alive = ticket
+        """Host half, first stage: drop decisions from the census; the pairs that hold an ambiguous or wide hole
+        (counted) arrive with their ring points, values and hole cells already cut out (tpiv_postval_compact) and go to
+        the triangulation -- in worker processes when fill_workers > 0.  Returns the state _post_complete takes."""
+        done, host, keep_alive = ticket
         done.synchronize()
-        cnt = host[0].numpy().astype(np.int64)                       # [n, 4] holes, ring, ambiguous, general
-        uk, vk, ck = host[1].numpy(), host[2].numpy(), host[3].numpy()
-        n, nr, nc = uk.shape
+        cnt = host["counts"].numpy().astype(np.int64)                # [n, 4] holes, ring, ambiguous, general
+        nr, nc = host["fu"].shape[1:]
+        n = cnt.shape[0]
         ring = cnt[:, 1]
         no_ring = ring == 0                  # nothing to interpolate from (B:300-304; the clean-pair quirk)
         too_many = ~no_ring & (4 * ring >= nr * nc)                  # points.size >= mask.size / 2 (B:299, 305)
@@ -476,24 +486,19 @@ class OfflinePIV:
         st["device_complete"] += int((keep & ~need_host).sum())
         for _ in range(2 * int(too_many.sum())):                  # once for u, once for v (B:306, B:889-890)
             print(TOO_MANY_MSG)
-        state = {"uk": uk, "vk": vk, "keep": keep, "need": np.flatnonzero(need_host), "host": host, "pending": None}
+        state = {"keep": keep, "need": np.flatnonzero(need_host), "host": host}
         if state["need"].size:
-            # (np.argwhere over the stack lists pair after pair, row-major inside a pair: the reference's order)
-            holes = (ck >= 1) & (ck <= 4)
-            holes[~need_host] = False
-            rings = np.zeros_like(holes)
-            rings[:, 1:, :] |= holes[:, :-1, :]
-            rings[:, :-1, :] |= holes[:, 1:, :]
-            rings[:, :, 1:] |= holes[:, :, :-1]
-            rings[:, :, :-1] |= holes[:, :, 1:]
-            rings &= ~holes
-            hp, rp = np.argwhere(holes), np.argwhere(rings)
-            vals = np.stack([uk[rings], vk[rings]], axis=1)
-            edges = np.append(state["need"], n)
-            h_cut, r_cut = np.searchsorted(hp[:, 0], edges), np.searchsorted(rp[:, 0], edges)
-            jobs = [(rp[r_cut[k]:r_cut[k + 1], 1:], vals[r_cut[k]:r_cut[k + 1]], hp[h_cut[k]:h_cut[k + 1], 1:])
-                    for k in range(state["need"].size)]
-            state["hp"], state["h_cut"] = hp, h_cut
+            off = host["offsets"].numpy()                            # [2, n + 1]: ring / hole list starts per pair
+            rc, uv, hc = host["ring_rc"].numpy(), host["ring_uv"].numpy(), host["hole_rc"].numpy()
+            tot_r, tot_h = int(off[0, n]), int(off[1, n])
+            if tot_r > rc.shape[0] or tot_h > hc.shape[0]:
+                # heavily damaged fields: the lists are longer than the asynchronous copy carried -- fetch them whole
+                _, ring_rc, ring_uv, hole_rc, _, _ = keep_alive
+                rc, uv, hc = ring_rc[:tot_r].cpu().numpy(), ring_uv[:tot_r].cpu().numpy(), hole_rc[:tot_h].cpu().numpy()
+            # (the lists list pair after pair, row-major inside a pair: np.argwhere's order, the reference's)
+            jobs = [(rc[off[0, k]:off[0, k + 1]], uv[off[0, k]:off[0, k + 1]], hc[off[1, k]:off[1, k + 1]])
+                    for k in state["need"]]
+            state["holes"] = [j[2] for j in jobs]
             pool = self._fill_pool()
             if pool is not None:
                 per = max(1, -(-len(jobs) // (2 * self.fill_workers)))          # two tasks per worker and batch
@@ -506,36 +511,40 @@ class OfflinePIV:
         return state
 
     def _post_complete(self, state):
-        """Second stage: the triangulation's values go into the raw fields and -- flipped and scaled with the reference's
-        expressions, cell by cell -- into the finished ones.  Returns the per-pair keep flags (False: dropped)."""
-        uk, vk, keep, need = state["uk"], state["vk"], state["keep"].copy(), state["need"]
+        """Second stage: the triangulation's values go -- flipped and scaled with the reference's expressions, cell by
+        cell -- into the finished fields (and into the raw ones when they were asked for).  Returns the state with the
+        per-pair keep flags (False: dropped)."""
+        keep, need, host = state["keep"].copy(), state["need"], state["host"]
         if need.size:
-            sols = state["sols"] if state["pending"] is None else [s_ for part in state["pending"].get() for s_ in part]
-            hp, h_cut, st = state["hp"], state["h_cut"], self.stats
-            fu, fv = state["host"][4].numpy(), state["host"][5].numpy()
-            nr = uk.shape[1]
-            for k, vals_k in enumerate(sols):
+            st = self.stats
+            fu, fv = host["fu"].numpy(), host["fv"].numpy()
+            uk, vk = (host["u"].numpy(), host["v"].numpy()) if "u" in host else (None, None)
+            nr = fu.shape[1]
+            for k, vals_k in enumerate(state["sols"]):
                 i = int(need[k])
                 st["host_fallback"] += 1
                 if vals_k is None:
                     st["dropped_by_qhull"] += 1
                     keep[i] = False
                     continue
-                cells = hp[h_cut[k]:h_cut[k + 1], 1:]
-                uk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 0]
-                vk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 1]
+                cells = state["holes"][k]
+                if uk is not None:
+                    uk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 0]
+                    vk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 1]
                 fu[i][nr - 1 - cells[:, 0], cells[:, 1]] = vals_k[:, 0] * self._scale / self._dt * 1000
                 fv[i][nr - 1 - cells[:, 0], cells[:, 1]] = -vals_k[:, 1] * self._scale / self._dt * 1000
         state["keep_final"] = keep
         return state
 
     def _post_collect(self, ticket):
-        """Both host stages at once; per pair None (dropped) or the raw (u, v) before the flip / scaling."""
+        """Both host stages at once; per pair None (dropped) or the raw (u, v) before the flip / scaling (the ticket
+        must come from _post_submit(..., want_raw=True))."""
         state = self._post_complete(self._post_extract(ticket))
-        return [(state["uk"][i], state["vk"][i]) if state["keep_final"][i] else None for i in range(state["uk"].shape[0])]
+        uk, vk = state["host"]["u"].numpy(), state["host"]["v"].numpy()
+        return [(uk[i], vk[i]) if state["keep_final"][i] else None for i in range(uk.shape[0])]
 
     def _post_validate_batch(self, u, v, inv):
-        return self._post_collect(self._post_submit(u, v, inv))
+        return self._post_collect(self._post_submit(u, v, inv, want_raw=True))
 
     def _post_pipeline(self, x, y, depth=1):
         """The host side of batched() as a pipeline: push(meta, ticket) after every launch returns the finished
@@ -575,7 +584,7 @@ class OfflinePIV:
         keep = state["keep_final"]
         if not keep.any():
             return [None] * keep.size
-        U, V = np.array(state["host"][4].numpy()), np.array(state["host"][5].numpy())
+        U, V = np.array(state["host"]["fu"].numpy()), np.array(state["host"]["fv"].numpy())
         xs, ys = x * self._scale, y * self._scale
         xs.flags.writeable = False
         ys.flags.writeable = False

@@ -785,6 +785,18 @@ int tpiv_postval(double* u, double* v, const uint8_t* invalid, int batch, int n_
     return TPIV_OK;
 }
 
+int tpiv_postval_compact(const double* u, const double* v, const uint8_t* cls, const int32_t* counts, int batch, int n_rows,
+                         int n_cols, int32_t* offsets, int32_t* ring_rc, double* ring_uv, int32_t* hole_rc, void* stream) {
+    if (batch < 0 || n_rows < 1 || n_cols < 1) return fail(TPIV_EINVAL, "tpiv_postval_compact: empty grid");
+    if ((long long)batch * n_rows * n_cols >= (1LL << 30)) return fail(TPIV_EUNSUPPORTED, "batch of fields too large");
+    if (batch == 0) return TPIV_OK;
+    if (!u || !v || !cls || !counts || !offsets || !ring_rc || !ring_uv || !hole_rc)
+        return fail(TPIV_EINVAL, "tpiv_postval_compact: null pointer");
+    HIP_TRY(tpiv::launch_postval_compact(u, v, cls, counts, batch, n_rows, n_cols, offsets, ring_rc, ring_uv, hole_rc,
+                                         (hipStream_t)stream));
+    return TPIV_OK;
+}
+
 int tpiv_ensemble_moments(const double* u, const double* v, int n, long long cells, double* out, void* stream) {
     if (n <= 0 || cells <= 0) return fail(TPIV_EINVAL, "tpiv_ensemble_moments: needs at least one field");
     if (!u || !v || !out) return fail(TPIV_EINVAL, "tpiv_ensemble_moments: null pointer");

@@ -149,6 +149,81 @@ __global__ __launch_bounds__(256) void postval_classify_kernel(PostvalParams p) 
     }
 }
 
+// ---- hand-over to the host triangulation: what fillMissingValues (B:284-308) feeds to the interpolator, cut out of
+// the batch on the device.  A pair "needs the host" when it is kept (ring > 0, 4 ring < cells) and holds an ambiguous
+// or general hole; for those pairs the ring cells (B:298 np.argwhere(neighbours): ROW-MAJOR order -- Qhull's result
+// depends on the insertion order, so the compaction is order-preserving) with their (u, v) and all hole cells
+// (np.argwhere(invalid_mask), same order) are packed pair after pair into three flat lists.
+__global__ void postval_offsets_kernel(const int* __restrict__ counts, int batch, int cells, int* __restrict__ offsets) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int r = 0, h = 0;
+    for (int i = 0; i < batch; ++i) {
+        const int holes = counts[4 * i], ring = counts[4 * i + 1], amb = counts[4 * i + 2], gen = counts[4 * i + 3];
+        const bool need = ring > 0 && 4LL * ring < (long long)cells && (amb + gen) > 0;
+        offsets[i] = r;
+        offsets[batch + 1 + i] = h;
+        r += need ? ring : 0;
+        h += need ? holes : 0;
+    }
+    offsets[batch] = r;
+    offsets[2 * batch + 1] = h;
+}
+
+__global__ __launch_bounds__(256) void postval_compact_kernel(const double* __restrict__ U, const double* __restrict__ V,
+                                                              const uint8_t* __restrict__ CLS, const int* __restrict__ offsets,
+                                                              int batch, int n_rows, int n_cols, int* __restrict__ ring_rc,
+                                                              double* __restrict__ ring_uv, int* __restrict__ hole_rc) {
+    const int pair = blockIdx.x;
+    const int r0 = offsets[pair], r1 = offsets[pair + 1];
+    const int h0 = offsets[batch + 1 + pair];
+    if (r1 == r0) return;                                  // dropped or complete on the device: nothing to hand over
+    const size_t off = (size_t)pair * n_rows * n_cols;
+    const double* u = U + off;
+    const double* v = V + off;
+    const uint8_t* cls = CLS + off;
+    const int n = n_rows * n_cols;
+    __shared__ int wsum[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int done_r = 0, done_h = 0;                            // cells of both kinds in the chunks before this one
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        const uint8_t c = i < n ? cls[i] : (uint8_t)PV_VALID;
+        const bool is_r = c == PV_RING, is_h = is_hole(c);
+        const unsigned long long br = __ballot(is_r), bh = __ballot(is_h);
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        if (lane == 0) {
+            wsum[0][wave] = __popcll(br);
+            wsum[1][wave] = __popcll(bh);
+        }
+        __syncthreads();
+        int pr = done_r + __popcll(br & below), ph = done_h + __popcll(bh & below);
+        int tr = 0, th = 0;
+#pragma unroll
+        for (int w_ = 0; w_ < 4; ++w_) {
+            pr += w_ < wave ? wsum[0][w_] : 0;
+            ph += w_ < wave ? wsum[1][w_] : 0;
+            tr += wsum[0][w_];
+            th += wsum[1][w_];
+        }
+        if (i < n) {
+            const int r = i / n_cols, cc = i - r * n_cols;
+            if (is_r) {
+                ring_rc[2 * (size_t)(r0 + pr)] = r;
+                ring_rc[2 * (size_t)(r0 + pr) + 1] = cc;
+                ring_uv[2 * (size_t)(r0 + pr)] = u[i];
+                ring_uv[2 * (size_t)(r0 + pr) + 1] = v[i];
+            }
+            if (is_h) {
+                hole_rc[2 * (size_t)(h0 + ph)] = r;
+                hole_rc[2 * (size_t)(h0 + ph) + 1] = cc;
+            }
+        }
+        done_r += tr;
+        done_h += th;
+        __syncthreads();                                   // wsum is rewritten by the next chunk
+    }
+}
+
 // ---- ensemble moments (workers.py:85-96): one thread per grid cell walks the stack of fields IN ORDER,
 // like numpy's reduction along the stack axis: mean = ((f0 + f1) + f2 ...) / n, then the two-pass
 // central moments sum_k (f_k - mean)^2 / n.  No contraction: numpy rounds the product and the sum apart.
@@ -183,6 +258,16 @@ __global__ __launch_bounds__(256) void ensemble_moments_kernel(const double* __r
 hipError_t launch_ensemble_moments(const double* U, const double* V, int n, long long cells, double* out, hipStream_t stream) {
     if (n <= 0 || cells <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ensemble_moments_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, U, V, n, cells, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_postval_compact(const double* u, const double* v, const uint8_t* cls, const int* counts, int batch, int n_rows,
+                                  int n_cols, int* offsets, int* ring_rc, double* ring_uv, int* hole_rc, hipStream_t stream) {
+    hipLaunchKernelGGL(postval_offsets_kernel, dim3(1), dim3(64), 0, stream, counts, batch, n_rows * n_cols, offsets);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(postval_compact_kernel, dim3(batch), dim3(256), 0, stream, u, v, cls, offsets, batch, n_rows, n_cols,
+                       ring_rc, ring_uv, hole_rc);
     return hipGetLastError();
 }
 

@@ -208,6 +208,25 @@ def postval(u, v, inv):
     return cls, counts
 
 
+def postval_compact(u, v, cls, counts):
+    """After postval: the ring cells (with their u, v) and the hole cells of the pairs that need the host
+    triangulation, packed pair after pair in np.argwhere order (tpiv_postval_compact).  Returns (offsets int32
+    [2, B + 1], ring_rc int32 [R, 2], ring_uv float64 [R, 2], hole_rc int32 [Hc, 2]) with the capacities R = B *
+    ceil(cells / 4), Hc = B * cells; the used prefixes are offsets[0, B] and offsets[1, B] entries long."""
+    _need_cuda(u, v, cls, counts)
+    B, nr, nc = u.shape
+    cells = nr * nc
+    offsets = torch.empty(2, B + 1, dtype=torch.int32, device=u.device)
+    ring_rc = torch.empty(B * ((cells + 3) // 4), 2, dtype=torch.int32, device=u.device)
+    ring_uv = torch.empty(B * ((cells + 3) // 4), 2, dtype=torch.float64, device=u.device)
+    hole_rc = torch.empty(B * cells, 2, dtype=torch.int32, device=u.device)
+    with torch.cuda.device(u.device):
+        check(lib.tpiv_postval_compact(u.data_ptr(), v.data_ptr(), cls.data_ptr(), counts.data_ptr(), B, nr, nc,
+                                       offsets.data_ptr(), ring_rc.data_ptr(), ring_uv.data_ptr(), hole_rc.data_ptr(),
+                                       _stream()))
+    return offsets, ring_rc, ring_uv, hole_rc
+
+
 def ensemble_moments(U, V):
     """(mean u, mean v, <u'u'>, <v'v'>, <u'v'>) of stacked fields U, V float64 [n, ...] on the GPU, accumulated in
     stack order like numpy (tpiv_ensemble_moments)."""
