@@ -186,6 +186,12 @@ int tpiv_postval_compact(const double* u_dev, const double* v_dev, const uint8_t
                          int batch, int n_rows, int n_cols, int32_t* offsets_dev, int32_t* ring_rc_dev,
                          double* ring_uv_dev, int32_t* hole_rc_dev, void* stream);
 
+/* B:894-898 for a batch of final fields [batch, n_rows, n_cols]: fu = flip(u, axis 0) * scale / dt * 1000,
+ * fv = -flip(v, axis 0) * scale / dt * 1000 -- the reference's float64 expression, left to right, three correctly
+ * rounded operations per value: bit-identical to numpy's.  (x, y are not flipped, B:899-900.) */
+int tpiv_finish_fields(const double* u_dev, const double* v_dev, int batch, int n_rows, int n_cols, double scale,
+                       double dt, double* fu_dev, double* fv_dev, void* stream);
+
 /* ---- ensemble statistics (workers.py:85-96 of the reference's job runner) ------------ */
 
 /* Mean and two-pass central moments of n stacked fields u_dev, v_dev [n, cells] float64 (dataset

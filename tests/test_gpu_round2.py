@@ -326,6 +326,23 @@ def test_postval_compact_lists_are_argwhere_lists(eng):
         assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(g_, r_))
 
 
+def test_finish_fields_is_the_reference_expression_bit_for_bit(eng):
+    """tpiv_finish_fields = B:894-898 on the device: flip along the rows, sign of v, `u * scale / dt * 1000` left to
+    right -- numpy's bits for ordinary values, zeros of either sign, subnormals and huge values, for several scales."""
+    rng = np.random.default_rng(21)
+    u = rng.standard_normal((3, 17, 23)) * 10.0 ** rng.integers(-12, 12, size=(3, 17, 23))
+    v = rng.standard_normal((3, 17, 23)) * 10.0 ** rng.integers(-12, 12, size=(3, 17, 23))
+    u[0, 0, :4] = [0.0, -0.0, 5e-324, -2.5e-310]
+    v[1, 3, :4] = [0.0, -0.0, 1.7e308, -1.7e308]
+    for scale, dt in ((1.0, 1), (0.02, 12), (0.013, 7), (3.3e-5, 1000)):
+        fu, fv = eng.finish_fields(torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda(), scale, dt)
+        with np.errstate(over="ignore"):
+            ru = np.flip(u, axis=1) * scale / dt * 1000
+            rv = -np.flip(v, axis=1) * scale / dt * 1000
+        assert np.array_equal(fu.cpu().numpy().view(np.int64), ru.view(np.int64)), (scale, dt)
+        assert np.array_equal(fv.cpu().numpy().view(np.int64), rv.view(np.int64)), (scale, dt)
+
+
 def test_postval_single_row_or_column_grid(eng):
     """A final grid with ONE row or column (a short frame under a large window): tpiv_postval accepts it and the
     census drops the pair like the reference does (its interpolator has no usable ring: Qhull refuses collinear

@@ -69,6 +69,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_void_p)]),
     "tpiv_postval": (C.c_int, [_f64p, _f64p, _u8p, _int, _int, _int, _u8p, _vp, _vp]),
     "tpiv_postval_compact": (C.c_int, [_f64p, _f64p, _u8p, _vp, _int, _int, _int, _vp, _vp, _f64p, _vp, _vp]),
+    "tpiv_finish_fields": (C.c_int, [_f64p, _f64p, _int, _int, _int, C.c_double, C.c_double, _f64p, _f64p, _vp]),
     "tpiv_ensemble_moments": (C.c_int, [_f64p, _f64p, _int, C.c_longlong, _f64p, _vp]),
     "tpiv_bmp_unpack": (C.c_int, [_u8p, _vp, _u8p, _int, _int, _int, _u8p, _vp]),
     "tpiv_read_files": (C.c_int, [C.POINTER(C.c_char_p), _int, C.c_void_p, C.c_size_t, _int, C.POINTER(C.c_longlong)]),

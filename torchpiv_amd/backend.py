@@ -439,8 +439,7 @@ class OfflinePIV:
         (unflipped, unscaled) fields, for callers of the function-level API."""
         cls, counts = engine.postval(u, v, inv)
         offsets, ring_rc, ring_uv, hole_rc = engine.postval_compact(u, v, cls, counts)
-        fu = torch.flip(u, dims=(1,)) * self._scale / self._dt * 1000
-        fv = -torch.flip(v, dims=(1,)) * self._scale / self._dt * 1000
+        fu, fv = engine.finish_fields(u, v, self._scale, self._dt)
         n = u.shape[0]
         cap_r, cap_h = min(ring_rc.shape[0], n * self.RING_CAP), min(hole_rc.shape[0], n * self.RING_CAP)
         src = {"counts": counts, "offsets": offsets, "ring_rc": ring_rc[:cap_r], "ring_uv": ring_uv[:cap_r],

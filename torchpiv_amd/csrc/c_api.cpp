@@ -797,6 +797,15 @@ int tpiv_postval_compact(const double* u, const double* v, const uint8_t* cls, c
     return TPIV_OK;
 }
 
+int tpiv_finish_fields(const double* u, const double* v, int batch, int n_rows, int n_cols, double scale, double dt,
+                       double* fu, double* fv, void* stream) {
+    if (batch < 0 || n_rows < 1 || n_cols < 1) return fail(TPIV_EINVAL, "tpiv_finish_fields: empty grid");
+    if (batch == 0) return TPIV_OK;
+    if (!u || !v || !fu || !fv) return fail(TPIV_EINVAL, "tpiv_finish_fields: null pointer");
+    HIP_TRY(tpiv::launch_finish_fields(u, v, batch, n_rows, n_cols, scale, dt, fu, fv, (hipStream_t)stream));
+    return TPIV_OK;
+}
+
 int tpiv_ensemble_moments(const double* u, const double* v, int n, long long cells, double* out, void* stream) {
     if (n <= 0 || cells <= 0) return fail(TPIV_EINVAL, "tpiv_ensemble_moments: needs at least one field");
     if (!u || !v || !out) return fail(TPIV_EINVAL, "tpiv_ensemble_moments: null pointer");

@@ -102,6 +102,9 @@ hipError_t launch_postval(const PostvalParams& p, hipStream_t stream);
 // ring / hole lists of the pairs that need the host triangulation, packed pair after pair in np.argwhere order
 hipError_t launch_postval_compact(const double* u, const double* v, const uint8_t* cls, const int* counts, int batch, int n_rows,
                                   int n_cols, int* offsets, int* ring_rc, double* ring_uv, int* hole_rc, hipStream_t stream);
+// B:894-898 for a batch: flip along the rows, sign of v, unit scaling (the reference's expression, bit-identical)
+hipError_t launch_finish_fields(const double* u, const double* v, int batch, int n_rows, int n_cols, double scale, double dt,
+                                double* fu, double* fv, hipStream_t stream);
 // ensemble statistics (postval.hip): out [5][cells] = mean u, mean v, <u'u'>, <v'v'>, <u'v'> of n stacked fields
 hipError_t launch_ensemble_moments(const double* U, const double* V, int n, long long cells, double* out, hipStream_t stream);
 

@@ -224,6 +224,26 @@ __global__ __launch_bounds__(256) void postval_compact_kernel(const double* __re
     }
 }
 
+// ---- B:894-898 for a batch: u = flip(u, rows) * scale / dt * 1000, v = -flip(v, rows) * scale / dt * 1000 -- the
+// reference's float64 expression evaluated left to right, three correctly rounded operations per value (no contraction:
+// numpy rounds every one of them), so the result is bit-identical to the host's.
+__global__ __launch_bounds__(256) void finish_fields_kernel(const double* __restrict__ U, const double* __restrict__ V,
+                                                            int batch, int n_rows, int n_cols, double scale, double dt,
+                                                            double* __restrict__ FU, double* __restrict__ FV) {
+#pragma clang fp contract(off)
+    const long long cells = (long long)n_rows * n_cols;
+    const long long total = cells * batch;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pair = i / cells;
+        const int rc = (int)(i - pair * cells);
+        const int r = rc / n_cols, c = rc - r * n_cols;
+        const long long src = pair * cells + (long long)(n_rows - 1 - r) * n_cols + c;
+        const double u = U[src], v = -V[src];
+        FU[i] = u * scale / dt * 1000.0;
+        FV[i] = v * scale / dt * 1000.0;
+    }
+}
+
 // ---- ensemble moments (workers.py:85-96): one thread per grid cell walks the stack of fields IN ORDER,
 // like numpy's reduction along the stack axis: mean = ((f0 + f1) + f2 ...) / n, then the two-pass
 // central moments sum_k (f_k - mean)^2 / n.  No contraction: numpy rounds the product and the sum apart.
@@ -258,6 +278,17 @@ __global__ __launch_bounds__(256) void ensemble_moments_kernel(const double* __r
 hipError_t launch_ensemble_moments(const double* U, const double* V, int n, long long cells, double* out, hipStream_t stream) {
     if (n <= 0 || cells <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ensemble_moments_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, U, V, n, cells, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_finish_fields(const double* u, const double* v, int batch, int n_rows, int n_cols, double scale, double dt,
+                                double* fu, double* fv, hipStream_t stream) {
+    const long long total = (long long)batch * n_rows * n_cols;
+    if (total <= 0) return hipErrorInvalidValue;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(finish_fields_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, u, v, batch, n_rows, n_cols, scale, dt,
+                       fu, fv);
     return hipGetLastError();
 }
 

@@ -227,6 +227,21 @@ def postval_compact(u, v, cls, counts):
     return offsets, ring_rc, ring_uv, hole_rc
 
 
+def finish_fields(u, v, scale, dt):
+    """(flip(u, rows) * scale / dt * 1000, -flip(v, rows) * scale / dt * 1000) for a batch of float64 fields on the GPU,
+    with the reference's expression (PIVbackend.py:894-898) evaluated left to right: bit-identical to numpy's."""
+    _need_cuda(u, v)
+    if u.dtype != torch.float64 or v.dtype != torch.float64 or u.shape != v.shape or u.dim() != 3 \
+            or not (u.is_contiguous() and v.is_contiguous()):
+        raise ValueError("finish_fields: two contiguous float64 tensors [batch, n_rows, n_cols] of one shape")
+    B, nr, nc = u.shape
+    fu, fv = torch.empty_like(u), torch.empty_like(v)
+    with torch.cuda.device(u.device):
+        check(lib.tpiv_finish_fields(u.data_ptr(), v.data_ptr(), B, nr, nc, float(scale), float(dt), fu.data_ptr(),
+                                     fv.data_ptr(), _stream()))
+    return fu, fv
+
+
 def ensemble_moments(U, V):
     """(mean u, mean v, <u'u'>, <v'v'>, <u'v'>) of stacked fields U, V float64 [n, ...] on the GPU, accumulated in
     stack order like numpy (tpiv_ensemble_moments)."""
