@@ -305,6 +305,14 @@ def test_batched_over_png_files_and_abandoned_generators(tmp_path):
         piv = T.OfflinePIV(str(tmp_path), "cuda:0", fmt, **kw)
         piv.call_batch = 1
         ref = [tuple(np.array(t) for t in r) for r in piv()]
+        piv.call_batch = 3                                  # the reference's API: fresh, writable x, y per pair (B:899-900)
+        g2 = piv()
+        t0 = next(g2)
+        assert t0[0].flags.writeable and t0[1].flags.writeable
+        t0[0][:] = 0.0
+        t1 = next(g2)
+        assert t1[0].any() and t1[0] is not t0[0]
+        g2.close()
         gen = piv.batched(3)
         first = next(gen)                                   # abandon the generator with batches still to come
         gen.close()

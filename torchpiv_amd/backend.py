@@ -630,8 +630,10 @@ class OfflinePIV:
 
     def __call__(self) -> Generator:
         if int(self.call_batch) > 1 and len(self._dataset) > 1:
+            # the reference hands out FRESH x, y per pair (B:899-900: x * scale makes a new array), which a caller may
+            # write into; batched() shares one read-only pair of coordinate arrays per batch, so copy here
             for _, x, y, u, v in self.batched(int(self.call_batch)):
-                yield x, y, u, v
+                yield x.copy(), y.copy(), u, v
             return
         end_time = time()
         for i in range(len(self._dataset)):
@@ -847,7 +849,7 @@ class ResidentPIV(OfflinePIV):
 
     def __call__(self) -> Generator:
         for _, x, y, u, v in self.batched(1):
-            yield x, y, u, v
+            yield x.copy(), y.copy(), u, v
 
 
 class OnlinePIV:
