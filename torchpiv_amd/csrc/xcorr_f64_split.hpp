@@ -82,6 +82,16 @@ __device__ __forceinline__ double lds_rd(unsigned addr) {
     }
     return v;
 }
+// explicit ds_write_b64 (the backend merges neighbouring writes into ds_write2_b64 pairs)
+template <int OFF>
+__device__ __forceinline__ void lds_wr(unsigned addr, double v) {
+    if constexpr (OFF < 65536) {
+        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+    } else {
+        const unsigned hi = addr + (unsigned)(OFF & ~0xffff);
+        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(hi), "v"(v), "n"(OFF & 0xffff) : "memory");
+    }
+}
 // wait until at most LEFT LDS operations are outstanding; the eight values become usable only behind it
 template <int LEFT>
 __device__ __forceinline__ void lds_wait(double (&v)[8]) {
@@ -96,6 +106,8 @@ template <int OFF>
 inline double lds_rd(unsigned) { return 0.0; }
 template <int LEFT>
 inline void lds_wait(double (&)[8]) {}
+template <int OFF>
+inline void lds_wr(unsigned, double) {}
 inline unsigned lds_addr(const double*) { return 0u; }
 #endif
 
@@ -208,10 +220,18 @@ struct Split {
     template <int COMP>
     static TPIV_HD void t1_write(const cd (&x)[M], int y, int h, double* plane) {
         double* row = plane + y * PL + h;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned base = lds_addr(row);
+        static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
+            constexpr int m = decltype(mc)::value;
+            lds_wr<16 * m>(base, COMP ? x[FFT_POS<m, M>].y : x[FFT_POS<m, M>].x);
+        });
+#else
         static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
             constexpr int m = decltype(mc)::value;
             row[2 * m] = COMP ? x[FFT_POS<m, M>].y : x[FFT_POS<m, M>].x;
         });
+#endif
     }
     // ---- T1 read: thread (k, g): u[i] = X[i][k] +- X[i + M][k]
     template <int COMP>
@@ -358,10 +378,18 @@ struct Split {
     template <int COMP>
     static TPIV_HD void t2_write(const cd (&t)[M], int k, int g, double* plane) {
         double* col = plane + (M * g) * PL + k;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned base = lds_addr(col);
+        static_for<0, M>([&](auto yc) TPIV_LAMBDA_INLINE {
+            constexpr int y1 = decltype(yc)::value;
+            lds_wr<y1 * PL * 8>(base, COMP ? t[FFT_POS<y1, M>].y : t[FFT_POS<y1, M>].x);
+        });
+#else
         static_for<0, M>([&](auto yc) TPIV_LAMBDA_INLINE {
             constexpr int y1 = decltype(yc)::value;
             col[y1 * PL] = COMP ? t[FFT_POS<y1, M>].y : t[FFT_POS<y1, M>].x;
         });
+#endif
     }
     // ---- T2 read: thread (y, q): Y[kx] = G_0[y % M][kx] +- G_1[y % M][kx], kx = 0..M
     template <int COMP>
@@ -467,7 +495,11 @@ struct Split {
             constexpr int fx0 = (4 * (i >> 1) + 2 * (i & 1) + W / 2) & (W - 1);   // + q: stays inside its pair
             const double v = peak_shifted(c[i], cmin, scale);
             c[i] = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+            lds_wr<fx0 * 8>(lds_addr(row), v);
+#else
             row[fx0] = v;
+#endif
         });
     }
     // second peak: the thread's maximum outside the flat-index exclusion zone of m (B:346-358): f in {clamp(m + i + W j),
