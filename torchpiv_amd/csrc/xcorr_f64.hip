@@ -435,10 +435,11 @@ __global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
         // ---- transposition 1 (one plane at a time): lane (w, kx) gets x[y] = X[y][kx]
         {
             const unsigned rd_base = f64s::lds_addr(pl + r);
+            const unsigned wr_base = f64s::lds_addr(pl + r * P);      // explicit ds_write_b64: merged write2 pairs are slower
             wave_sync();
             static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int k = decltype(kc)::value;
-                pl[r * P + k] = x[FFT_POS<k, WS>].x;
+                f64s::lds_wr<8 * k>(wr_base, x[FFT_POS<k, WS>].x);
             });
             wave_sync();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
             wave_sync();
             static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int k = decltype(kc)::value;
-                pl[r * P + k] = x[FFT_POS<k, WS>].y;
+                f64s::lds_wr<8 * k>(wr_base, x[FFT_POS<k, WS>].y);
             });
             wave_sync();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
         cd hs[M + 1];
         {
             const unsigned rd_base = f64s::lds_addr(pl + r);
+            const unsigned wr_base2 = f64s::lds_addr(pl + r * P);
             cd b[WS];
             static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int k = decltype(kc)::value;
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
             if (r <= M) {
                 static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int k = decltype(kc)::value;
-                    pl[r * P + k] = b[k].x;                            // row kx, column y
+                    f64s::lds_wr<8 * k>(wr_base2, b[k].x);                            // row kx, column y
                 });
             }
             wave_sync();
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
             if (r <= M) {
                 static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int k = decltype(kc)::value;
-                    pl[r * P + k] = b[k].y;
+                    f64s::lds_wr<8 * k>(wr_base2, b[k].y);
                 });
             }
             wave_sync();
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
                 constexpr int xs = decltype(xc)::value;
                 const double v = f64s::peak_shifted(c[xs], cmin, map_scale);
                 c[xs] = v;
-                pl[ys * P + xs] = v;
+                f64s::lds_wr<8 * xs>(f64s::lds_addr(pl + ys * P), v);
             });
             const double rmax = f64s::peak_shifted(rraw, cmin, map_scale);
             const double gmax = grp_reduce<WS>(rmax, dmax);
