@@ -59,6 +59,25 @@ __device__ __forceinline__ int sdwa_sub(uint32_t a, uint32_t b) {
         : "=v"(r) : "v"(a), "v"(b), "n"(SEL));
     return r;
 }
+// all four byte lanes of a dword pair of frame a and of frame b in ONE asm block (the backend pads every asm block with
+// a wait state of its own: eight single-instruction blocks cost eight s_nop)
+#define TPIV_SDWA4(OP)                                                                                                  \
+    asm(OP " %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"                       \
+        OP " %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"                       \
+        OP " %2, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"                       \
+        OP " %3, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3\n\t"                       \
+        OP " %4, %10, %11 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"                     \
+        OP " %5, %10, %11 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"                     \
+        OP " %6, %10, %11 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2\n\t"                     \
+        OP " %7, %10, %11 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3"                          \
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])        \
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1))
+template <bool SUB>
+__device__ __forceinline__ void sdwa_quad(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, int (&r)[8]) {
+    if constexpr (SUB) TPIV_SDWA4("v_sub_u32_sdwa");
+    else TPIV_SDWA4("v_add_u32_sdwa");
+}
+#undef TPIV_SDWA4
 #endif
 
 template <int K, int NDW>
@@ -183,18 +202,28 @@ struct Split {
         // sub-dword-addressed integer add / subtract each (SDWA byte selects), then one exact conversion -- two
         // instructions per real sample instead of four (byte -> float, byte -> float, fma, float -> double)
         if (h) {
-            static_for<0, M>([&](auto jc) TPIV_LAMBDA_INLINE {
-                constexpr int j = decltype(jc)::value;
-                x[j] = cd{(double)sdwa_sub<j & 3>(da[j >> 2], da[(j + M) >> 2]), (double)sdwa_sub<j & 3>(db[j >> 2], db[(j + M) >> 2])};
+            static_for<0, M / 4>([&](auto qc) TPIV_LAMBDA_INLINE {
+                constexpr int q = decltype(qc)::value;
+                int r[8];
+                sdwa_quad<true>(da[q], da[q + M / 4], db[q], db[q + M / 4], r);
+                static_for<0, 4>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    x[4 * q + k] = cd{(double)r[k], (double)r[4 + k]};
+                });
             });
             static_for<1, M>([&](auto jc) TPIV_LAMBDA_INLINE {
                 constexpr int j = decltype(jc)::value;
                 x[j] = twmul_d<j, W, 1>(x[j]);
             });
         } else {
-            static_for<0, M>([&](auto jc) TPIV_LAMBDA_INLINE {
-                constexpr int j = decltype(jc)::value;
-                x[j] = cd{(double)sdwa_add<j & 3>(da[j >> 2], da[(j + M) >> 2]), (double)sdwa_add<j & 3>(db[j >> 2], db[(j + M) >> 2])};
+            static_for<0, M / 4>([&](auto qc) TPIV_LAMBDA_INLINE {
+                constexpr int q = decltype(qc)::value;
+                int r[8];
+                sdwa_quad<false>(da[q], da[q + M / 4], db[q], db[q + M / 4], r);
+                static_for<0, 4>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    x[4 * q + k] = cd{(double)r[k], (double)r[4 + k]};
+                });
             });
         }
 #else
