@@ -318,6 +318,13 @@ def test_batched_over_png_files_and_abandoned_generators(tmp_path):
         gen.close()
         rd = piv._reader
         assert rd._h is None                                # reader threads stopped and joined
+        # a second abandoned run over the pairs in REVERSE order leaves uploads / unpack kernels of other files queued:
+        # the restart below must not see their bytes (the staging and device buffers are reused)
+        piv.pipeline_depth = 4
+        gen = piv.batched(2, indices=list(range(len(piv) - 1, -1, -1)))
+        next(gen)
+        gen.close()
+        piv.pipeline_depth = 2
         got = [tuple(np.array(t) for t in r[1:]) for r in piv.batched(3)]
         assert len(got) == len(ref) >= 5 and np.array_equal(first[3], ref[0][2], equal_nan=True)
         for g_, r_ in zip(got, ref):

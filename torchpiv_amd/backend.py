@@ -336,14 +336,18 @@ class OfflinePIV:
 
     def __init__(self, folder: str, device: str, file_fmt: str, wind_size: int, overlap: int,
                  multipass: int = 1, multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.,
-                 multipass_scale: float = 2., folder_mode: str = "pairs", precision: str = "f64") -> None:
+                 multipass_scale: float = 2., folder_mode: str = "pairs", precision: str = "f64",
+                 validation_ratio: float = 1.2, validation_window: int = 3) -> None:
         # precision (extension, keyword after the reference's arguments).  "f64" (default): the reference's own
         # arithmetic types -- pass 1 in float64 (B:513-514), later passes float32 with a float64 epilogue.
         # "reference": the same plus the reference's operation order in the CWS sampling (bit-identical staged
         # windows).  "fast": pass 1 in float32 too (~1e-6 px from the float64 pass 1, about 1.9x the rate).
+        # validation_ratio / validation_window (extensions): the constants the reference hides inside
+        # correlation_to_displacement (B:364-365: val_ratio=1.2, validation_window=3), same defaults.
         if precision not in PRECISIONS:
             raise KeyError(precision)
         self._precision = precision
+        self._val_ratio, self._val_win = float(validation_ratio), int(validation_window)
         self._wind_size = wind_size
         self._overlap = overlap
         self._dt = dt
@@ -380,6 +384,7 @@ class OfflinePIV:
             self._plan = engine.Plan(H, W, int(self._wind_size), int(self._overlap),
                                      n_pass=max(1, int(self._iter)), mode=self._mode,
                                      pass_scale=self._iter_scale, max_batch=max_batch,
+                                     val_ratio=self._val_ratio, val_win=self._val_win,
                                      device=self._device, precision=self._precision)
         return self._plan
 
@@ -622,6 +627,7 @@ class OfflinePIV:
             plan = plans[shape] = engine.Plan(shape[0], shape[1], int(self._wind_size), int(self._overlap),
                                               n_pass=max(1, int(self._iter)), mode=self._mode,
                                               pass_scale=self._iter_scale, max_batch=1, device=self._device,
+                                              val_ratio=self._val_ratio, val_win=self._val_win,
                                               precision=self._precision)
         u, v, inv = plan.run(a, b)
         w, o, _, _ = plan.geometry[-1]
@@ -678,6 +684,10 @@ class OfflinePIV:
         prev = getattr(self, "_reader", None)            # a reader that outlived its (abandoned) generator still fills the buffers
         if prev is not None:
             prev.close()
+            # ... and uploads / unpack kernels of that run may still be queued on ITS upload stream and on the compute
+            # stream: the staging and device buffers below are the same memory, and the new run's first upload carries no
+            # dependency on them (an old upload landing afterwards would be unpacked as the new batch 0)
+            torch.cuda.synchronize(self._device)
         if getattr(self, "_stage_key", None) != key:
             # three staging buffers: one being read into, one uploading, one of slack
             self._stage = [torch.empty(2 * batch_size, cap, dtype=torch.uint8).pin_memory() for _ in range(3)]
@@ -785,8 +795,11 @@ class OfflinePIV:
             release = None
             yield from emit(pipe.flush())
         finally:
-            # consumer finished, raised, or abandoned the generator (GeneratorExit lands here): stop the reader threads
+            # consumer finished, raised, or abandoned the generator (GeneratorExit lands here): stop the reader threads,
+            # then wait for every upload / unpack still queued (they read the staging buffers and write raw_dev, which the
+            # next batched() call on this object reuses with a fresh upload stream and no events to order itself behind)
             rd.close()
+            torch.cuda.synchronize(dev)
             if decoders is not None:
                 decoders.shutdown(wait=False)
 
@@ -798,13 +811,15 @@ class ResidentPIV(OfflinePIV):
 
     def __init__(self, frames_a: torch.Tensor, frames_b: torch.Tensor, wind_size: int, overlap: int,
                  multipass: int = 1, multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.,
-                 multipass_scale: float = 2., precision: str = "f64") -> None:
+                 multipass_scale: float = 2., precision: str = "f64", validation_ratio: float = 1.2,
+                 validation_window: int = 3) -> None:
         if frames_a.shape != frames_b.shape or frames_a.dim() != 3 or frames_a.dtype != torch.uint8 \
                 or frames_b.dtype != torch.uint8:
             raise ValueError("ResidentPIV: two uint8 tensors [n, H, W] of one shape")
         if precision not in PRECISIONS:
             raise KeyError(precision)
         self._precision = precision
+        self._val_ratio, self._val_win = float(validation_ratio), int(validation_window)
         self._wind_size, self._overlap, self._dt = wind_size, overlap, dt
         self._iter, self._iter_scale, self._scale = multipass, multipass_scale, scale
         self._device = _require_gpu(frames_a.device)
