@@ -299,6 +299,64 @@ def test_f64_split_scheme_on_the_host(tmp_path, W):
             assert (m // W - W // 2, m % W - W // 2) == shifts[i]
 
 
+@pytest.mark.parametrize("W,wv", [(64, 3), (64, 0), (64, 1), (64, 5), (128, 3), (128, 6)])
+def test_f64_split_peak_stage_on_handmade_maps(tmp_path, W, wv):
+    """The float64 kernels' peak stage (third generation: raw cells, zone rows, shift on read; xcorr_f64_split.hpp P) on
+    crafted maps -- a peak at every special flat index (every one-sided fix-up of B:385-392, the last-column neighbour in
+    the next row), rivals at the edges, the row wraps and the two clamps of the exclusion zone of B:346-358, ties, a
+    constant map -- against numpy + the oracle's second_peak (pinned to the reference by g6): arg-max, the six record
+    cells bit for bit.  val_win 5 / 6 take the path that keeps the zone rows in the plane."""
+    import struct
+    from oracle import piv_oracle as O
+    exe = str(tmp_path / "f64h")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host", "f64_split_harness.cpp")],
+                   check=True)
+    rng = np.random.default_rng(7 * W + wv)
+    n = W * W
+    specials = [0, 1, 2, W - 2, W - 1, W, W + 1, 2 * W - 1, 2 * W, n - 2 * W, n - W - 1, n - W, n - W + 1, n - 3, n - 2,
+                n - 1, n // 2 + W // 2, n // 2 + W // 2 - 1, 5 * W - 1, 6 * W, 3 * W + 3, n - 3 * W - 4, (W // 2) * W,
+                (W // 2) * W + W - 1, wv * W + wv, wv * W + wv + 1, n - 1 - wv * W - wv, n - 2 - wv * W - wv]
+    rivals = (None, wv + 1, -(wv + 1), wv, -wv, wv * W + wv, -(wv * W + wv), wv * W + wv + 1, (wv + 1) * W, -(wv + 1) * W,
+              W - wv, W - wv - 1, -(W - wv), "first", "last")
+    maps = []
+    for m in specials:
+        for rv in rivals:
+            a = rng.random((W, W)) * 5 + 1
+            a.flat[m] = 100.0
+            for q, val in ((m + 1, 60.0), (m - 1, 40.0), (m + W, 55.0), (m - W, 35.0)):
+                if 0 <= q < n:
+                    a.flat[q] = val
+            if rv is not None:
+                rival = 0 if rv == "first" else (n - 1 if rv == "last" else (m + rv) % n)
+                if rival != m:
+                    a.flat[rival] = max(a.flat[rival], 90.0 if (rival + m) % 2 else 80.0)
+            maps.append(a)
+    maps += [rng.random((W, W)) * 10 - 5 for _ in range(32)]          # raw cells may be negative
+    tie = np.ones((W, W))
+    tie[W // 4, W // 4] = tie[W // 2 + 1, W // 2 + 2] = 50.0            # exact tie: first flat index wins
+    maps += [tie, np.full((W, W), 5.0)]
+    maps = np.stack(maps)
+    inp = struct.pack("<ii", len(maps), wv) + maps.astype(np.float64).tobytes()
+    out = subprocess.run([exe, str(W), "maps"], input=inp, capture_output=True, check=True).stdout
+    rec = np.frombuffer(out, dtype=np.float64).reshape(len(maps), 8)
+    for i, a in enumerate(maps):
+        v = (a - a.min()) * 1.0 + 1e-7
+        flat = v.reshape(1, -1)
+        m = int(flat.argmax())
+        assert int(rec[i, 6]) == m, (i, int(rec[i, 6]), m)
+        left, right, top, bot = m + 1, m - 1, m + W, m - W                  # B:385-392
+        left = m if left >= n - 1 else left
+        right = m if right <= 0 else right
+        top = m if top >= n - 1 else top
+        bot = m if bot <= 0 else bot
+        for slot, q in ((0, m), (1, left), (2, right), (3, top), (4, bot)):
+            assert rec[i, slot] == flat[0, q], (i, slot)
+        z = flat.copy()
+        m2 = int(O.second_peak(z, np.array([m]), wv, W, W)[0])
+        assert rec[i, 5] == z[0, m2], (i, m, m2, rec[i, 5], z[0, m2])      # (0.0 when the whole map is excluded)
+        assert rec[i, 7] == 0.0
+
+
 def test_fast_hole_fill_is_the_reference_interpolator_bit_for_bit():
     """torchpiv_amd._qhull.qhull_fill (scipy.spatial.Delaunay + the barycentric arithmetic of scipy's _interpnd spelled out
     in numpy) against the reference's literal scipy.interpolate.LinearNDInterpolator call on random hole patterns --

@@ -37,34 +37,37 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // =====================================================================================================
 // 64x64 and 128x128 windows: every line split over two threads, 32- / 64-point in-register codelets, the radix-2
-// steps folded into planar LDS transposes (scheme and per-thread arithmetic: xcorr_f64_split.hpp).
+// steps folded into the LDS transposes (scheme and per-thread arithmetic: xcorr_f64_split.hpp).
 // =====================================================================================================
 template <int W>
-struct F64SplitShared {
-    double plane[W * (W + 1)];
-    double redd[16];
-    unsigned long long redu[4];
-    int redi[4];
+struct __attribute__((aligned(16))) F64SplitShared {
+    double plane[f64s::Split<W>::PLANE];                        // T1: one component of the tile, column-major; T2: complex elements
+    double zone[f64s::Split<W>::ZR * f64s::Split<W>::ZP];       // raw map rows around the maximum (peak analysis)
+    double rmx[2 * W];                                          // every thread's raw row maximum
+    double redd[8];                                             // per wavefront: minimum [0..3], maximum [4..7]
+    unsigned long long redu[4];                                 // 128x128: per-wavefront window sums
 };
 
-// W = 64: 128 threads (two wavefronts: wavefront = half of every line), 33 KB, four workgroups per CU, <= 256 VGPRs.
-// W = 128: 256 threads (wavefronts 0-1 = first halves of lines 0..63 / 64..127, wavefronts 2-3 = second halves), 132 KB:
+// W = 64: 128 threads (two wavefronts: wavefront = half of every line), 39.7 KB, four workgroups per CU, <= 256 VGPRs.
+// W = 128: 256 threads (wavefronts 0-1 = first halves of lines 0..63 / 64..127, wavefronts 2-3 = second halves), 143 KB:
 //          one workgroup per CU and one wavefront per SIMD with up to 512 registers (64-point codelets hold 256).
+// Seven workgroup barriers per window: T1 three (real plane written / read / imaginary plane written), T2 two (plane free /
+// written), peak analysis two.
 template <int W>
 __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel(PassParams p) {
     using S = f64s::Split<W>;
     using f64s::dmax2;
     using f64s::dmin2;
     using f64s::peak_shifted;
-    constexpr int M = S::M, PL = S::PL, NDW = S::NDW, NWV = 2 * W / 64;      // wavefronts per workgroup
+    constexpr int M = S::M, NDW = S::NDW, NWV = 2 * W / 64;                      // wavefronts per workgroup
     constexpr int LB = W == 64 ? 6 : 7;                                          // log2 W: line = t & (W - 1), half = t >> LB
+    constexpr int NJ = W / 64;                                                   // map rows per lane in the row scans of the peak stage
     __shared__ F64SplitShared<W> sm;
     double* const plane = sm.plane;
     const int tid = threadIdx.x;
     // The thread index at the point of use.  128x128: lane id (two VALU instructions) + the wavefront's base in an SGPR --
-    // a copy of threadIdx.x kept across the loop is spilled and re-loaded from scratch in front of every phase there
-    // (7.14 -> 7.05 ms per 64 pairs).  64x64: an opaque copy of the register (the recomputation costs more than the
-    // re-loads: 16.40 vs 16.48 ms per 256 pairs, same box).
+    // a copy of threadIdx.x kept across the loop is spilled and re-loaded from scratch in front of every phase there.
+    // 64x64: an opaque copy of the register (the recomputation costs more than the re-loads).
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
     auto thread_index = [&]() TPIV_LAMBDA_INLINE {
         if constexpr (W == 64) {
@@ -76,11 +79,17 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
         }
     };
 #define TPIV_F64_TID() thread_index()
+    const int half = wave_base >> LB;            // wave-uniform: 0 = first halves of the lines, 1 = second halves
+    const int g = 1 - half;                      // parity of the column bins this thread owns
 
     const int N = p.n_rows * p.n_cols;
     const long long items = (long long)p.batch * N;
     const int st = p.ws - p.ov;
     const int HW = p.H * p.W;
+    const int wv = p.val_win;
+    const int nz = 2 * wv + 3;                   // map rows around the maximum that the record / the exclusion zone can touch
+    const bool zone_in_plane = nz > S::ZR;       // (val_win > 4: the zone rows go through the plane, at the price of one more barrier)
+    double* const zone = zone_in_plane ? plane : sm.zone;
     // XCD-aware static order: workgroups b, b+8, ... share an XCD and walk one contiguous run of windows
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
     const long long chunk = (items + 7) / 8;
@@ -98,21 +107,6 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
         load_dwords<NDW>(p.A + off, da);
         load_dwords<NDW>(p.B + off, db);
     };
-    // exchange between the wavefronts of the workgroup, ONE barrier: every exchange has its own LDS slots (re-used a
-    // window later, many barriers on)
-    auto exchange = [&](auto v, auto op, auto* slots) TPIV_LAMBDA_INLINE {
-        v = grp_reduce<64>(v, op);
-        if constexpr (W == 64) {
-            if ((threadIdx.x & 63) == 0) slots[threadIdx.x >> 6] = v;
-        } else {
-            if (fresh_lane() == 0) slots[wave_base >> 6] = v;
-        }
-        lds_barrier();
-        auto r = slots[0];
-#pragma unroll
-        for (int w_ = 1; w_ < NWV; ++w_) r = op(r, slots[w_]);
-        return r;
-    };
     if (lo + slot < hi) fetch(lo + slot);
     TPIV_STAMP_DECL
     TPIV_STAMP_START;
@@ -122,182 +116,209 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
 #endif
         // (lane-derived values are re-made from the thread index at every phase -- TPIV_F64_TID() -- so that the
         //  loop-invariant LDS addresses are not hoisted out of the item loop into registers)
-        // ---- window sums: exact integers.  64x64: every wavefront holds all 64 rows (no exchange); 128x128: the rows of
-        //      wavefronts 0 and 1 together
-        unsigned ia = 0, ib = 0;
-#pragma unroll
-        for (int q = 0; q < NDW; ++q) {
-            ia = __builtin_amdgcn_sad_u8(da[q], 0u, ia);
-            ib = __builtin_amdgcn_sad_u8(db[q], 0u, ib);
-        }
+        // ---- window sums: exact integers, kept in scalar registers until the peak stage.  64x64: every wavefront holds
+        //      all 64 rows; 128x128: the rows of wavefronts 0 and 1 together (added behind the first barrier of the peak stage)
+        unsigned long long s2;
         {
+            unsigned ia = 0, ib = 0;
+#pragma unroll
+            for (int q = 0; q < NDW; ++q) {
+                ia = __builtin_amdgcn_sad_u8(da[q], 0u, ia);
+                ib = __builtin_amdgcn_sad_u8(db[q], 0u, ib);
+            }
             auto uadd = [](unsigned long long a, unsigned long long b) TPIV_LAMBDA_INLINE { return a + b; };
-            unsigned long long s2 = grp_reduce<64>((unsigned long long)ia | ((unsigned long long)ib << 32), uadd);
+            s2 = grp_reduce<64>((unsigned long long)ia | ((unsigned long long)ib << 32), uadd);
+            s2 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(s2 >> 32)) << 32) |
+                 (unsigned)__builtin_amdgcn_readfirstlane((unsigned)s2);
             if constexpr (W == 128) {
                 if (fresh_lane() == 0) sm.redu[wave_base >> 6] = s2;
-                lds_barrier();
-                s2 = sm.redu[0] + sm.redu[1];
             }
-            ia = (unsigned)s2;
-            ib = (unsigned)(s2 >> 32);
         }
+
+        // ---- R: rows forward
+        cd x[M];
+        S::rows_forward(da, db, half, x);
+        TPIV_STAMP(0);      // window sums, rows forward
+
+        // ---- T1 + C: transposition with the DIF step of the column transform, columns forward
+        cd u[M];
+        if (zone_in_plane) lds_barrier();            // (the previous window's zone reads)
+        {
+            const int y_ = TPIV_F64_TID() & (W - 1);
+            if (half) S::template t1_write<0, 1>(x, y_, plane);
+            else S::template t1_write<0, 0>(x, y_, plane);
+        }
+        lds_barrier();
+        S::template t1_read<0>(u, TPIV_F64_TID() & (W - 1), g, plane);
+        lds_barrier();
+        {
+            const int y_ = TPIV_F64_TID() & (W - 1);
+            if (half) S::template t1_write<1, 1>(x, y_, plane);
+            else S::template t1_write<1, 0>(x, y_, plane);
+        }
+        lds_barrier();
+        S::template t1_read<1>(u, TPIV_F64_TID() & (W - 1), g, plane);
+        TPIV_STAMP(1);      // transposition 1 (3 barriers)
+        // ---- C, X, Ci: the column stages, one straight-line instance per parity (wave-uniform branch: the parity-0
+        //      instance carries no twiddle products, and nothing is common to the two instances that the compiler could hoist
+        //      in front of the branch and keep in registers)
+        // ---- C, X, Ci and the T2 write: one straight-line instance per parity behind a wave-uniform branch that ends
+        //      only where nothing of it is live any more (its results sit in LDS): a merge in between would have to bring
+        //      the 128 registers of the spectrum together from both sides, and the register allocator answers that with a
+        //      second set of registers and scratch traffic.  (Every wavefront passes exactly one barrier inside.)
+        auto column_stages = [&](auto gc) TPIV_LAMBDA_INLINE {
+            constexpr int G = decltype(gc)::value;
+            S::cols_forward(u, G);
+            __builtin_amdgcn_sched_barrier(0);
+            TPIV_STAMP(2);      // columns forward
+            // cross-spectrum; the mirrored column sits in the neighbouring lane (lanes 0, 1 of the line order: their own)
+            {
+                const bool own = (TPIV_F64_TID() & (W - 1)) < 2;
+                auto sh = [&](double v, int, int) TPIV_LAMBDA_INLINE {
+                    const double r = f64s::dpp_xor1(v);
+                    return own ? v : r;
+                };
+                S::template cross_spectrum_g<G>(u, u, sh);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            TPIV_STAMP(3);      // cross-spectrum incl. the exchange
+            // columns inverse, transposition with the DIT step
+            cd t[M];
+            S::cols_inverse(u, G, t);
+            __builtin_amdgcn_sched_barrier(0);
+            TPIV_STAMP(4);      // columns inverse
+            lds_barrier();                               // every thread has read its T1 column
+            S::t2_write(t, TPIV_F64_TID() & (W - 1), G, plane);
+        };
+        if (g) column_stages(std::integral_constant<int, 1>{});
+        else column_stages(std::integral_constant<int, 0>{});
+        cd Y[M + 1];
+        lds_barrier();
+        S::t2_read(Y, TPIV_F64_TID() & (W - 1), plane);
+        TPIV_STAMP(5);      // transposition 2 (2 barriers)
+
+        // ---- Ri: rows inverse (c2r over the thread pair)
+        double c[M];
+        S::rows_inverse(Y, half, c);
+        TPIV_STAMP(6);      // rows inverse
+
+        // ---- P: peak analysis on the raw float64 cells (xcorr_f64_split.hpp, P).  Two exchanges, ONE barrier each.
+        auto dmin = [](double a, double b) TPIV_LAMBDA_INLINE { return dmin2(a, b); };
+        auto dmax = [](double a, double b) TPIV_LAMBDA_INLINE { return dmax2(a, b); };
+        auto imin = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
+        double cmin, graw;
+        {
+            double mn_, mx_;
+            S::peak_local_minmax(c, mn_, mx_);
+            // prefetch: the last iteration re-loads its own window (no branch around the loads)
+            fetch(item + per_xcd < hi ? item + per_xcd : item);
+            const int t_ = TPIV_F64_TID();
+            sm.rmx[t_] = mx_;
+            mn_ = grp_reduce<64>(mn_, dmin);
+            mx_ = grp_reduce<64>(mx_, dmax);
+            if ((t_ & 63) == 0) {
+                sm.redd[t_ >> 6] = mn_;
+                sm.redd[4 + (t_ >> 6)] = mx_;
+            }
+            lds_barrier();                            // (also: every thread has read its T2 row -> the plane is free)
+            cmin = sm.redd[0];
+            graw = sm.redd[4];
+#pragma unroll
+            for (int w_ = 1; w_ < NWV; ++w_) {
+                cmin = dmin2(cmin, sm.redd[w_]);
+                graw = dmax2(graw, sm.redd[4 + w_]);
+            }
+        }
+        if constexpr (W == 128) s2 = sm.redu[0] + sm.redu[1];
+        const unsigned ia = (unsigned)s2, ib = (unsigned)(s2 >> 32);
         const bool dead = ia == 0u || ib == 0u;          // zero-mean window: 0/0 = NaN map in the reference
         // a / mean(a), b / mean(b) (B:513-514) as ONE factor on the correlation map (xcorr_f64_split.hpp, rows_forward):
         // n^2 / sum(a) * n^2 / sum(b), times 1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra;
         // sum(a) sum(b) < 2^44 is exact, so this is one correctly rounded division per window
         const double map_scale = dead ? 0.0 : ((double)(W * W) * 0.25) / ((double)ia * (double)ib);
-
-        // ---- R: rows forward
-        cd x[M];
-        S::rows_forward(da, db, TPIV_F64_TID() >> LB, x);
-        TPIV_STAMP(0);      // window sums, rows forward
-
-        // ---- T1 + C: transposition with the DIF step of the column transform, columns forward
-        cd u[M];
-        lds_barrier();                               // plane free (the previous window's record reads)
-        {
-            const int t_ = TPIV_F64_TID();
-            S::template t1_write<0>(x, t_ & (W - 1), t_ >> LB, plane);
-        }
-        lds_barrier();
-        {
-            const int t_ = TPIV_F64_TID();
-            S::template t1_read<0>(u, t_ & (W - 1), 1 - (t_ >> LB), plane);
-        }
-        lds_barrier();
-        {
-            const int t_ = TPIV_F64_TID();
-            S::template t1_write<1>(x, t_ & (W - 1), t_ >> LB, plane);
-        }
-        lds_barrier();
-        {
-            const int t_ = TPIV_F64_TID();
-            S::template t1_read<1>(u, t_ & (W - 1), 1 - (t_ >> LB), plane);
-        }
-        TPIV_STAMP(1);      // transposition 1 (4 barriers)
-        const int g = 1 - (TPIV_F64_TID() >> LB);    // parity of the column bins this thread owns (wave-uniform)
-        S::cols_forward(u, g);
-        TPIV_STAMP(2);      // columns forward
-
-        // ---- X: cross-spectrum
-        if constexpr (W == 64) {
-            // the mirrored bin sits in lane (64 - k) % 64 of the same wavefront
-            const int partner = (64 - (TPIV_F64_TID() & 63)) & 63;
-            auto sh = [](double v, int, int, int pt) TPIV_LAMBDA_INLINE { return __shfl(v, pt, 64); };
-            if (g == 0) S::template cross_spectrum_g<0>(u, partner, sh);
-            else S::template cross_spectrum_g<1>(u, partner, sh);
-        } else {
-            // the mirrored column lives in another wavefront: through the plane, one component at a time
-            double mre[M];
-            lds_barrier();                           // every thread has read its T1 column
-            {
-                const int t_ = TPIV_F64_TID();
-                S::template cross_write<0>(u, t_ & (W - 1), 1 - (t_ >> LB), plane);
-            }
-            lds_barrier();
-            {
-                const int t_ = TPIV_F64_TID();
-                S::cross_read(mre, t_ & (W - 1), 1 - (t_ >> LB), plane);
-            }
-            lds_barrier();
-            {
-                const int t_ = TPIV_F64_TID();
-                S::template cross_write<1>(u, t_ & (W - 1), 1 - (t_ >> LB), plane);
-            }
-            lds_barrier();
-            double mim[M];
-            {
-                const int t_ = TPIV_F64_TID();
-                S::cross_read(mim, t_ & (W - 1), 1 - (t_ >> LB), plane);
-            }
-            S::cross_finish(u, mre, mim);
-        }
-
-        TPIV_STAMP(3);      // cross-spectrum incl. the exchange
-        // ---- Ci + T2: columns inverse, transposition with the DIT step
-        cd t[M];
-        S::cols_inverse(u, g, t);
-        TPIV_STAMP(4);      // columns inverse
-        cd Y[M + 1];
-        lds_barrier();                               // every thread has read what it needs from the plane
-        {
-            const int t_ = TPIV_F64_TID();
-            S::template t2_write<0>(t, t_ & (W - 1), 1 - (t_ >> LB), plane);
-        }
-        lds_barrier();
-        S::template t2_read<0>(Y, TPIV_F64_TID() & (W - 1), plane);
-        lds_barrier();
-        {
-            const int t_ = TPIV_F64_TID();
-            S::template t2_write<1>(t, t_ & (W - 1), 1 - (t_ >> LB), plane);
-        }
-        lds_barrier();
-        S::template t2_read<1>(Y, TPIV_F64_TID() & (W - 1), plane);
-
-        TPIV_STAMP(5);      // transposition 2 (4 barriers)
-        // ---- Ri: rows inverse (c2r over the thread pair)
-        double c[M];
-        S::rows_inverse(Y, TPIV_F64_TID() >> LB, c);
-        TPIV_STAMP(6);      // rows inverse
-
-        // ---- P: peak analysis on the float64 map.  Three exchanges between the wavefronts, ONE barrier each:
-        //      (min, raw max) -> map -> first row of the maximum -> second peak.
-        auto dmin = [](double a, double b) TPIV_LAMBDA_INLINE { return dmin2(a, b); };
-        auto dmax = [](double a, double b) TPIV_LAMBDA_INLINE { return dmax2(a, b); };
-        auto imin = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
-        double cmin, rraw;
-        S::peak_local_minmax(c, cmin, rraw);
-        // prefetch: the last iteration re-loads its own window (no branch around the loads)
-        fetch(item + per_xcd < hi ? item + per_xcd : item);
-        {
-            const double mn = grp_reduce<64>(cmin, dmin), mx = grp_reduce<64>(rraw, dmax);
-            const int t_ = TPIV_F64_TID();
-            if ((t_ & 63) == 0) {
-                sm.redd[t_ >> 6] = mn;
-                sm.redd[4 + (t_ >> 6)] = mx;
-            }
-            lds_barrier();                            // (also: every thread has read its T2 row -> the map may be written)
-        }
-        double graw = sm.redd[4];
-        cmin = sm.redd[0];
-#pragma unroll
-        for (int w_ = 1; w_ < NWV; ++w_) {
-            cmin = dmin2(cmin, sm.redd[w_]);
-            graw = dmax2(graw, sm.redd[4 + w_]);
-        }
         // the maximum of the shifted map is the shifted raw maximum (monotonic, same roundings)
         const double gmax = peak_shifted(graw, cmin, map_scale);
-        {
-            const int t_ = TPIV_F64_TID();
-            S::peak_shift_and_write(c, cmin, map_scale, t_ & (W - 1), t_ >> LB, plane);
-        }
         // arg-max = FIRST flat index holding the maximum (B:383): the smallest shifted row whose maximum is the global
-        // one, then the first column of that row -- lane = column, LDS reads and ballots (every wavefront does it: same
-        // row, same result, no exchange)
-        int ywin;
-        {
-            const int t_ = TPIV_F64_TID();
-            const int fy = ((t_ & (W - 1)) + W / 2) & (W - 1);
-            ywin = exchange(peak_shifted(rraw, cmin, map_scale) == gmax ? fy : W - 1, imin, sm.redi);      // (also: map complete)
-        }
-        int xwin = W - 1;
+        // one, then the first column of that row.  Every wavefront looks at all rows (lane l: rows l, l + 64, ...; both
+        // halves of a row) -- same result in every wavefront, no exchange.
+        double rm[NJ];
+        int ywin = W - 1;
         {
             const int l_ = TPIV_F64_TID() & 63;
 #pragma unroll
-            for (int part = W / 64 - 1; part >= 0; --part) {
-                const unsigned long long hit = __ballot(plane[ywin * PL + 64 * part + l_] == gmax);
+            for (int j = 0; j < NJ; ++j) {
+                rm[j] = dmax2(sm.rmx[64 * j + l_], sm.rmx[W + 64 * j + l_]);
+                const int fy = S::frow(64 * j + l_);
+                ywin = ((int)(peak_shifted(rm[j], cmin, map_scale) == gmax) & (int)(fy < ywin)) ? fy : ywin;
+            }
+            ywin = grp_reduce<64>(ywin, imin);
+            ywin = __builtin_amdgcn_readfirstlane(ywin);
+        }
+        const int zlo = ywin - wv - 1;
+        {
+            const int t_ = TPIV_F64_TID();
+            S::peak_zone_write(c, t_ & (W - 1), t_ >> LB, zlo, nz, zone);
+        }
+        lds_barrier();                                // zone rows complete
+        int xwin = W - 1;
+        {
+            const int l_ = TPIV_F64_TID() & 63;
+            const double* zrow = zone + (wv + 1) * S::ZP;
+#pragma unroll
+            for (int part = NJ - 1; part >= 0; --part) {
+                const unsigned long long hit = __ballot(peak_shifted(zrow[64 * part + l_], cmin, map_scale) == gmax);
                 xwin = hit ? 64 * part + (int)__builtin_ctzll(hit) : xwin;
             }
         }
         const int m = ywin * W + xwin;
-        double sv;
+        // second peak (B:346-358): the largest cell outside the exclusion zone = max(row maxima of the rows outside the
+        // zone rows, cells of the zone rows that are not excluded); every wavefront scans all of it (9 cells per lane)
+        double sv = f64s::PEAK_NONE;
         {
-            const int t_ = TPIV_F64_TID();
-            sv = exchange(S::peak_second_local(c, t_ & (W - 1), t_ >> LB, m, p.val_win), dmax, sm.redd + 8);
+            const int l_ = TPIV_F64_TID() & 63;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int zr = S::frow(64 * j + l_) - zlo;
+                sv = dmax2(sv, (unsigned)zr >= (unsigned)nz ? rm[j] : f64s::PEAK_NONE);
+            }
+            // straight-line code: the cells of the ZR buffer rows are loaded unconditionally (compile-time offsets; rows
+            // beyond nz hold stale cells and are masked out).  The test "cell (fy, fx) = m + i + W j with |i|, |j| <= wv, or one
+            // of the two clamps" (S::peak_excluded, which the CPU suite checks against the oracle) is taken apart: the column
+            // part depends on the lane only -- computed once per 64-column piece of a row --, the row part on the wave-uniform
+            // row and the lane's wrap adjustment.
+            const int mx = xwin;
+            const int nk = nz * NJ;                               // 64-cell pieces of the zone rows
+            constexpr int KU = S::ZR * NJ;
+            double raw[KU];
+            static_for<0, KU>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                raw[k] = zone[(k / NJ) * S::ZP + 64 * (k % NJ) + l_];
+            });
+            int q[NJ];
+            bool colok[NJ];
+#pragma unroll
+            for (int c_ = 0; c_ < NJ; ++c_) colok[c_] = S::peak_col_ok(64 * c_ + l_, mx, wv, q[c_]);
+            const bool clamp_lo = m - wv - wv * W <= 0, clamp_hi = m + wv + wv * W >= W * W - 1;      // wave-uniform
+            static_for<0, KU>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                constexpr int zr = k / NJ, c_ = k % NJ;
+                const int fy = zlo + zr;                                                          // wave-uniform
+                const bool row_ok = (k < nk) & ((unsigned)fy < (unsigned)W);                      // wave-uniform
+                const bool ex = S::peak_excluded_zr(colok[c_], q[c_], zr, fy, 64 * c_ + l_, wv, clamp_lo, clamp_hi);
+                sv = dmax2(sv, (row_ok & !ex) ? raw[k] : f64s::PEAK_NONE);
+            });
+            for (int k = KU; k < nk; ++k) {                        // (val_win > 4 only: the zone rows sit in the plane)
+                const int fy = zlo + k / NJ, fx = 64 * (k % NJ) + l_;
+                const int use = (int)((unsigned)fy < (unsigned)W) & (S::peak_excluded(fy * W + fx, m, wv) ^ 1);
+                sv = dmax2(sv, use ? zone[(k / NJ) * S::ZP + fx] : f64s::PEAK_NONE);
+            }
+            sv = grp_reduce<64>(sv, dmax);
         }
         {
             const int t_ = W == 64 ? tid : TPIV_F64_TID();
-            if (t_ < 8) reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + t_] = S::peak_record_slot(t_, m, sv, dead, plane);
+            if (t_ < 8)
+                reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + t_] =
+                    S::peak_record_slot(t_, m, sv, dead, zone, zlo, cmin, map_scale);
         }
         TPIV_STAMP(7);      // peak analysis incl. the issue of the next window's loads
 #undef TPIV_F64_TID
@@ -309,7 +330,7 @@ template <int W>
 static hipError_t launch_f64_split(const PassParams& p, int n_cu, hipStream_t stream) {
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
     if (items <= 0) return hipErrorInvalidValue;
-    // LDS: 33.4 KB / 132.3 KB per workgroup  (TPIV_F64_PER_CU: A/B runs of the residency)
+    // LDS: 39.7 KB / 143 KB per workgroup  (TPIV_F64_PER_CU: A/B runs of the residency)
     static const int per_cu_env = [] { const char* e_ = getenv("TPIV_F64_PER_CU"); return e_ ? atoi(e_) : 0; }();
     const int per_cu = W == 64 ? (per_cu_env > 0 ? per_cu_env : 4) : 1;
     long long blocks = items < (long long)n_cu * per_cu ? items : (long long)n_cu * per_cu;

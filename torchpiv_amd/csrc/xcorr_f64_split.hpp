@@ -1,39 +1,51 @@
 // Per-thread arithmetic of the float64 first pass for 64x64 and 128x128 windows (xcorr_f64.hip), written as host/device
-// functions so that the CPU suite can run the WHOLE scheme -- index maps, splits, partner bins, combines --
+// functions so that the CPU suite can run the WHOLE scheme -- index maps, splits, partner bins, combines, peak logic --
 // thread by thread against numpy (tests/host/f64_split_harness.cpp, tests/test_host_logic.py).
 //
-// A 64-point complex float64 line does not fit one lane (256 VGPRs), so every line is split over TWO threads
-// and every 64-point transform is a 32-point in-register codelet (fft_inreg_f64.hpp) plus one radix-2 step
-// that is folded into the LDS transposition in front of (decimation in frequency) or behind (decimation in
-// time) the codelet -- adds and subtractions of two plane cells while reading, plane by plane:
+// A W-point complex float64 line does not fit one lane, so every line is split over TWO threads and every W-point
+// transform is a W/2-point in-register codelet (fft_inreg_f64.hpp) plus one radix-2 step that is folded into the LDS
+// transposition in front of (decimation in frequency) or behind (decimation in time) the codelet.  Third generation
+// (round 4); what changed against the second one is marked (r4):
 //
-//   workgroup = 128 threads = one window; thread t: lane = t & 63, wave wv = t >> 6
-//   R   rows forward     thread (y = lane, h = wv) loads the whole image row y of both frames, forms the DIF halves
-//                        u[j] = x[j] + x[j+32]  (h = 0)   /   (x[j] - x[j+32]) w64^j  (h = 1),  j = 0..31
+//   workgroup = 2 W threads = one window; thread t: line = t % W, half = t / W  (W = 64: half = wavefront)
+//   R   rows forward     thread (y = line, h = half) loads the whole image row y of both frames, forms the DIF halves
+//                        u[j] = x[j] + x[j+W/2]  (h = 0)   /   (x[j] - x[j+W/2]) w^j  (h = 1)
 //                        (integer sums / differences of the bytes, exact; a / mean, b / mean of B:513-514 are applied
 //                        later as ONE factor on the map, see rows_forward) and transforms: X[y][2m + h] at
-//                        x[fft_pos(m, 32)]
-//   T1  transposition    plane[y][kx] <- X, one float64 component at a time (64 x 65 doubles = 33 KB: four
-//                        workgroups per CU); thread (k = lane, g = 1 - wv) reads column k as the DIF halves over
-//                        the rows: u[i] = X[i][k] +- X[i+32][k], the odd half times w64^i
-//   C   columns forward  32-point codelet: Z[2m + g][k] at u[fft_pos(m, 32)]
-//   X   cross-spectrum   P = conj(A) B of the packed transform Z = FFT2(a + i b); the mirrored bin Z(-ky, -k) has the
-//                        parity of ky, i.e. it lives in the same wavefront, lane (64 - k) % 64: ds_bpermute, no LDS memory
-//   Ci  columns inverse  the thread's own-parity bins through a 32-point inverse codelet: G_g[y1]; decimation in time:
-//                        Y[y1 + 32 c][k] = G_0[y1] +- w64^-y1 G_1[y1]; the g = 1 threads multiply by w64^-y1
-//   T2  transposition    plane[32 g + y1][k] <- G; thread (y = lane, q = wv) reads spectrum columns 0..32 of its row
-//                        (the row is real: Hermitian spectrum) as G_0 +- G_1
-//   Ri  rows inverse     the real 64-point row split over the thread pair by output parity: the even / odd samples are
-//                        real 32-point rows themselves (c2r through a 16-point codelet): thread q holds corr[y][2n + q]
-//   P   peak analysis    on the float64 map (B:346-358, B:381-392, B:518), 8-double record for finalize_kernel<true>
+//                        x[fft_pos(m)]
+//   T1  transposition    one float64 component at a time through the plane, which is stored COLUMN-major in the lane
+//                        order of the column stages (r4): plane[pos(kx)][y], pitch W + 2.  The writer's lanes are
+//                        consecutive rows y (contiguous, conflict-free); the reader (position L = line, g = 1 - half)
+//                        gets two consecutive rows of its column with ONE ds_read_b128 (lane stride W + 2 doubles:
+//                        conflict-free for the 16-lane groups of a 128-bit read) and forms the DIF halves over the
+//                        rows: u[i] = X[i][k] +- X[i+W/2][k], the odd half times w^i
+//   C   columns forward  W/2-point codelet: Z[2m + g][k] at u[fft_pos(m)]
+//   X   cross-spectrum   P = conj(A) B of the packed transform Z = FFT2(a + i b) needs the mirrored bin Z(-ky, -k).
+//                        (r4) The columns sit in the lanes in the order 0, W/2, 1, W-1, 2, W-2, ...: column k and its
+//                        mirror W - k are NEIGHBOURING lanes, so the mirrored bin comes through a quad-permute DPP move
+//                        (full-rate VALU, no LDS, no wait; it was 128 ds_bpermute per thread for W = 64 and two more
+//                        passes through the plane with four barriers for W = 128).  Lanes 0 and 1 (columns 0 and W/2
+//                        are their own mirrors) keep their own value.
+//   Ci  columns inverse  the thread's own-parity bins through a W/2-point inverse codelet: G_g[y1]; decimation in time:
+//                        Y[y1 + W/2 c][k] = G_0[y1] +- w^-y1 G_1[y1]; the g = 1 threads multiply by w^-y1
+//   T2  transposition    (r4) only the spectrum columns 0 .. W/2 are needed (the map rows are real), so both components
+//                        fit the plane at once: 16-byte complex elements plane2[W/2 g + y1][kx], pitch W/2 + 1
+//                        elements, ONE write phase and ONE read phase (two barriers instead of four);
+//                        thread (y = line, q = half) reads its row as G_0 +- G_1 with ds_read_b128
+//   Ri  rows inverse     the real W-point row split over the thread pair by output parity: the even / odd samples are
+//                        real W/2-point rows themselves (c2r through a W/4-point codelet): thread q holds corr[y][2n + q]
+//   P   peak analysis    on the float64 map (B:346-358, B:381-392, B:518), 8-double record for finalize_kernel<true>.
+//                        (r4) The map is never shifted or stored as a whole: v = (c - min) scale + 1e-7 is monotonic in
+//                        c, so minimum, maximum, arg-max candidates and the second peak are found on the RAW cells and
+//                        only the six cells of the record are shifted.  Exchange 1: per-wavefront (min, max) and every
+//                        thread's row maximum -> first row that holds the maximum.  Then the threads of the 2 wv + 3
+//                        rows around it (everything the flat-index neighbours and the exclusion zone of B:346-358 can
+//                        touch) put their cells into a small zone buffer; exchange 2; first column of the maximum by
+//                        ballot, second peak = max(row maxima outside the zone rows, zone cells outside the exclusion
+//                        zone), record.  Two barriers, none at the top of the next window.
 //
-// The odd halves carry 30 twiddle products per stage; the parities are assigned so that wave 0 takes them in the
-// column stages and wave 1 in the row stages.
-//
-// 128x128 windows run the same scheme with 64-point codelets (Split<128>: 256 threads, line = t % 128, half = t / 128;
-// one 132 KB plane, i.e. one workgroup per CU and up to 512 registers per thread).  There the two halves of a line and
-// the mirrored column -k live in different wavefronts, so the cross-spectrum fetches Z(-ky, -k) through the plane
-// (cross_write / cross_read) instead of ds_bpermute.  The text above gives the numbers of the 64x64 case.
+// The odd halves carry W/2 - 2 twiddle products per stage; the parities are assigned so that half 0 takes them in the
+// column stages and half 1 in the row stages.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -43,24 +55,12 @@
 namespace tpiv {
 namespace f64s {
 
+typedef double d2 __attribute__((ext_vector_type(2)));
+
 #if defined(__HIP_DEVICE_COMPILE__)
-// byte SEL of a (+ / -) byte SEL of b as a 32-bit integer, one instruction (sub-dword addressing of both sources)
-template <int SEL>
-__device__ __forceinline__ int sdwa_add(uint32_t a, uint32_t b) {
-    int r;
-    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_%3 src1_sel:BYTE_%3"
-        : "=v"(r) : "v"(a), "v"(b), "n"(SEL));
-    return r;
-}
-template <int SEL>
-__device__ __forceinline__ int sdwa_sub(uint32_t a, uint32_t b) {
-    int r;
-    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_%3 src1_sel:BYTE_%3"
-        : "=v"(r) : "v"(a), "v"(b), "n"(SEL));
-    return r;
-}
 // all four byte lanes of a dword pair of frame a and of frame b in ONE asm block (the backend pads every asm block with
-// a wait state of its own: eight single-instruction blocks cost eight s_nop)
+// a wait state of its own: eight single-instruction blocks cost eight s_nop).  Sums / differences of two bytes that sit
+// in the same byte lane of two dwords: ONE sub-dword-addressed integer instruction each.
 #define TPIV_SDWA4(OP)                                                                                                  \
     asm(OP " %0, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0\n\t"                       \
         OP " %1, %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n\t"                       \
@@ -85,23 +85,37 @@ TPIV_HD float byte_of(const uint32_t (&d)[NDW]) {
     return (float)((d[K >> 2] >> (8 * (K & 3))) & 0xffu);
 }
 
-// ---- LDS reads of the transposes.  Device: explicit ds_read_b64 (the backend would merge neighbouring reads into
-// ds_read2_b64 pairs, which run at HALF the LDS rate: 8 cycles for 2 x 8 bytes per lane against 2 + 2), issued in
-// batches of eight with the next batch in flight while the current one is consumed (lgkmcnt counts at most 15).
-// Host: plain loads.
+// ---- LDS accesses of the transposes.  Device: explicit ds_read_b64 / ds_read_b128 / ds_write_b64 / ds_write_b128 (the
+// backend would merge neighbouring 8-byte accesses into ds_read2_b64 / ds_write2_b64 pairs, which run at HALF the LDS
+// rate), reads issued in batches with the next batch in flight while the current one is consumed (lgkmcnt counts at
+// most 15).  The value of a read is usable only behind lds_wait; the asm statements are volatile and clobber memory, so
+// the compiler keeps them in program order among themselves and against ordinary LDS accesses.  (Constraint, kept by
+// the zero-scratch build and checked by tests/test_host_logic.py + the full-size parity tests on every toolchain bump:
+// the compiler must not copy or spill a destination register between the read and its wait -- it cannot know that the
+// value has not landed yet.)  Host: plain loads.
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int OFF>
 __device__ __forceinline__ double lds_rd(unsigned addr) {
     double v;
     if constexpr (OFF < 65536) {
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    } else {                  // the offset field has 16 bits (the 128x128 plane is 132 KB): second base, shared by the reads
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    } else {                  // the offset field has 16 bits (the 128x128 plane is 130 KB): second base, shared by the reads
         const unsigned hi = addr + (unsigned)(OFF & ~0xffff);
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(hi), "n"(OFF & 0xffff));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(hi), "n"(OFF & 0xffff) : "memory");
     }
     return v;
 }
-// explicit ds_write_b64 (the backend merges neighbouring writes into ds_write2_b64 pairs)
+template <int OFF>
+__device__ __forceinline__ d2 lds_rd2(unsigned addr) {          // 16-byte aligned address
+    d2 v;
+    if constexpr (OFF < 65536) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    } else {
+        const unsigned hi = addr + (unsigned)(OFF & ~0xffff);
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(hi), "n"(OFF & 0xffff) : "memory");
+    }
+    return v;
+}
 template <int OFF>
 __device__ __forceinline__ void lds_wr(unsigned addr, double v) {
     if constexpr (OFF < 65536) {
@@ -111,23 +125,51 @@ __device__ __forceinline__ void lds_wr(unsigned addr, double v) {
         asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(hi), "v"(v), "n"(OFF & 0xffff) : "memory");
     }
 }
-// wait until at most LEFT LDS operations are outstanding; the eight values become usable only behind it
+template <int OFF>
+__device__ __forceinline__ void lds_wr2(unsigned addr, d2 v) {   // 16-byte aligned address
+    if constexpr (OFF < 65536) {
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+    } else {
+        const unsigned hi = addr + (unsigned)(OFF & ~0xffff);
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(hi), "v"(v), "n"(OFF & 0xffff) : "memory");
+    }
+}
+// wait until at most LEFT LDS operations are outstanding; the values become usable only behind it
 template <int LEFT>
 __device__ __forceinline__ void lds_wait(double (&v)[8]) {
     asm volatile("s_waitcnt lgkmcnt(%8)"
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
-                 : "n"(LEFT));
+                 : "n"(LEFT)
+                 : "memory");
+}
+template <int LEFT>
+__device__ __forceinline__ void lds_wait(d2 (&v)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(LEFT) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned)(uintptr_t)p; }     // low dword of a flat LDS address
+// the value of the NEIGHBOURING lane (lane ^ 1): one quad-permute DPP move per dword
+__device__ __forceinline__ double dpp_xor1(double v) {
+    // (bound_ctrl with old = 0: no lane of a quad permute reads out of bounds, and the compiler needs no move for `old`)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true);      // quad_perm:[1,0,3,2]
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 #elif defined(__HIPCC__)
 // host pass of a HIP translation unit: the kernels' bodies are parsed, never run
 template <int OFF>
 inline double lds_rd(unsigned) { return 0.0; }
+template <int OFF>
+inline d2 lds_rd2(unsigned) { return d2{0.0, 0.0}; }
 template <int LEFT>
 inline void lds_wait(double (&)[8]) {}
+template <int LEFT>
+inline void lds_wait(d2 (&)[4]) {}
 template <int OFF>
 inline void lds_wr(unsigned, double) {}
+template <int OFF>
+inline void lds_wr2(unsigned, d2) {}
 inline unsigned lds_addr(const double*) { return 0u; }
+inline double dpp_xor1(double v) { return v; }
 #endif
 
 // (device: an empty asm on a value keeps computations that depend on it where they are written -- left alone, the
@@ -182,20 +224,34 @@ TPIV_HD double peak_shifted(double c, double cmin, double scale) {
     return (c - cmin) * scale + 1e-7;
 #endif
 }
+// "no cell": below every map value (raw correlation sums are bounded by 255^2 W^4 < 1e14)
+constexpr double PEAK_NONE = -1.0e300;
+
+constexpr int ilog2_c(int n) { return n <= 1 ? 0 : 1 + ilog2_c(n / 2); }
 
 // W = window edge (64 or 128); every function is the work of ONE thread
 template <int W>
 struct Split {
     static constexpr int WS = W;
+    static constexpr int LOGW = ilog2_c(W);
     static constexpr int M = W / 2;          // codelet length
-    static constexpr int PL = W + 1;         // plane pitch in doubles: conflict-free ds_read_b64 / ds_write_b64 along rows and columns
     static constexpr int NDW = W / 4;        // dwords per window row
     static constexpr int NT = 2 * W;         // threads per window: line = t % W, half = t / W
+    static constexpr int P1 = W + 2;         // T1: doubles per stored spectrum column (pitch of plane[pos][y])
+    static constexpr int P2 = M + 1;         // T2: complex elements per stored row (kx = 0 .. W/2)
+    static constexpr int PLANE = W * P1;     // doubles; = 2 * W * P2
+    static constexpr int ZP = W + 1;         // zone buffer: doubles per map row
+    static constexpr int ZR = 11;            // zone rows the buffer holds (2 wv + 3 <= ZR, i.e. wv <= 4; else the plane serves)
+    static_assert(PLANE == 2 * W * P2, "T1 and T2 share the plane");
+
+    // lane order of the spectrum columns in the column stages: 0, W/2, 1, W-1, 2, W-2, ... (mirror pairs side by side)
+    static constexpr TPIV_HD int col_of(int L) { return L == 0 ? 0 : (L == 1 ? W / 2 : ((L & 1) ? W - (L >> 1) : (L >> 1))); }
+    static constexpr TPIV_HD int pos_of(int c) { return c == 0 ? 0 : (c == W / 2 ? 1 : (c < W / 2 ? 2 * c : 2 * (W - c) + 1)); }
 
     // ---- R: thread (y, h).  da / db: row y of frame a / b.  The samples go in as they are: the normalisation a / mean(a),
     // b / mean(b) of B:513-514 is linear, so it is ONE factor 1 / (mean(a) mean(b)) on the whole correlation map, applied
-    // where the map is shifted by its minimum (peak_shifted) -- W multiplies per thread and one of two divisions per window
-    // less, at rounding-level differences (1e-16 relative) from scaling every sample first.
+    // where map cells are shifted by the minimum (peak_shifted) -- W multiplies per thread and one of two divisions per
+    // window less, at rounding-level differences (1e-16 relative) from scaling every sample first.
     static TPIV_HD void rows_forward(const uint32_t (&da)[NDW], const uint32_t (&db)[NDW], int h, cd (&x)[M]) {
 #if defined(__HIP_DEVICE_COMPILE__)
         // sums / differences of two bytes that sit in the same byte lane of two dwords (M is a multiple of 4): ONE
@@ -245,55 +301,56 @@ struct Split {
         fft_inreg_d<M, 1>(x);          // X[y][2m + h] at x[FFT_POS<m, M>]
     }
 
-    // ---- T1 write: component COMP (0 = real, 1 = imaginary) of X[y][2m + h]
-    template <int COMP>
-    static TPIV_HD void t1_write(const cd (&x)[M], int y, int h, double* plane) {
-        double* row = plane + y * PL + h;
+    // ---- T1 write: component COMP (0 = real, 1 = imaginary) of X[y][kx = 2m + h] -> plane[pos(kx)][y].  h is a
+    // compile-time argument (the positions are offsets in the instructions); the kernel branches on it wave-uniformly.
+    template <int COMP, int H_>
+    static TPIV_HD void t1_write(const cd (&x)[M], int y, double* plane) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned base = lds_addr(row);
+        const unsigned base = lds_addr(plane + y);
         static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
             constexpr int m = decltype(mc)::value;
-            lds_wr<16 * m>(base, COMP ? x[FFT_POS<m, M>].y : x[FFT_POS<m, M>].x);
+            lds_wr<pos_of(2 * m + H_) * P1 * 8>(base, COMP ? x[FFT_POS<m, M>].y : x[FFT_POS<m, M>].x);
         });
 #else
         static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
             constexpr int m = decltype(mc)::value;
-            row[2 * m] = COMP ? x[FFT_POS<m, M>].y : x[FFT_POS<m, M>].x;
+            plane[pos_of(2 * m + H_) * P1 + y] = COMP ? x[FFT_POS<m, M>].y : x[FFT_POS<m, M>].x;
         });
 #endif
     }
-    // ---- T1 read: thread (k, g): u[i] = X[i][k] +- X[i + M][k]
+    // ---- T1 read: thread (position L, parity g): u[i] = X[i][k] +- X[i + M][k], k = col_of(L)
     template <int COMP>
-    static TPIV_HD void t1_read(cd (&u)[M], int k, int g, const double* plane) {
+    static TPIV_HD void t1_read(cd (&u)[M], int L, int g, const double* plane) {
         const double sg = g ? -1.0 : 1.0;
 #if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned base = lds_addr(plane + k);
-        constexpr int NB = M / 4;                                   // batches of 4 rows i = 8 reads
-        double v[2][8];
+        const unsigned base = lds_addr(plane + L * P1);
+        constexpr int NB = M / 4;                                   // batches of 4 rows i = 4 reads of 16 bytes
+        d2 v[2][4];
         auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
             constexpr int b_ = decltype(bc)::value;
-            static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
-                constexpr int i = 4 * b_ + decltype(ic)::value;
-                v[b_ & 1][2 * decltype(ic)::value] = lds_rd<i * PL * 8>(base);
-                v[b_ & 1][2 * decltype(ic)::value + 1] = lds_rd<(i + M) * PL * 8>(base);
-            });
+            v[b_ & 1][0] = lds_rd2<(4 * b_) * 8>(base);
+            v[b_ & 1][1] = lds_rd2<(4 * b_ + M) * 8>(base);
+            v[b_ & 1][2] = lds_rd2<(4 * b_ + 2) * 8>(base);
+            v[b_ & 1][3] = lds_rd2<(4 * b_ + 2 + M) * 8>(base);
         };
         issue(std::integral_constant<int, 0>{});
         static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
             constexpr int b_ = decltype(bc)::value;
             if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
-            lds_wait<(b_ + 1 < NB) ? 8 : 0>(v[b_ & 1]);
+            lds_wait<(b_ + 1 < NB) ? 4 : 0>(v[b_ & 1]);
             static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
                 constexpr int q = decltype(ic)::value, i = 4 * b_ + q;
-                const double r = v[b_ & 1][2 * q] + sg * v[b_ & 1][2 * q + 1];
+                const double lo_ = (q & 1) ? v[b_ & 1][q & 2].y : v[b_ & 1][q & 2].x;
+                const double hi_ = (q & 1) ? v[b_ & 1][(q & 2) + 1].y : v[b_ & 1][(q & 2) + 1].x;
+                const double r = lo_ + sg * hi_;
                 if constexpr (COMP) u[i].y = r;
                 else u[i].x = r;
             });
         });
 #else
-        const double* col = plane + k;
+        const double* col = plane + L * P1;
         for (int i = 0; i < M; ++i) {
-            const double r = col[i * PL] + sg * col[(i + M) * PL];
+            const double r = col[i] + sg * col[i + M];
             if (COMP) u[i].y = r;
             else u[i].x = r;
         }
@@ -310,11 +367,12 @@ struct Split {
         fft_inreg_d<M, 1>(u);
     }
 
-    // ---- X (64x64): cross-spectrum in place with the mirrored bins fetched by ds_bpermute.  sh(value, reg, comp, partner)
-    // returns the PARTNER thread's value of register `reg` (device: ds_bpermute of `value`; the host harness looks it up).
+    // ---- X: cross-spectrum z -> pz.  sh(value, reg, comp) returns the MIRROR thread's value of register `reg`: the
+    // neighbouring lane's (device: quad-permute DPP of `value`; the host harness looks it up), the thread's own in the
+    // lanes of the self-mirrored columns 0 and W/2.
     // bin ky = 2m + G sits at z[FFT_POS<m>]; its mirror -ky = 2 m' + G with m' = (M - m) % M (G = 0), M - 1 - m (G = 1)
     template <int G, typename SH>
-    static TPIV_HD void cross_spectrum_g(cd (&z)[M], int partner, SH&& sh) {
+    static TPIV_HD void cross_spectrum_g(const cd (&z)[M], cd (&pz)[M], SH&& sh) {
         constexpr int NPAIR = G ? M / 2 : M / 2 + 1;
         static_for<0, NPAIR>([&](auto mc) TPIV_LAMBDA_INLINE {
             constexpr int m = decltype(mc)::value;
@@ -323,69 +381,27 @@ struct Split {
             cd z1 = z[p1];
             pin(z1);
             if constexpr (m == m2) {
-                const cd m1{sh(z1.x, p1, 0, partner), sh(z1.y, p1, 1, partner)};
-                z[p1] = cross_bin(z1, m1);
+                const cd m1{sh(z1.x, p1, 0), sh(z1.y, p1, 1)};
+                pz[p1] = cross_bin(z1, m1);
+                pin(pz[p1]);
             } else {
                 cd z2 = z[p2];
                 pin(z2);
-                const cd m1{sh(z2.x, p2, 0, partner), sh(z2.y, p2, 1, partner)};      // Z(-ky, -k)
-                const cd m2v{sh(z1.x, p1, 0, partner), sh(z1.y, p1, 1, partner)};     // Z(+ky, -k): the mirror of bin -ky
-                z[p1] = cross_bin(z1, m1);
-                z[p2] = cross_bin(z2, m2v);
+                const cd m1{sh(z2.x, p2, 0), sh(z2.y, p2, 1)};      // Z(-ky, -k)
+                const cd m2v{sh(z1.x, p1, 0), sh(z1.y, p1, 1)};     // Z(+ky, -k): the mirror of bin -ky
+                pz[p1] = cross_bin(z1, m1);
+                pz[p2] = cross_bin(z2, m2v);
+                // (the empty asm statements execute in program order: with the inputs AND the results of a pair passing
+                //  through one, the pairs stay one after the other -- left alone, instruction selection emits the 128
+                //  moves of all pairs first and the register allocator spills them)
+                pin(pz[p1]);
+                pin(pz[p2]);
             }
 #if defined(__HIP_DEVICE_COMPILE__)
-            // keep the exchange of a bin pair together: hoisted ahead, the 8 permutes of every pair hold their results
-            // in registers next to the 128 of the spectrum
-            if constexpr (m % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+            // keep the exchange of a bin pair together: hoisted ahead, the moves of every pair hold their results in
+            // registers next to the 128 of the spectrum
+            __builtin_amdgcn_sched_barrier(0);
 #endif
-        });
-    }
-    // ---- X (128x128): the mirrored bins through the plane.  cross_write<COMP>: plane[ky][k] <- Z(ky, k); cross_read<COMP>:
-    // mir[m] = component of Z(-ky, -k) for the thread's bins ky = 2m + g (row (W - ky) % W, column (W - k) % W).
-    template <int COMP>
-    static TPIV_HD void cross_write(const cd (&z)[M], int k, int g, double* plane) {
-        double* col = plane + g * PL + k;
-        static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
-            constexpr int m = decltype(mc)::value;
-            col[2 * m * PL] = COMP ? z[FFT_POS<m, M>].y : z[FFT_POS<m, M>].x;
-        });
-    }
-    static TPIV_HD void cross_read(double (&mir)[M], int k, int g, const double* plane) {
-        const int mk = (W - k) & (W - 1);
-        // row of bin m: (W - 2m - g) % W = W - 2m - g for m >= 1; m = 0: (W - g) % W
-        const double* c0 = plane + mk - g * PL;                  // + (W - 2m) * PL for m >= 1
-        mir[0] = plane[((W - g) & (W - 1)) * PL + mk];
-#if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned base = lds_addr(c0);
-        constexpr int NB = (M - 1 + 7) / 8;
-        double v[2][8];
-        auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
-            constexpr int b_ = decltype(bc)::value;
-            static_for<0, 8>([&](auto ic) TPIV_LAMBDA_INLINE {
-                constexpr int m = 1 + 8 * b_ + decltype(ic)::value;
-                if constexpr (m < M) v[b_ & 1][decltype(ic)::value] = lds_rd<(W - 2 * m) * PL * 8>(base);
-                else v[b_ & 1][decltype(ic)::value] = 0.0;
-            });
-        };
-        issue(std::integral_constant<int, 0>{});
-        static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
-            constexpr int b_ = decltype(bc)::value;
-            if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
-            constexpr int left = M - 1 - 8 * (b_ + 1);               // reads issued behind this batch
-            lds_wait<(b_ + 1 < NB) ? (left < 8 ? left : 8) : 0>(v[b_ & 1]);
-            static_for<0, 8>([&](auto ic) TPIV_LAMBDA_INLINE {
-                constexpr int m = 1 + 8 * b_ + decltype(ic)::value;
-                if constexpr (m < M) mir[m] = v[b_ & 1][decltype(ic)::value];
-            });
-        });
-#else
-        for (int m = 1; m < M; ++m) mir[m] = c0[(W - 2 * m) * PL];
-#endif
-    }
-    static TPIV_HD void cross_finish(cd (&z)[M], const double (&mre)[M], const double (&mim)[M]) {
-        static_for<0, M>([&](auto mc) TPIV_LAMBDA_INLINE {
-            constexpr int m = decltype(mc)::value;
-            z[FFT_POS<m, M>] = cross_bin(z[FFT_POS<m, M>], cd{mre[m], mim[m]});
         });
     }
 
@@ -403,64 +419,57 @@ struct Split {
             });
         }
     }
-    // ---- T2 write: thread (k, g): plane[M g + y1][k] <- G_g[y1][k]
-    template <int COMP>
-    static TPIV_HD void t2_write(const cd (&t)[M], int k, int g, double* plane) {
-        double* col = plane + (M * g) * PL + k;
+    // ---- T2 write: thread (position L, g), k = col_of(L): plane2[M g + y1][k] <- G_g[y1][k] for the columns k <= W/2
+    // (the others are the mirrors nobody reads: the map rows are real)
+    static TPIV_HD void t2_write(const cd (&t)[M], int L, int g, double* plane) {
+        const int k = col_of(L);
+        if (k > M) return;
+        double* el = plane + 2 * ((M * g) * P2 + k);
 #if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned base = lds_addr(col);
+        const unsigned base = lds_addr(el);
         static_for<0, M>([&](auto yc) TPIV_LAMBDA_INLINE {
             constexpr int y1 = decltype(yc)::value;
-            lds_wr<y1 * PL * 8>(base, COMP ? t[FFT_POS<y1, M>].y : t[FFT_POS<y1, M>].x);
+            lds_wr2<y1 * P2 * 16>(base, d2{t[FFT_POS<y1, M>].x, t[FFT_POS<y1, M>].y});
         });
 #else
         static_for<0, M>([&](auto yc) TPIV_LAMBDA_INLINE {
             constexpr int y1 = decltype(yc)::value;
-            col[y1 * PL] = COMP ? t[FFT_POS<y1, M>].y : t[FFT_POS<y1, M>].x;
+            el[2 * y1 * P2] = t[FFT_POS<y1, M>].x;
+            el[2 * y1 * P2 + 1] = t[FFT_POS<y1, M>].y;
         });
 #endif
     }
     // ---- T2 read: thread (y, q): Y[kx] = G_0[y % M][kx] +- G_1[y % M][kx], kx = 0..M
-    template <int COMP>
     static TPIV_HD void t2_read(cd (&Y)[M + 1], int y, const double* plane) {
         const double sg = y < M ? 1.0 : -1.0;
 #if defined(__HIP_DEVICE_COMPILE__)
-        const unsigned base = lds_addr(plane + (y & (M - 1)) * PL);
-        constexpr int NB = M / 4 + 1;                               // M / 4 batches of 4 columns + column M
-        double v[2][8];
+        const unsigned base = lds_addr(plane + 2 * (y & (M - 1)) * P2);
+        constexpr int NB = (M + 2) / 2;                              // batches of 2 columns = 4 reads of 16 bytes; the last holds column M alone
+        d2 v[2][4];
         auto issue = [&](auto bc) TPIV_LAMBDA_INLINE {
             constexpr int b_ = decltype(bc)::value;
-            static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
-                constexpr int kx = 4 * b_ + decltype(ic)::value;
-                if constexpr (kx <= M) {
-                    v[b_ & 1][2 * decltype(ic)::value] = lds_rd<kx * 8>(base);
-                    v[b_ & 1][2 * decltype(ic)::value + 1] = lds_rd<(M * PL + kx) * 8>(base);
-                }
-            });
+            v[b_ & 1][0] = lds_rd2<(2 * b_) * 16>(base);
+            v[b_ & 1][1] = lds_rd2<(M * P2 + 2 * b_) * 16>(base);
+            if constexpr (2 * b_ + 1 <= M) {
+                v[b_ & 1][2] = lds_rd2<(2 * b_ + 1) * 16>(base);
+                v[b_ & 1][3] = lds_rd2<(M * P2 + 2 * b_ + 1) * 16>(base);
+            }
         };
         issue(std::integral_constant<int, 0>{});
         static_for<0, NB>([&](auto bc) TPIV_LAMBDA_INLINE {
             constexpr int b_ = decltype(bc)::value;
             if constexpr (b_ + 1 < NB) issue(std::integral_constant<int, b_ + 1>{});
-            // outstanding behind this batch: the next one (8 reads, the last batch holds 2)
-            lds_wait<(b_ + 1 < NB) ? (b_ + 2 == NB ? 2 : 8) : 0>(v[b_ & 1]);
-            static_for<0, 4>([&](auto ic) TPIV_LAMBDA_INLINE {
-                constexpr int q = decltype(ic)::value, kx = 4 * b_ + q;
-                if constexpr (kx <= M) {
-                    const double r = v[b_ & 1][2 * q] + sg * v[b_ & 1][2 * q + 1];
-                    if constexpr (COMP) Y[kx].y = r;
-                    else Y[kx].x = r;
-                }
-            });
+            // outstanding behind this batch: the next one (4 reads, the last batch holds 2)
+            lds_wait<(b_ + 1 < NB) ? (b_ + 2 == NB ? 2 : 4) : 0>(v[b_ & 1]);
+            Y[2 * b_] = cd{v[b_ & 1][0].x + sg * v[b_ & 1][1].x, v[b_ & 1][0].y + sg * v[b_ & 1][1].y};
+            if constexpr (2 * b_ + 1 <= M)
+                Y[2 * b_ + 1] = cd{v[b_ & 1][2].x + sg * v[b_ & 1][3].x, v[b_ & 1][2].y + sg * v[b_ & 1][3].y};
         });
 #else
-        const double* r0 = plane + (y & (M - 1)) * PL;
-        const double* r1 = r0 + M * PL;
-        for (int kx = 0; kx <= M; ++kx) {
-            const double r = r0[kx] + sg * r1[kx];
-            if (COMP) Y[kx].y = r;
-            else Y[kx].x = r;
-        }
+        const double* r0 = plane + 2 * (y & (M - 1)) * P2;
+        const double* r1 = r0 + 2 * M * P2;
+        for (int kx = 0; kx <= M; ++kx)
+            Y[kx] = cd{r0[2 * kx] + sg * r1[2 * kx], r0[2 * kx + 1] + sg * r1[2 * kx + 1]};
 #endif
     }
     // ---- Ri: the real W-point row from its Hermitian half spectrum Y[0..M], split over the thread pair by OUTPUT parity
@@ -500,10 +509,12 @@ struct Split {
         });
     }
 
-    // ---- P: peak analysis in fftshift coordinates (y' = (y + W/2) % W, x' likewise).  Thread (y, q) holds
-    // c[2n + e] = corr[y][x = 4n + 2e + q].
-    // one pass over the raw cells gives their minimum AND their maximum: v = (c - min) + 1e-7 is monotonic in c, so the
-    // maximum of the shifted cells is the shifted maximum (exactly: the same two roundings)
+    // ---- P: peak analysis in fftshift coordinates (fy = (y + W/2) % W, fx likewise) on the RAW cells.  Thread (y, q)
+    // holds c[i] = corr[y][x = 4 (i / 2) + 2 (i % 2) + q], i.e. the shifted column fx0(i) + q.
+    static constexpr TPIV_HD int fx0(int i) { return (4 * (i >> 1) + 2 * (i & 1) + W / 2) & (W - 1); }
+    static TPIV_HD int frow(int y) { return (y + W / 2) & (W - 1); }
+    // one pass over the raw cells gives their minimum AND their maximum: v = (c - min) scale + 1e-7 is monotonic in c, so
+    // the maximum of the shifted cells is the shifted maximum (exactly: the same two roundings)
     static TPIV_HD void peak_local_minmax(const double (&c)[M], double& mn, double& mx) {
         mn = c[0];
         mx = c[0];
@@ -513,73 +524,61 @@ struct Split {
             mx = dmax2(mx, c[i]);
         }
     }
-    // v = (c - min) + 1e-7, written to the map (plane, shifted coordinates).  (No index is tracked: the arg-max position
-    // comes from the map afterwards -- first the smallest row whose maximum is the global one, then the first column of
-    // that row -- which keeps the scan free of compare / select chains.)
-    static TPIV_HD void peak_shift_and_write(double (&c)[M], double cmin, double scale, int y, int q, double* plane) {
-        const int fy = (y + W / 2) & (W - 1);
-        double* row = plane + fy * PL + q;
+    // The rows whose cells the record and the second peak may need one by one: the flat-index neighbours of the arg-max m
+    // (B:385-392) lie in the map rows my - 1 .. my + 1, the exclusion zone {clamp(m + i + W j), |i|, |j| <= wv} (B:346-358)
+    // in the rows my - wv - 1 .. my + wv + 1 (row wrap of m + i) -- the clamps to cell 0 / cell W^2 - 1 only occur when
+    // those rows reach the first / last map row.  Zone row zr <-> map row zlo + zr, zlo = my - wv - 1 (may be negative:
+    // rows outside the map are never touched), nz = 2 wv + 3.
+    static TPIV_HD void peak_zone_write(const double (&c)[M], int y, int q, int zlo, int nz, double* zone) {
+        const int zr = frow(y) - zlo;
+        if (zr < 0 || zr >= nz) return;
+        double* row = zone + zr * ZP + q;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const unsigned base = lds_addr(row);
         static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
             constexpr int i = decltype(ic)::value;
-            constexpr int fx0 = (4 * (i >> 1) + 2 * (i & 1) + W / 2) & (W - 1);   // + q: stays inside its pair
-            const double v = peak_shifted(c[i], cmin, scale);
-            c[i] = v;
-#if defined(__HIP_DEVICE_COMPILE__)
-            lds_wr<fx0 * 8>(lds_addr(row), v);
-#else
-            row[fx0] = v;
-#endif
+            lds_wr<fx0(i) * 8>(base, c[i]);
         });
+#else
+        static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
+            constexpr int i = decltype(ic)::value;
+            row[fx0(i)] = c[i];
+        });
+#endif
     }
-    // second peak: the thread's maximum outside the flat-index exclusion zone of m (B:346-358): f in {clamp(m + i + W j),
-    // |i|, |j| <= wv}: in row fy the columns mx + i (j = fy - my), mx + i + W (the row wrap, j = fy - my - 1) and
-    // mx + i - W (j = fy - my + 1), plus the two clamps.  Negative if every cell of the thread is excluded (an excluded
-    // cell takes part with its sign bit set: every map value is >= 1e-7).
-    static TPIV_HD double peak_second_local(const double (&c)[M], int y, int q, int m, int wv) {
-        constexpr int NW = W / 64;
-        const int fy = (y + W / 2) & (W - 1);
-        const int my = m / W, mx = m % W;
-        const int dj = fy - my;
-        unsigned long long ex[NW] = {};                // bit fx set = excluded
-        auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
-            lo_ = lo_ < 0 ? 0 : lo_;
-            hi_ = hi_ > W - 1 ? W - 1 : hi_;
-            for (int b_ = lo_; b_ <= hi_; ++b_) ex[b_ >> 6] |= 1ull << (b_ & 63);     // at most 2 wv + 1 columns
-        };
-        if (dj >= -wv && dj <= wv) span(mx - wv, mx + wv);
-        if (dj + 1 >= -wv && dj + 1 <= wv) span(mx - wv + W, mx + wv + W);
-        if (dj - 1 >= -wv && dj - 1 <= wv) span(mx - wv - W, mx + wv - W);
-        if (fy == 0 && (m - wv - wv * W) <= 0) ex[0] |= 1ull;
-        if (fy == W - 1 && (m + wv + wv * W) >= W * W - 1) ex[NW - 1] |= 1ull << 63;
-        // this thread's columns are fx0 + q: shift the mask down by q, the bit positions become compile-time constants
-        unsigned word[2 * NW];
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            unsigned long long w_ = ex[i] >> q;
-            if (i + 1 < NW && q) w_ |= ex[i + 1] << 63;
-            word[2 * i] = (unsigned)w_;
-            word[2 * i + 1] = (unsigned)(w_ >> 32);
-        }
-        double sv = -1.0;
-        static_for<0, M>([&](auto ic) TPIV_LAMBDA_INLINE {
-            constexpr int i = decltype(ic)::value;
-            constexpr int fx0 = (4 * (i >> 1) + 2 * (i & 1) + W / 2) & (W - 1);
-#if defined(__HIP_DEVICE_COMPILE__)
-            // sign-extended exclusion bit (0 / -1) -> sign bit of the value: excluded cells lose every comparison
-            const int kill = __builtin_amdgcn_sbfe((int)word[fx0 >> 5], fx0 & 31, 1);
-            const double v = __hiloint2double(__double2hiint(c[i]) | (kill & (int)0x80000000), __double2loint(c[i]));
-#else
-            const bool excl = (word[fx0 >> 5] >> (fx0 & 31)) & 1u;
-            const double v = excl ? -c[i] : c[i];
-#endif
-            sv = dmax2(sv, v);
-        });
-        return sv;
+    // is the flat cell f inside the exclusion zone of m?  f = m + i + W j with |i|, |j| <= wv (wv < W/2: unique), or one
+    // of the two clamps
+    // (0 / 1, written without short-circuit operators: the kernel evaluates it per lane inside straight-line code)
+    static TPIV_HD int peak_excluded(int f, int m, int wv) {
+        constexpr int KD = W * W;
+        const int d = f - m;
+        const int j0 = (d + W / 2) >> LOGW;             // floor((d + W/2) / W): arithmetic shift
+        const int r = d - (j0 << LOGW);                 // -W/2 <= r < W/2
+        int ex = (int)((unsigned)(r + wv) <= (unsigned)(2 * wv)) & (int)((unsigned)(j0 + wv) <= (unsigned)(2 * wv));
+        ex |= (int)(f == 0) & (int)(m - wv - wv * W <= 0);
+        ex |= (int)(f == KD - 1) & (int)(m + wv + wv * W >= KD - 1);
+        return ex;
+    }
+    // The same test taken apart for the kernel's scan of the zone rows (zone row zr <-> map row fy = my - wv - 1 + zr): with
+    // dx = fx - mx and q = floor((dx + W/2) / W) in {-1, 0, 1} the cell is m + i + W j with i = dx - q W, j = (fy - my) + q =
+    // zr - wv - 1 + q.  The column part depends on the lane only, the row part on the wave-uniform row and q.
+    static TPIV_HD bool peak_col_ok(int fx, int mx, int wv, int& q) {
+        const int dx = fx - mx;
+        q = (dx + W / 2) >> LOGW;
+        return (unsigned)(dx - (q << LOGW) + wv) <= (unsigned)(2 * wv);
+    }
+    static TPIV_HD bool peak_excluded_zr(bool colok, int q, int zr, int fy, int fx, int wv, bool clamp_lo, bool clamp_hi) {
+        bool ex = colok & ((unsigned)(zr - 1 + q) <= (unsigned)(2 * wv));
+        ex |= (clamp_lo & (fy == 0)) & (fx == 0);              // clamp_lo: m - wv - wv W <= 0
+        ex |= (clamp_hi & (fy == W - 1)) & (fx == W - 1);      // clamp_hi: m + wv + wv W >= W^2 - 1
+        return ex;
     }
     // record for finalize_kernel<true>: slot 0..7 = c[m], c[left], c[right], c[top], c[bot], c[m2], m, dead
-    // (flat-index neighbours and fix-ups of B:385-392; `sv` < 0: nothing left outside the exclusion zone -- the
-    // reference's second arg-max then runs over the zeroed map: c[m2] = 0, ratio = +inf)
-    static TPIV_HD double peak_record_slot(int slot, int m, double sv, bool dead, const double* plane) {
+    // (flat-index neighbours and fix-ups of B:385-392; sv_raw == PEAK_NONE: nothing left outside the exclusion zone -- the
+    // reference's second arg-max then runs over the zeroed map: c[m2] = 0, ratio = +inf).  The cells come out of the
+    // zone buffer and are shifted here.
+    static TPIV_HD double peak_record_slot(int slot, int m, double sv_raw, bool dead, const double* zone, int zlo, double cmin,
+                                           double scale) {
         const int KD = W * W;
         int left = m + 1, right = m - 1, top = m + W, bot = m - W;
         if (left >= KD - 1) left = m;
@@ -591,8 +590,10 @@ struct Split {
         qi = slot == 2 ? right : qi;
         qi = slot == 3 ? top : qi;
         qi = slot == 4 ? bot : qi;
-        double outv = plane[(qi / W) * PL + (qi % W)];
-        outv = slot == 5 ? (sv >= 0.0 ? sv : 0.0) : outv;
+        double raw = zone[((qi >> LOGW) - zlo) * ZP + (qi & (W - 1))];
+        raw = slot == 5 ? sv_raw : raw;
+        double outv = peak_shifted(raw, cmin, scale);
+        outv = (slot == 5 && sv_raw == PEAK_NONE) ? 0.0 : outv;
         outv = slot == 6 ? (double)m : outv;
         outv = slot == 7 ? (dead ? 1.0 : 0.0) : outv;
         return outv;
