@@ -281,8 +281,102 @@ def e2e_block(r, log, n, workers):
             "resident_clean_all_dropped": r.get("clean"), "resident_straight_runs": r.get("runs"),
             "resident_isolated_spots": r.get("spots"), "bmp_files_isolated_spots": r.get("files"),
             "bmp_files_generator_call": r.get("files_call"), "trials": r.get("trials"),
-            "note": "every figure is the median of three runs of pairs_per_case pairs (the distinct pairs streamed repeatedly)",
+            "host_cpu_s_per_pair": r.get("host_cpu_s_per_pair"),
+            "host": host_block(workers),
+            "note": "every figure is the median of three runs of pairs_per_case pairs behind one untimed run (the distinct pairs "
+                    "streamed repeatedly); host_cpu_s_per_pair = user + system CPU seconds of the process, its threads and "
+                    "its fill-worker processes per pair over the timed runs",
             "post_validation": r.get("stats"), "log": log}
+
+
+def host_block(workers=None):
+    """What the host side of a rank may count on, and what 8 ranks at the single-GPU generator rate would need."""
+    from torchpiv_amd import hostcfg
+    b = hostcfg.host_budget(1)
+    b8 = hostcfg.host_budget(8)
+    return {"cores_available": b["cores"], "cgroup_cpu_quota": hostcfg.cgroup_cpu_quota(),
+            "affinity_mask": len(os.sched_getaffinity(0)), "fill_workers_used": workers,
+            "budget_1_rank": {k: b[k] for k in ("per_rank", "read_threads", "fill_workers")},
+            "budget_8_ranks_on_this_node": {k: b8[k] for k in ("per_rank", "read_threads", "fill_workers")}}
+
+
+def e2e_sharded(args):
+    """`--e2e --gpus N`: the GENERATOR path sharded like dist.run_sharded -- every rank streams its own resident pairs
+    (isolated dead spots: nearly every pair needs the host triangulation) through ResidentPIV.batched with reader / worker
+    counts taken from its share of the node's cores, the finished fields stay on the device, ONE gather of (u, v) onto
+    rank 0 closes the timed region.  One JSON line from rank 0; `value` = pairs of all ranks / wall time (max over ranks)."""
+    from torchpiv_amd import hostcfg
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None:
+        raise SystemExit(spawn_ranks(args))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    pinned = hostcfg.pin_rank(local, int(world_env))        # before any GPU call and before the workers are started
+    import torch
+    import torch.distributed as dist
+    import torchpiv_amd as T
+    from torchpiv_amd import dist as pdist
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_generator
+    rank, world, local = pdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: {world} rank(s) running, --gpus {args.gpus} asked for")
+    if os.environ.get("TPIV_DIST_BACKEND") == "gloo":
+        local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    n, reps, batch = args.e2e_pairs, 4, 32
+    A, B = e2e_generator.make_frames(n, args.size, args.size, "spots")
+    piv = T.ResidentPIV(A, B, args.ws, args.ws // 2, multipass=args.passes, multipass_mode=args.mode, precision=args.precision)
+    budget = piv.auto_host_config(world)
+    order = list(range(n)) * reps
+    ids_base = rank * n * reps
+
+    def one_run():
+        piv.device_out = True
+        ids, uv = [], []
+        for i, x, y, u, v in piv.batched(batch, indices=order):
+            ids.append(ids_base + len(ids))
+            uv.append(torch.stack([u, v]))
+        f = torch.stack(uv) if uv else torch.zeros((0, 2, 0, 0), dtype=torch.float64, device=dev)
+        out = pdist.gather_fields(torch.tensor(ids, dtype=torch.int64, device=dev), f)
+        return len(ids), out
+
+    one_run()                                   # untimed: plan creation, worker start, communicator
+    piv.reset_stats()
+    dist.barrier()
+    torch.cuda.synchronize()
+    c0 = hostcfg.tree_cpu_seconds()
+    t0 = time.perf_counter()
+    yielded, (ids_all, f_all) = one_run()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    cpu = hostcfg.tree_cpu_seconds() - c0
+    backend = dist.get_backend()
+    t = torch.tensor([elapsed, cpu, float(yielded)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    me = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(dev), "device_index": dev.index,
+          "cores_pinned": len(pinned) if pinned else None, "post_validation": dict(piv.stats)}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, me)
+    if rank == 0:
+        total = n * reps * world
+        rec = {"metric": "generator pairs/s end to end at 4 MP, wind=64 ov=32 2-pass CWS (passes + post-validation + flip/scale "
+                         "+ yield), pairs sharded over the ranks, one gather of the fields at the end",
+               "value": total / float(tmax[0]), "unit": "pairs/s", "n_gpus": world, "higher_is_better": True, "scaling": "weak",
+               "data": "synthetic", "dtype": DTYPE[args.precision],
+               "config": {"workload": f"{n * reps} resident {args.size}x{args.size} pairs per rank ({n} distinct, isolated dead "
+                                      f"spots), batch {batch}, wind={args.ws} overlap={args.ws // 2} {args.passes}-pass {args.mode}",
+                          "pairs_total": total, "yielded_total": int(t[2]), "gathered_on_rank0": int(ids_all.numel())},
+               "host": {"budget_per_rank": budget, "host_cpu_s_per_pair": float(t[1]) / total,
+                        "cores_needed_at_this_rate": float(t[1]) / float(tmax[0])},
+               "distributed": {"world_size": world, "backend": backend, "collectives_per_gather": 2, "ranks": gathered}}
+        print(json.dumps(rec), flush=True)
+    piv.close()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def e2e_mode(args):
@@ -310,8 +404,8 @@ PREC_NOTE = {
 def main():
     args = parse_args()
     if args.e2e:
-        if args.gpus != 1:
-            raise SystemExit("bench.py --e2e is a single-GPU mode")
+        if args.gpus != 1 or os.environ.get("WORLD_SIZE") is not None:
+            return e2e_sharded(args)
         return e2e_mode(args)
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:

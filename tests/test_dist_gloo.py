@@ -70,6 +70,29 @@ def _worker(rank, world, port, q):
         assert st.n == 6 and all(np.array_equal(a, b) for a, b in zip(st.moments(), full.moments()))
     else:
         assert st.n == 0
+    # streaming mode: per-rank running accumulators, ONE payload gather of six planes per rank, Chan merge on rank 0 --
+    # the two-pass moments to rounding (uneven shards; with world 2 rank 1 holds 2 of 7 fields, offsets keep it honest)
+    fields7 = [(rng.standard_normal((4, 5)) * 3 + 100.0, rng.standard_normal((4, 5)) - 50.0) for _ in range(7)]
+    ss = EnsembleStats(streaming=True)
+    for k, (u, v) in enumerate(fields7):
+        if (k % 3 == 1) == (rank == 1):
+            ss.add(u, v, index=k)
+    calls = []
+    real_ag, real_g = dist.all_gather_into_tensor, dist.gather
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append("all_gather"), real_ag(*a, **k))[1]
+    dist.gather = lambda *a, **k: (calls.append("gather"), real_g(*a, **k))[1]
+    ss.gather()
+    dist.all_gather_into_tensor, dist.gather = real_ag, real_g
+    assert calls == ["all_gather", "gather"], calls
+    if rank == 0:
+        full = EnsembleStats()
+        for u, v in fields7:
+            full.add(u, v)
+        assert ss.n == 7
+        for a, b in zip(ss.moments(), full.moments()):
+            assert np.abs(a - b).max() <= 1e-12 * 100.0, float(np.abs(a - b).max())
+    else:
+        assert ss.n == 0
     dist.barrier()
     dist.destroy_process_group()
 

@@ -334,3 +334,47 @@ def test_batched_over_png_files_and_abandoned_generators(tmp_path):
     # and the two formats hold the same pixels, so they give the same fields
     for g_, r_ in zip(out["png"], out["bmp"]):
         assert all(np.array_equal(x, y, equal_nan=True) for x, y in zip(g_, r_))
+
+
+@pytest.mark.gpu
+def test_device_out_rows_equal_the_numpy_tuples(folder, golden):
+    """device_out (what dist.run_sharded gathers from): batched() hands out rows of the per-batch DEVICE stacks of the
+    finished fields, hole fills of the host stage scattered in -- the same bits as the numpy tuples of the default mode,
+    for pairs finished on the device and for pairs that needed the host triangulation alike."""
+    import torchpiv_amd as T
+    g = golden("g5_generator")
+    ws, ov, mp_, mode, dt = (int(t) for t in g["r1_kw"])
+    piv = T.OfflinePIV(folder, "cuda:0", "bmp", ws, ov, multipass=mp_, multipass_mode=("DWS", "CWS")[mode], dt=dt,
+                       scale=float(g["r1_scale"][0]))
+    ref = {i: (u, v) for i, x, y, u, v in piv.batched(3)}
+    piv.device_out = True
+    got = {i: (u, v) for i, x, y, u, v in piv.batched(3)}
+    assert ref and sorted(ref) == sorted(got) and piv.stats["host_fallback"] > 0
+    for i in ref:
+        assert isinstance(got[i][0], torch.Tensor) and got[i][0].is_cuda and got[i][0].dtype == torch.float64
+        assert np.array_equal(got[i][0].cpu().numpy(), ref[i][0], equal_nan=True)
+        assert np.array_equal(got[i][1].cpu().numpy(), ref[i][1], equal_nan=True)
+    piv.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_sharded_generator_rehearsal_two_ranks_one_gpu():
+    """`bench.py --gpus 2 --e2e`: the generator path sharded over two ranks (gloo: both ranks time-slice the one GPU of
+    the test box -- a rehearsal of the launch, of the per-rank host budget and of the single end-of-run gather from the
+    device-resident fields, not a measurement), one JSON line with the `distributed` and `host` blocks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TPIV_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--e2e", "--e2e-pairs", "16",
+                        "--size", "1024"], env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["distributed"]["world_size"] == 2 and line["distributed"]["backend"] == "gloo"
+    assert line["config"]["pairs_total"] == 2 * 16 * 4
+    assert line["config"]["gathered_on_rank0"] == line["config"]["yielded_total"] > 0
+    assert line["host"]["host_cpu_s_per_pair"] > 0 and line["host"]["budget_per_rank"]["ranks_on_node"] == 2
+    assert sum(rk["post_validation"]["pairs"] for rk in line["distributed"]["ranks"]) == 2 * 16 * 4

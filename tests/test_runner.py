@@ -123,3 +123,29 @@ def test_run_folder_matches_generator(tmp_path, golden):
     #  grid; the region-free statement is the bit-equality with the generator's own tuples above, and the
     #  generator's parity is tests/test_gpu_api.py::test_offline_piv_generator's strict chain)
     assert not (~close & ~region).any()
+
+
+def test_streaming_statistics_agree_with_the_two_pass_mode(golden):
+    """EnsembleStats(streaming=True): Welford accumulators instead of the stacked fields -- O(1) memory in the number of
+    pairs -- give the reference's two-pass moments to rounding on the fields of the reference's own run (g9), and the
+    whole statistics table (gradients included) to 1e-9 of each column's scale; the default mode stays bit-identical
+    (the tests above)."""
+    from torchpiv_amd.runner import EnsembleStats
+    g = golden("g9_stats")
+    n = int(np.asarray(g["n_pairs"]).reshape(-1)[0]) if "n_pairs" in g.files else None
+    us = [g[k] for k in sorted(k for k in g.files if k.startswith("pair") and k.endswith("_u"))]
+    vs = [g[k] for k in sorted(k for k in g.files if k.startswith("pair") and k.endswith("_v"))]
+    assert us and len(us) == len(vs) and (n is None or n == len(us))
+    two, one = EnsembleStats(), EnsembleStats(streaming=True)
+    for u, v in zip(us, vs):
+        two.add(u, v)
+        one.add(u, v)
+    assert one.n == two.n
+    scale = max(float(np.abs(np.stack(us)).max()), float(np.abs(np.stack(vs)).max()))
+    for a, b in zip(one.moments(), two.moments()):
+        assert np.abs(a - b).max() <= 1e-12 * max(scale, scale * scale)
+    x, y = g["pair0_x"], g["pair0_y"]
+    ta, tb = one.table(x, y), two.table(x, y)
+    assert list(ta) == list(tb)
+    for k in ta:
+        assert np.abs(ta[k] - tb[k]).max() <= 1e-9 * max(1.0, float(np.abs(tb[k]).max())), k

@@ -49,13 +49,19 @@ def rate(gen, n):
 
 
 def rate3(make_gen, n, trials=3):
-    """Median of `trials` runs (the host side shares its cores with other tenants: single runs of 0.2 s scatter by
-    +-15 %); returns (median rate, yielded, [all rates])."""
+    """Median of `trials` runs behind one untimed run (the first pass over a case pays for page faults, the plan's first
+    launches and the worker pool's start: round 3 counted it as a trial and the medians hid a +-20 % spread); returns
+    (median rate, yielded, [all rates], host CPU seconds per pair: user + system time of this process, its threads and
+    its fill-worker processes over the timed trials)."""
+    from torchpiv_amd import hostcfg
+    rate(make_gen(), n)
     rs = []
+    c0 = hostcfg.tree_cpu_seconds()
     for _ in range(trials):
         r, k = rate(make_gen(), n)
         rs.append(r)
-    return sorted(rs)[len(rs) // 2], k, [round(r_) for r_ in rs]
+    cpu = (hostcfg.tree_cpu_seconds() - c0) / (trials * n)
+    return sorted(rs)[len(rs) // 2], k, [round(r_) for r_ in rs], cpu
 
 
 def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True, budget_s=None, precision="f64", reps=8):
@@ -71,12 +77,13 @@ def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True,
         piv.fill_workers = workers
         rate(piv.batched(batch), n)                      # warm-up: plan creation
         piv.reset_stats()
-        r, k, rs = rate3(lambda: piv.batched(batch, indices=order), n * reps)
+        r, k, rs, cpu = rate3(lambda: piv.batched(batch, indices=order), n * reps)
         out[kind] = r
         out.setdefault("trials", {})[kind] = rs
-        st_ = {k_: v_ // 3 for k_, v_ in piv.stats.items()}
+        out.setdefault("host_cpu_s_per_pair", {})[kind] = cpu
+        st_ = {k_: v_ // 4 for k_, v_ in piv.stats.items()}
         out.setdefault("stats", {})[kind] = dict(st_, yielded=k)
-        print(f"resident {kind:6s}: {r:8.1f} pairs/s, median of {rs} ({k} of {n * reps} yielded)  {st_}")
+        print(f"resident {kind:6s}: {r:8.1f} pairs/s, median of {rs} ({k} of {n * reps} yielded), host CPU {cpu * 1e6:.0f} us/pair  {st_}")
         over = budget_s is not None and time.perf_counter() - t_start > budget_s
         if kind == "spots" and files and not over:
             from PIL import Image
@@ -93,13 +100,15 @@ def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True,
                 fp.read_threads = read_threads
             rate(fp.batched(batch, indices=range(n)), n)
             fp.reset_stats()
-            r, k, rs = rate3(lambda: fp.batched(batch), n * reps)
+            r, k, rs, cpu = rate3(lambda: fp.batched(batch), n * reps)
             out["files"] = r
             out["trials"]["files"] = rs
-            print(f"files    {kind:6s}: {r:8.1f} pairs/s, median of {rs} ({k} of {n * reps} yielded; 8-bit BMP in the page cache)")
-            r, k, rs = rate3(lambda: fp(), n * reps)
+            out["host_cpu_s_per_pair"]["files"] = cpu
+            print(f"files    {kind:6s}: {r:8.1f} pairs/s, median of {rs} ({k} of {n * reps} yielded; 8-bit BMP in the page cache), host CPU {cpu * 1e6:.0f} us/pair")
+            r, k, rs, cpu = rate3(lambda: fp(), n * reps)
             out["files_call"] = r
             out["trials"]["files_call"] = rs
+            out["host_cpu_s_per_pair"]["files_call"] = cpu
             print(f"files    __call__ (the reference's generator API; reads ahead {fp.call_batch} pairs per launch): {r:8.1f} pairs/s, median of {rs} ({k} yielded)")
             if budget_s is None:
                 fp.call_batch = 1

@@ -398,6 +398,18 @@ class OfflinePIV:
     fill_workers = 0         # > 0: the host triangulations of a batch run in that many worker processes
     pipeline_depth = 2       # batched() over files: launches in flight before a batch's results are collected
     read_threads = 8         # file reader threads of batched() (a page-cache read into pinned memory runs at ~3 GB/s per thread)
+    device_out = False       # batched(): yield u, v as float64 tensors ON THE DEVICE (the finished fields of B:894-898, hole
+                             # fills scattered in from the host) instead of numpy arrays -- for callers that go on with them
+                             # on the GPU (dist.run_sharded: the end-of-run gather over xGMI)
+
+    def auto_host_config(self, ranks_on_node=None):
+        """Size the reader threads and the fill-worker processes from the cores this rank really has (affinity mask and
+        container quota divided by the ranks of the node, torchpiv_amd.hostcfg) instead of the single-GPU defaults.
+        Returns the budget dict."""
+        from . import hostcfg
+        b = hostcfg.host_budget(ranks_on_node)
+        self.read_threads, self.fill_workers = b["read_threads"], b["fill_workers"]
+        return b
 
     def _fill_pool(self):
         if self.fill_workers <= 0:
@@ -492,7 +504,7 @@ class OfflinePIV:
         st["device_complete"] += int((keep & ~need_host).sum())
         for _ in range(2 * int(too_many.sum())):                  # once for u, once for v (B:306, B:889-890)
             print(TOO_MANY_MSG)
-        state = {"keep": keep, "need": np.flatnonzero(need_host), "host": host}
+        state = {"keep": keep, "need": np.flatnonzero(need_host), "host": host, "dev": keep_alive[0]}
         if state["need"].size:
             off = host["offsets"].numpy()                            # [2, n + 1]: ring / hole list starts per pair
             rc, uv, hc = host["ring_rc"].numpy(), host["ring_uv"].numpy(), host["hole_rc"].numpy()
@@ -539,6 +551,24 @@ class OfflinePIV:
                     vk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 1]
                 fu[i][nr - 1 - cells[:, 0], cells[:, 1]] = vals_k[:, 0] * self._scale / self._dt * 1000
                 fv[i][nr - 1 - cells[:, 0], cells[:, 1]] = -vals_k[:, 1] * self._scale / self._dt * 1000
+        if self.device_out and need.size:
+            # the same patches into the device copies of the finished fields: ONE small upload + index_put per batch
+            ii, rr, cc, pu, pv = [], [], [], [], []
+            for k, vals_k in enumerate(state["sols"]):
+                if vals_k is None:
+                    continue
+                cells = state["holes"][k]
+                ii.append(np.full(cells.shape[0], int(need[k]), dtype=np.int64))
+                rr.append(nr - 1 - cells[:, 0].astype(np.int64))
+                cc.append(cells[:, 1].astype(np.int64))
+                pu.append(vals_k[:, 0] * self._scale / self._dt * 1000)
+                pv.append(-vals_k[:, 1] * self._scale / self._dt * 1000)
+            if ii:
+                dev = state["dev"]["fu"].device
+                idx = torch.from_numpy(np.stack([np.concatenate(ii), np.concatenate(rr), np.concatenate(cc)])).to(dev)
+                val = torch.from_numpy(np.stack([np.concatenate(pu), np.concatenate(pv)])).to(dev)
+                state["dev"]["fu"][idx[0], idx[1], idx[2]] = val[0]
+                state["dev"]["fv"][idx[0], idx[1], idx[2]] = val[1]
         state["keep_final"] = keep
         return state
 
@@ -590,7 +620,10 @@ class OfflinePIV:
         keep = state["keep_final"]
         if not keep.any():
             return [None] * keep.size
-        U, V = np.array(state["host"]["fu"].numpy()), np.array(state["host"]["fv"].numpy())
+        if self.device_out:
+            U, V = state["dev"]["fu"], state["dev"]["fv"]           # rows of the batch's device stacks (views)
+        else:
+            U, V = np.array(state["host"]["fu"].numpy()), np.array(state["host"]["fv"].numpy())
         xs, ys = x * self._scale, y * self._scale
         xs.flags.writeable = False
         ys.flags.writeable = False
@@ -716,6 +749,8 @@ class OfflinePIV:
                 for i, staged in order:
                     out = next(res) if staged else self._one(i)
                     if out is not None:
+                        if self.device_out and not staged:      # the one-pair path finishes on the host
+                            out = out[:2] + tuple(torch.from_numpy(np.ascontiguousarray(f)).to(dev) for f in out[2:])
                         yield (i,) + out
 
         # uploads run on their own stream into a double-buffered device copy of the staging slots, so that the PCIe

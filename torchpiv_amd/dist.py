@@ -147,13 +147,20 @@ def run_sharded(piv, batch_size: int = 32, policy: str = "block", group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     mine = shard_indices(len(piv), rank, world, policy)
     ids, uv, xy = [], [], None
-    for i, x, y, u, v in piv.batched(batch_size, indices=mine):
-        ids.append(i)
-        uv.append(np.stack([u, v]))
-        xy = (x, y)
+    # the finished fields stay where the last kernel left them: batched() hands out rows of the per-batch device stacks
+    # (hole fills of the host stage scattered in), and the gather below reads device memory -- nothing goes host -> device
+    was = piv.device_out
+    piv.device_out = True
+    try:
+        for i, x, y, u, v in piv.batched(batch_size, indices=mine):
+            ids.append(i)
+            uv.append(torch.stack([u, v]))
+            xy = (x, y)
+    finally:
+        piv.device_out = was
     dev = piv._device
     if uv:
-        f = torch.from_numpy(np.stack(uv)).to(dev)
+        f = torch.stack(uv)
     else:       # empty shard (or every pair of it dropped): gather_fields takes the grid from the other ranks
         f = torch.zeros((0, 2, 0, 0), dtype=torch.float64, device=dev)
     i_all, f_all = gather_fields(torch.tensor(ids, dtype=torch.int64, device=dev), f, group=group)

@@ -48,8 +48,14 @@ def bmp_layout(buf):
         return None
     w, h, planes, bpp, comp = struct.unpack_from("<iiHHI", buf, 18)
     ncol = struct.unpack_from("<I", buf, 46)[0]
-    if comp not in (0, 3) or bpp not in (8, 24, 32) or w <= 0 or h == 0:
+    if comp not in (0, 3) or bpp not in (8, 24, 32) or w <= 0 or h == 0 or planes != 1:
         return None
+    if comp == 3:
+        # BI_BITFIELDS: only the standard layout of a 32-bit file (B, G, R in the low three bytes) is plain BGR(A);
+        # other channel masks belong to the general decoder (imdecode_gray), which honours them
+        masks_at = 14 + 40                                      # the masks follow the 40-byte header (V4 / V5: its first extra fields)
+        if bpp != 32 or len(buf) < masks_at + 12 or struct.unpack_from("<III", buf, masks_at) != (0xFF0000, 0xFF00, 0xFF):
+            return None
     lut = None
     if bpp == 8:
         n = ncol if ncol else 256
@@ -125,11 +131,17 @@ def parse_bmp_headers(raw: np.ndarray, sizes: np.ndarray, H: int, W: int):
     u32 = lambda off: hdr[:, off:off + 4].copy().view("<u4")[:, 0].astype(np.int64)      # noqa: E731
     i32 = lambda off: hdr[:, off:off + 4].copy().view("<i4")[:, 0].astype(np.int64)      # noqa: E731
     u16 = lambda off: hdr[:, off:off + 2].copy().view("<u2")[:, 0].astype(np.int64)      # noqa: E731
-    data_off, hsz, w, h, bpp, comp, ncol = u32(10), u32(14), i32(18), i32(22), u16(28), u32(30), u32(46)
+    data_off, hsz, w, h, planes, bpp, comp, ncol = u32(10), u32(14), i32(18), i32(22), u16(26), u16(28), u32(30), u32(46)
     stride = ((w * bpp + 31) // 32) * 4
-    # the common camera file: BITMAPINFOHEADER, uncompressed, 8 / 24 / 32 bit, full palette right behind the header
-    plain = ok & (hdr[:, 0] == 0x42) & (hdr[:, 1] == 0x4D) & (hsz == 40) & ((comp == 0) | (comp == 3)) & (w == W) & \
-        (np.abs(h) == H) & np.isin(bpp, (8, 24, 32)) & (data_off + stride * H <= sizes) & ((bpp != 8) | (ncol == 0) | (ncol == 256))
+    # the common camera file: BITMAPINFOHEADER, one plane, uncompressed, 8 / 24 / 32 bit, full palette right behind the
+    # header, pixel data behind header and palette.  BI_BITFIELDS (comp == 3) only with the standard channel masks of a
+    # 32-bit file (B, G, R in the low three bytes, read from offset 54): any other mask layout -- and every other header --
+    # goes to the per-file decoder, which honours the masks.
+    std_masks = (u32(54) == 0x00FF0000) & (u32(58) == 0x0000FF00) & (u32(62) == 0x000000FF)
+    plain = ok & (hdr[:, 0] == 0x42) & (hdr[:, 1] == 0x4D) & (hsz == 40) & (planes == 1) & \
+        ((comp == 0) | ((comp == 3) & (bpp == 32) & std_masks & (data_off >= 54 + 12))) & (w == W) & \
+        (np.abs(h) == H) & np.isin(bpp, (8, 24, 32)) & (data_off + stride * H <= sizes) & \
+        ((bpp != 8) | (ncol == 0) | (ncol == 256)) & (data_off >= 54 + np.where(bpp == 8, 1024, 0))
     if plain.any():
         pal = hdr[:, 54:54 + 1024].reshape(n, 256, 4)
         luts = _bgr_to_gray(pal[..., 0], pal[..., 1], pal[..., 2])

@@ -74,19 +74,62 @@ class EnsembleStats:
     E[x^2] - E[x]^2 would cancel where the two-pass form does not).  The fields are kept on the host until
     the end of the run (O(n) memory, see moments()) and the moments come from a kernel on the GPU
     (tpiv_ensemble_moments: one thread per grid cell walks the stack in order), chunk of cells by chunk of
-    cells, or from numpy."""
+    cells, or from numpy.
 
-    def __init__(self):
+    streaming=True (extension for long runs): nothing is kept per pair.  Five float64 accumulators per grid cell --
+    mean u, mean v and the centred sums M2_uu, M2_vv, C_uv -- are updated field by field with Welford's recurrence
+    (no E[x^2] - E[x]^2 cancellation), every rank accumulates its own shard, and the ranks' accumulators are merged on
+    rank 0 with Chan's pairwise formula after ONE payload gather of 6 planes per rank (the five accumulators and the
+    count).  A 4000 x 1023 x 1023 run needs 50 MB per rank instead of 67 GB on rank 0; the moments agree with the
+    two-pass mode to rounding (<= 1e-12 relative to the field's scale, tests/test_runner.py), not bit for bit."""
+
+    def __init__(self, streaming: bool = False):
+        self.streaming = bool(streaming)
         self.ids, self.u, self.v = [], [], []
+        self._n = 0
+        self._acc = None                 # streaming: float64 [5, R, S] = mean u, mean v, M2_uu, M2_vv, C_uv
 
     @property
     def n(self):
-        return len(self.u)
+        return self._n if self.streaming else len(self.u)
 
     def add(self, u: np.ndarray, v: np.ndarray, index=None):
+        if self.streaming:
+            u = np.asarray(u, dtype=np.float64)
+            v = np.asarray(v, dtype=np.float64)
+            if self._acc is None:
+                self._acc = np.zeros((5,) + u.shape, dtype=np.float64)
+            self._n += 1
+            a = self._acc
+            du, dv = u - a[0], v - a[1]                  # against the OLD means
+            a[0] += du / self._n
+            a[1] += dv / self._n
+            du2, dv2 = u - a[0], v - a[1]                # against the NEW means
+            a[2] += du * du2
+            a[3] += dv * dv2
+            a[4] += du * dv2
+            return
         self.ids.append(len(self.ids) if index is None else int(index))
         self.u.append(np.asarray(u, dtype=np.float64))
         self.v.append(np.asarray(v, dtype=np.float64))
+
+    @staticmethod
+    def _merge(na, A, nb, B):
+        """Chan et al.: accumulators of two disjoint samples -> accumulators of their union."""
+        if nb == 0:
+            return na, A
+        if na == 0:
+            return nb, B
+        n = na + nb
+        du, dv = B[0] - A[0], B[1] - A[1]
+        w = na * nb / n
+        out = np.empty_like(A)
+        out[0] = A[0] + du * (nb / n)
+        out[1] = A[1] + dv * (nb / n)
+        out[2] = A[2] + B[2] + du * du * w
+        out[3] = A[3] + B[3] + dv * dv * w
+        out[4] = A[4] + B[4] + du * dv * w
+        return n, out
 
     def gather(self, device=None, group=None):
         """Multi-rank runs: bring every rank's fields onto rank 0, in dataset order (one count exchange
@@ -97,6 +140,22 @@ class EnsembleStats:
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
         dev = device if (device is not None and dist.get_backend(group) == "nccl") else "cpu"
+        if self.streaming:
+            # six planes per rank: the five accumulators and the count (ranks without a field send nothing and take the
+            # grid from the others, like an empty shard of fields)
+            if self._n:
+                f = torch.from_numpy(np.concatenate([self._acc, np.full((1,) + self._acc.shape[1:], float(self._n))])[None]).to(dev)
+            else:
+                f = torch.zeros((0, 6, 0, 0), dtype=torch.float64, device=dev)
+            me = dist.get_rank(group)
+            ids, planes = pdist.gather_fields(torch.tensor([me] if self._n else [], dtype=torch.int64, device=dev), f, group=group)
+            self._n, self._acc = 0, None
+            if ids is None:
+                return
+            planes = planes.cpu().numpy()
+            for k in range(planes.shape[0]):             # rank order
+                self._n, self._acc = self._merge(self._n, self._acc, int(round(planes[k, 5].flat[0])), planes[k, :5].copy())
+            return
         f = torch.from_numpy(np.stack([np.stack(self.u), np.stack(self.v)], axis=1)).to(dev) if self.u \
             else torch.zeros((0, 2, 0, 0), dtype=torch.float64, device=dev)
         ids, fields = pdist.gather_fields(torch.tensor(self.ids, dtype=torch.int64, device=dev), f, group=group)
@@ -121,6 +180,9 @@ class EnsembleStats:
         grid cells (CHUNK_BYTES per field component), each chunk is stacked, uploaded and reduced on its own
         (tpiv_ensemble_moments walks a cell's stack in order, so cutting along the cells changes no bit), and
         a chunk that does not fit the GPU is reduced by numpy instead."""
+        if self.streaming:
+            a = self._acc
+            return a[0].copy(), a[1].copy(), a[2] / self._n, a[3] / self._n, a[4] / self._n
         order = np.argsort(np.asarray(self.ids), kind="stable")
         n = len(order)
         shape = self.u[order[0]].shape
@@ -174,9 +236,11 @@ def run_folder(folder: str, device: str, file_fmt: str, wind_size: int, overlap:
                multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.0, multipass_scale: float = 2.0,
                folder_mode: str = "pairs", save_opt: str = "Dont save", save_dir: str = "Out",
                batch_size: int = 32, on_pair=None, distributed: bool = False, stats_on_device: bool = True,
-               precision: str = "f64"):
+               precision: str = "f64", streaming_stats: bool = False):
     """Process a folder like PIVWorker.run.  save_opt: "Dont save" | "Save all binary" |
     "Save all text" | "Save statistics" (anything but "Dont save" also writes the statistics table).
+    streaming_stats: running accumulators instead of the stacked fields (EnsembleStats(streaming=True): O(1) memory in
+    the number of pairs, one 6-plane gather between ranks; moments to rounding instead of bit for bit).
     Returns (table, n_pairs_done); with distributed=True every rank processes its shard of the
     pairs and rank 0 returns the table of the whole ensemble (other ranks: (None, n_local))."""
     piv = OfflinePIV(folder, device, file_fmt, wind_size, overlap, multipass=multipass,
@@ -193,7 +257,9 @@ def run_folder(folder: str, device: str, file_fmt: str, wind_size: int, overlap:
             rank, world = dist.get_rank(), dist.get_world_size()
         indices = pdist.shard_indices(len(piv), rank, world)
     name = os.path.basename(os.path.normpath(folder))
-    stats = EnsembleStats()
+    stats = EnsembleStats(streaming=streaming_stats)
+    if distributed and world > 1:
+        piv.auto_host_config()           # reader threads / fill workers from this rank's share of the node's cores
     x = y = None
     done = 0
     for i, xx, yy, u, v in piv.batched(batch_size, indices=indices):
