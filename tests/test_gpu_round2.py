@@ -209,6 +209,23 @@ def _random_masks(rng, nr, nc):
     m[:, 0] = m[:, nc - 1] = True
     m[0, :] = m[nr - 1, :] = True
     cases.append(("whole frame border", m))
+    # groups whose every cell has a triangulation-independent fill (round 4: postval_rules.inc): L, T, S shapes, a long L,
+    # a thick bar's corner cells stay GENERAL (co-circular), so that one is listed apart
+    m = np.zeros((nr, nc), bool)
+    m[2, 3] = m[3, 3] = m[3, 4] = True                       # L3
+    m[2, 9:12] = m[3, 10] = True                             # T4
+    m[7, 3] = m[7, 4] = m[8, 4] = m[8, 5] = True             # S4
+    m[10:13, 12] = m[12, 13] = True                          # L4
+    m[12, 17:19] = m[13, 18] = m[14, 18] = True              # L4, other orientation
+    cases.append(("L, T and S shaped groups", m))            # device-complete
+    m = np.zeros((nr, nc), bool)
+    m[4:6, 5:9] = True                                       # 2 x 4 bar: co-circular octagons, stays with Qhull
+    m[10, 3] = m[11, 3] = m[11, 4] = True
+    cases.append(("thick bar + L", m))
+    for k, dens in enumerate((0.04, 0.06, 0.08, 0.10, 0.12, 0.08)):      # clustered random holes: whatever groups come up
+        m = rng.random((nr, nc)) < dens
+        m |= np.roll(m, 1, axis=k % 2) & (rng.random((nr, nc)) < 0.5)
+        cases.append((f"random clustered {k}", m))
     return cases
 
 
@@ -256,6 +273,10 @@ def test_postval_device_vs_host(eng, golden):
         assert np.allclose(Vd[k][filled], hv[filled], rtol=0, atol=1e-12), name
         if counts[k, 2] + counts[k, 3] == 0:
             assert np.allclose(Ud[k], hu, rtol=0, atol=1e-12, equal_nan=True), name
+        if name == "L, T and S shaped groups":
+            assert counts[k, 2] + counts[k, 3] == 0 and filled.sum() == m.sum(), (name, counts[k].tolist())
+        if name == "thick bar + L":
+            assert counts[k, 3] > 0 and filled.sum() >= 3, (name, counts[k].tolist())
         print(f"  postval '{name}': holes {counts[k, 0]}, ring {counts[k, 1]}, ambiguous {counts[k, 2]}, "
               f"general {counts[k, 3]}, filled on the device {int(filled.sum())}")
     # the reference's KAT (golden g6 pv_*): same NaN pattern through the device path

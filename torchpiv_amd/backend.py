@@ -419,8 +419,10 @@ class OfflinePIV:
             import multiprocessing as mp
             if pool is not None:
                 pool.terminate()
-            # spawn: the workers never see this process's HIP state; they only run scipy on small arrays
-            self._pool = pool = mp.get_context("spawn").Pool(self.fill_workers)
+            # spawn: the workers never see this process's HIP state; they only run scipy on small arrays (with ONE BLAS
+            # thread each: _qhull.single_thread_blas)
+            from ._qhull import single_thread_blas
+            self._pool = pool = mp.get_context("spawn").Pool(self.fill_workers, initializer=single_thread_blas)
             self._pool_size = self.fill_workers
         return pool
 
@@ -525,7 +527,12 @@ class OfflinePIV:
                 state["sols"] = [s_ for part in pool.map(qhull_fill_many, [jobs[k:k + per] for k in range(0, len(jobs), per)])
                                  for s_ in part]
             else:
-                state["sols"] = qhull_fill_many(jobs)
+                if not getattr(OfflinePIV, "_blas_limited", False):
+                    from ._qhull import blas_one_thread
+                    OfflinePIV._blas_ctx = blas_one_thread
+                    OfflinePIV._blas_limited = True
+                with OfflinePIV._blas_ctx():
+                    state["sols"] = qhull_fill_many(jobs)
         return state
 
     def _post_complete(self, state):

@@ -27,9 +27,17 @@
 //     CO-CIRCULAR diamond: the triangulation may take either diagonal, the value is (N+S)/2 or
 //     (E+W)/2, and Qhull decides by the order in which it happened to insert the four vertices
 //     ('Qt' fans a non-simplicial facet from its highest vertex id) -- a function of the whole point
-//     set.  Such cells (class AMBIGUOUS) and cells inside wider holes (class GENERAL) are only
-//     counted here: pairs that contain any go to the host triangulation (torchpiv_amd/backend.py),
-//     and the fallbacks are counted.
+//     set.  Such cells (class AMBIGUOUS) are only counted here: pairs that contain any go to the host
+//     triangulation (torchpiv_amd/backend.py), and the fallbacks are counted.
+//
+//   postval_rules_kernel     (round 4) cells of wider holes (class GENERAL: corners of L / T / S shaped groups of
+//                            invalid vectors, ends of thick bars ...): a triangle of ring points that contains the
+//                            cell and whose CLOSED circumdisc holds no other ring point belongs to EVERY Delaunay
+//                            triangulation (strict empty-circle property), so the cell's value is the barycentric
+//                            sum over that triangle whatever Qhull does elsewhere.  postval_rules.inc lists the 40
+//                            such triangles with circumradius^2 <= 5/2 (generated and checked against SciPy by
+//                            tools/research/fill_rules.py): three vertex offsets, the weights, and the other lattice
+//                            cells of the disc, none of which may be a ring cell.  Cells no rule covers stay GENERAL.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -147,6 +155,43 @@ __global__ __launch_bounds__(256) void postval_classify_kernel(PostvalParams p) 
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if ((threadIdx.x & 63) == 0 && s) atomicAdd(&p.counts[pair * 4 + q], s);
     }
+}
+
+#include "postval_rules.inc"
+
+__global__ __launch_bounds__(256) void postval_rules_kernel(PostvalParams p) {
+    const int pair = blockIdx.y;
+    const size_t off = (size_t)pair * p.n_rows * p.n_cols;
+    double* __restrict__ u = p.u + off;
+    double* __restrict__ v = p.v + off;
+    uint8_t* cls = p.cls + off;
+    const int nr = p.n_rows, nc = p.n_cols, n = nr * nc;
+    int n_filled = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (cls[i] != PV_GENERAL) continue;
+        const int r = i / nc, c = i - r * nc;
+        // (ring cells are valid cells: this kernel neither changes them nor their values; it only turns GENERAL into
+        //  FILLED, both of which are "hole" to every test below)
+        auto ring = [&](int dr, int dc) {
+            const int rr = r + dr, cc = c + dc;
+            return rr >= 0 && rr < nr && cc >= 0 && cc < nc && cls[rr * nc + cc] == PV_RING;
+        };
+        for (int k = 0; k < PV_N_RULES; ++k) {
+            const PvRule& R = PV_RULES[k];
+            bool ok = ring(R.v[0][0], R.v[0][1]) && ring(R.v[1][0], R.v[1][1]) && ring(R.v[2][0], R.v[2][1]);
+            for (int b = 0; ok && b < R.nb; ++b) ok = !ring(R.b[b][0], R.b[b][1]);
+            if (!ok) continue;
+            const int i0 = i + R.v[0][0] * nc + R.v[0][1], i1 = i + R.v[1][0] * nc + R.v[1][1], i2 = i + R.v[2][0] * nc + R.v[2][1];
+            u[i] = R.w[0] * u[i0] + R.w[1] * u[i1] + R.w[2] * u[i2];
+            v[i] = R.w[0] * v[i0] + R.w[1] * v[i1] + R.w[2] * v[i2];
+            cls[i] = PV_FILLED;
+            ++n_filled;
+            break;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_filled += __shfl_xor(n_filled, o, 64);
+    if ((threadIdx.x & 63) == 0 && n_filled) atomicSub(&p.counts[pair * 4 + 3], n_filled);
 }
 
 // ---- hand-over to the host triangulation: what fillMissingValues (B:284-308) feeds to the interpolator, cut out of
@@ -313,6 +358,9 @@ hipError_t launch_postval(const PostvalParams& p, hipStream_t stream) {
     if (bpp < 1) bpp = 1;
     if (bpp > 256) bpp = 256;
     hipLaunchKernelGGL(postval_classify_kernel, dim3(bpp, p.batch), dim3(256), 0, stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(postval_rules_kernel, dim3(bpp, p.batch), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
