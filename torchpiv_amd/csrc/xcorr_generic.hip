@@ -9,6 +9,7 @@
 // mean, no mean removal, float64 transforms, map and peak analysis).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fft_inreg.hpp"
 #include "piv_kernels.h"
@@ -40,6 +41,30 @@ __device__ __forceinline__ float cws_sample_g(const uint8_t* __restrict__ f, int
     const float f21 = fetch_clamped_g(f, (long long)dy * W + ux, HW);
     const float f12 = fetch_clamped_g(f, (long long)uy * W + dx, HW);
     const float f22 = fetch_clamped_g(f, (long long)uy * W + ux, HW);
+    const float wxu = ux_f - nx, wxd = nx - dx_f, wyu = uy_f - ny, wyd = ny - dy_f;
+    float r = (f11 * wxu) * wyu;
+    r = r + (f21 * wxd) * wyu;
+    r = r + (f12 * wxu) * wyd;
+    r = r + (f22 * wxd) * wyd;
+    const bool degenerate = ((long long)(ux - dx) * (long long)(uy - dy)) == 0;
+    return degenerate ? f11 : r;
+}
+
+// The same sample with the four corner pixels taken from a patch of the frame that the wavefront loaded into LDS
+// (patch[py][px] = pixel with the flat index clamp((by + py) * W + (bx + px)), i.e. exactly what fetch_clamped_g returns for
+// that corner); a corner outside the patch -- a wild predictor -- falls back to the global fetch.
+__device__ __forceinline__ float cws_sample_patch(const uint8_t* __restrict__ patch, int PD, int bx, int by,
+                                                  const uint8_t* __restrict__ f, int HW, int W, int gx, int gy, float vx, float vy) {
+#pragma clang fp contract(off)
+    const float nx = (float)gx + vx, ny = (float)gy + vy;
+    const float ux_f = ceilf(nx), dx_f = floorf(nx), uy_f = ceilf(ny), dy_f = floorf(ny);
+    const int ux = f2i_sat_g(ux_f), dx = f2i_sat_g(dx_f), uy = f2i_sat_g(uy_f), dy = f2i_sat_g(dy_f);
+    auto px = [&](int yy, int xx) {
+        const int py = yy - by, pxx = xx - bx;
+        return ((unsigned)py < (unsigned)PD && (unsigned)pxx < (unsigned)PD) ? (float)patch[py * PD + pxx]
+                                                                               : fetch_clamped_g(f, (long long)yy * W + xx, HW);
+    };
+    const float f11 = px(dy, dx), f21 = px(dy, ux), f12 = px(uy, dx), f22 = px(uy, ux);
     const float wxu = ux_f - nx, wxd = nx - dx_f, wyu = uy_f - ny, wyd = ny - dy_f;
     float r = (f11 * wxu) * wyu;
     r = r + (f21 * wxd) * wyu;
@@ -421,7 +446,340 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
     }
 }
 
+
+// =====================================================================================================
+// Second generation for the sizes the reference's own schedule produces with multipass_scale != 2 (42, 28, 48, 24, 96,
+// ...: PIVbackend.py:855-858, int(ws // scale)): the same staging / peak semantics, but
+//   * both complex tiles live in LDS (2 n (n | 1) elements; n <= 96), not in an L2-resident scratch,
+//   * every length-n transform is a two-factor Cooley-Tukey n = n1 n2 (2 <= n1 <= n2 <= 12: a radix-16 butterfly needs 248 registers and would set the kernel's occupancy): per line n2 radix-n1
+//     butterflies, a twiddle w_n^(b k1), then n1 radix-n2 butterflies -- n (n1 + n2) complex multiply-adds per line
+//     instead of n^2 (42 = 6 x 7: 13 instead of 42 per output), each butterfly a fully unrolled direct DFT on REGISTERS
+//     (inputs, outputs and the radix's roots: one LDS read and one LDS write per element and step),
+//   * no integer division per element (float reciprocal, exact for the index range).
+// Float32 only (every mode); even sizes whose factors fit; everything else stays with xcorr_generic_kernel above.
+// =====================================================================================================
+using cff = cplx<float>;
+constexpr int CT_T = 64;     // threads per workgroup of the second-generation kernel: ONE wavefront per window -- its LDS
+                             // exchanges need no workgroup barrier (s_barrier of a one-wave workgroup is free) and its
+                             // reductions are cross-lane moves instead of LDS trees with nine barriers each
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = rmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ AM<float> wave_argmax(AM<float> a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = better_g(a, AM<float>{__shfl_xor(a.v, o, 64), __shfl_xor(a.idx, o, 64)});
+    return a;
+}
+
+__device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((float)i + 0.5f) * rcp); }     // i / n for i < 2^22
+
+// One radix-R step over `count` butterflies.  Butterfly w (t = butterfly inside its line, line): inputs
+// src[line * lsi + t * bsi + j * esi], j < R; outputs dst[line * lso + t * bso + k * eso] = sum_j in[j] w_R^(+-j k), times
+// tw[(t k) % n] when TWIDDLE.  line_fast: consecutive work items walk the lines (unit stride of a column pass) instead of
+// the butterflies of one line.
+template <int R, bool TWIDDLE>
+__device__ __noinline__ void radix_pass(const cff* __restrict__ src, cff* __restrict__ dst, int n, int nlines, int per_line,
+                                           int lsi, int esi, int bsi, int lso, int eso, int bso, bool line_fast, bool inverse,
+                                           const cff* __restrict__ tw) {
+    cff w[R];
+    const int step = n / R;                      // w_R^j = w_n^(j n / R)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        w[j] = tw[j * step];
+        if (inverse) w[j].y = -w[j].y;
+    }
+    const int count = nlines * per_line;
+    const float rcp = 1.0f / (float)(line_fast ? nlines : per_line);
+    for (int item = threadIdx.x; item < count; item += CT_T) {
+        const int hi = div_small(item, rcp);
+        const int lo = item - hi * (line_fast ? nlines : per_line);
+        const int line = line_fast ? lo : hi, t = line_fast ? hi : lo;
+        cff in[R], out[R];
+        const cff* s0 = src + line * lsi + t * bsi;
+#pragma unroll
+        for (int j = 0; j < R; ++j) in[j] = s0[j * esi];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            float re = in[0].x, im = in[0].y;
+#pragma unroll
+            for (int j = 1; j < R; ++j) {
+                const cff ww = w[(j * k) % R];
+                re += in[j].x * ww.x - in[j].y * ww.y;
+                im += in[j].x * ww.y + in[j].y * ww.x;
+            }
+            out[k] = cff{re, im};
+        }
+        cff* d0 = dst + line * lso + t * bso;
+        if constexpr (TWIDDLE) {
+            int idx = 0;                          // (t k) % n, k ascending
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                cff ww = tw[idx];
+                if (inverse) ww.y = -ww.y;
+                d0[k * eso] = cff{out[k].x * ww.x - out[k].y * ww.y, out[k].x * ww.y + out[k].y * ww.x};
+                idx += t;
+                if (idx >= n) idx -= n;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) d0[k * eso] = out[k];
+        }
+    }
+}
+
+// (the butterflies are separate functions, one per radix: a single out-of-line dispatcher would save and restore the
+//  registers of its LARGEST case -- radix 16, 248 VGPRs -- around every call, whatever radix runs)
+template <bool TWIDDLE>
+__device__ __forceinline__ void radix_dispatch(int R, const cff* src, cff* dst, int n, int nlines, int per_line, int lsi, int esi,
+                                            int bsi, int lso, int eso, int bso, bool line_fast, bool inverse, const cff* tw) {
+#define TPIV_RADIX(r)                                                                                                   \
+    case r: radix_pass<r, TWIDDLE>(src, dst, n, nlines, per_line, lsi, esi, bsi, lso, eso, bso, line_fast, inverse, tw); break;
+    switch (R) {
+        TPIV_RADIX(2) TPIV_RADIX(3) TPIV_RADIX(4) TPIV_RADIX(5) TPIV_RADIX(6) TPIV_RADIX(7) TPIV_RADIX(8)
+        default: break;
+    }
+#undef TPIV_RADIX
+}
+
+// the length-n transform of every line of the tile `a` (n lines; element (line, pos) at line * ls + pos * es), in place from
+// the caller's view: step 1 into `tmp` (lines of n, contiguous), step 2 back into `a`.
+__device__ __forceinline__ void axis_transform(cff* a, cff* tmp, int n, int n1, int n2, int ls, int es, bool inverse,
+                                               const cff* tw) {
+    const bool line_fast = ls == 1;
+    // step 1: n2 radix-n1 butterflies per line over a: in[a_] = a[line, n2 a_ + b]; tmp[line, k1 n2 + b] = (...) w_n^(b k1)
+    radix_dispatch<true>(n1, a, tmp, n, n, n2, ls, n2 * es, es, n, n2, 1, line_fast, inverse, tw);
+    __syncthreads();
+    // step 2: n1 radix-n2 butterflies per line over b: in[b] = tmp[line, k1 n2 + b]; a[line, k1 + n1 k2] = out[k2]
+    radix_dispatch<false>(n2, tmp, a, n, n, n1, n, 1, n2, ls, n1 * es, es, false, inverse, tw);
+    __syncthreads();
+}
+
+template <int MODE>
+__global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, int n1, int n2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
+    const int n = p.ws, nn = n * n, P = n | 1;             // tile pitch: odd (rows and columns both conflict-poor)
+    cff* T0 = reinterpret_cast<cff*>(ct_smem);
+    cff* T1 = T0 + n * P;
+    cff* tw = T1 + n * P;                                   // exp(-2 pi i k / n), k < n
+    const int PD = n + 4;                                   // CWS: source patch of a shifted window incl. the interpolation margin
+    uint8_t* patch_a = reinterpret_cast<uint8_t*>(T1);      // (the patches live in the second tile's memory: it is idle until the
+    uint8_t* patch_b = patch_a + PD * PD;                   //  first transform -- more LDS would cost a resident wavefront per CU)
+    const int tid = threadIdx.x;
+    const int N = p.n_rows * p.n_cols;
+    const long long items = (long long)p.batch * N;
+    const int HW = p.H * p.W;
+    const int st = p.ws - p.ov;
+    const float rcp_n = 1.0f / (float)n;
+    for (int k = tid; k < n; k += CT_T) {
+        double s, c;
+        sincospi(2.0 * (double)k / (double)n, &s, &c);
+        tw[k] = cff{(float)c, (float)(-s)};
+    }
+    __syncthreads();
+
+    for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+        const int pair = (int)(item / N), win = (int)(item % N);
+        const int y0 = (win / p.n_cols) * st, x0 = (win % p.n_cols) * st;
+        const uint8_t* __restrict__ fa = p.A + (size_t)pair * HW;
+        const uint8_t* __restrict__ fb = p.B + (size_t)pair * HW;
+        const size_t fidx = (size_t)item;
+        float vx = 0.f, vy = 0.f;
+        long long sh = 0;
+        if constexpr (MODE == MODE_DWS) {
+            double sx, sy;
+            pred_half_shift<MODE_DWS>(p, fidx, sx, sy);
+            sh = (long long)sy * p.W + (long long)sx;
+        }
+        if constexpr (MODE == MODE_CWS) pred_half_shift_cws_f32(p, fidx, vx, vy);
+        if constexpr (MODE == MODE_CWSF) {      // B:644-645
+            vx = (float)(p.u0[fidx] / (double)n);
+            vy = (float)(p.v0[fidx] / (double)n);
+        }
+        // ---- staging (same sampling arithmetic as xcorr_generic_kernel).  CWS: the (n + 4)^2 source pixels of the shifted
+        //      window go into LDS first -- independent byte loads, all in flight together -- and the bilinear samples read
+        //      their corners there (per sample four dependent global byte loads before: 230 of 600 us per pair at 42 x 42)
+        int bxa = 0, bya = 0, bxb = 0, byb = 0;
+        if constexpr (MODE == MODE_CWS) {
+            bxa = x0 + f2i_sat_g(floorf(-vx)) - 1;
+            bya = y0 + f2i_sat_g(floorf(-vy)) - 1;
+            bxb = x0 + f2i_sat_g(floorf(vx)) - 1;
+            byb = y0 + f2i_sat_g(floorf(vy)) - 1;
+            const float rcp_pd = 1.0f / (float)PD;
+#pragma unroll 4
+            for (int i = tid; i < PD * PD; i += CT_T) {
+                const int py = div_small(i, rcp_pd), px = i - py * PD;
+                patch_a[i] = (uint8_t)fetch_clamped_g(fa, (long long)(bya + py) * p.W + (bxa + px), HW);
+                patch_b[i] = (uint8_t)fetch_clamped_g(fb, (long long)(byb + py) * p.W + (bxb + px), HW);
+            }
+            __syncthreads();
+        }
+        float sa = 0, sb = 0;
+#pragma unroll 4
+        for (int i = tid; i < nn; i += CT_T) {
+            const int y = div_small(i, rcp_n), x = i - y * n;
+            float a, b;
+            if constexpr (MODE == MODE_PASS1) {
+                const size_t q = (size_t)(y0 + y) * p.W + x0 + x;
+                a = (float)fa[q];
+                b = (float)fb[q];
+            } else if constexpr (MODE == MODE_DWS) {
+                const long long q = (long long)(y0 + y) * p.W + x0 + x;
+                a = fetch_clamped_g(fa, q - sh, HW);
+                b = fetch_clamped_g(fb, q + sh, HW);
+            } else if constexpr (MODE == MODE_CWS) {
+                a = cws_sample_patch(patch_a, PD, bxa, bya, fa, HW, p.W, x0 + x, y0 + y, -vx, -vy);
+                b = cws_sample_patch(patch_b, PD, bxb, byb, fb, HW, p.W, x0 + x, y0 + y, vx, vy);
+            } else {
+                a = bicubic_local(fa, p.W, y0, x0, n, x, y, -vx, -vy);
+                b = bicubic_local(fb, p.W, y0, x0, n, x, y, vx, vy);
+            }
+            T0[y * P + x] = cff{a, b};
+            sa += a;
+            sb += b;
+            if (p.dbg_win != nullptr) {
+                p.dbg_win[fidx * 2 * nn + i] = a;
+                p.dbg_win[fidx * 2 * nn + nn + i] = b;
+            }
+        }
+        sa = wave_sum(sa);
+        sb = wave_sum(sb);
+        const float ma = sa / (float)nn, mb = sb / (float)nn;
+        bool dead = false;
+        float ka = 1, kb = 1;
+        if constexpr (MODE == MODE_PASS1 || MODE == MODE_CWSF) {      // a / mean(a): B:513-514, B:656-657
+            dead = (sa == 0) || (sb == 0);
+            ka = dead ? 0.f : 1.f / ma;
+            kb = dead ? 0.f : 1.f / mb;
+        }
+        __syncthreads();
+        // mean removal (conditions the float32 transform; corr - min is unchanged by it) and the normalisation
+#pragma unroll 4
+        for (int i = tid; i < nn; i += CT_T) {
+            const int y = div_small(i, rcp_n), x = i - y * n;
+            const cff z = T0[y * P + x];
+            T0[y * P + x] = cff{(z.x - ma) * ka, (z.y - mb) * kb};
+        }
+        __syncthreads();
+        axis_transform(T0, T1, n, n1, n2, P, 1, false, tw);          // rows:    T0[y][kx]
+        axis_transform(T0, T1, n, n1, n2, 1, P, false, tw);          // columns: T0[ky][kx]
+        // ---- cross-spectrum: T1[k] = conj(A) * B / n^2 with A, B split out of Z = FFT2(a + i b)
+        const float scale = 0.25f / (float)nn;
+#pragma unroll 4
+        for (int i = tid; i < nn; i += CT_T) {
+            const int ky = div_small(i, rcp_n), kx = i - ky * n;
+            const cff zk = T0[ky * P + kx];
+            const cff zm = T0[(ky ? n - ky : 0) * P + (kx ? n - kx : 0)];
+            cff pr;
+            pr.x = (zk.x * zm.y + zk.y * zm.x) * (2.0f * scale);
+            pr.y = ((zm.x * zm.x - zk.x * zk.x) + (zm.y * zm.y - zk.y * zk.y)) * scale;
+            T1[ky * P + kx] = pr;
+        }
+        __syncthreads();
+        axis_transform(T1, T0, n, n1, n2, 1, P, true, tw);           // inverse over ky: T1[y][kx]
+        axis_transform(T1, T0, n, n1, n2, P, 1, true, tw);           // inverse over kx: T1[y][x] (the real part is the map)
+        // ---- map in fftshift coordinates (into T0's memory), minimum
+        float* map = reinterpret_cast<float*>(T0);
+        float cmin = 3.4e38f;
+        const int hshift = n / 2;
+#pragma unroll 4
+        for (int i = tid; i < nn; i += CT_T) {
+            const int y = div_small(i, rcp_n), x = i - y * n;
+            const float re = T1[y * P + x].x;
+            int ys = y + hshift, xs = x + hshift;
+            ys -= ys >= n ? n : 0;
+            xs -= xs >= n ? n : 0;
+            map[ys * n + xs] = re;
+            cmin = rmin(cmin, re);
+        }
+        cmin = wave_min(cmin);
+        // ---- corr - min + eps (B:518, B:381), first peak
+        AM<float> best{-1.f, 0};
+#pragma unroll 4
+        for (int i = tid; i < nn; i += CT_T) {
+            const float v = add_eps(map[i], cmin);
+            map[i] = v;
+            if (p.dbg_corr != nullptr) p.dbg_corr[fidx * nn + i] = v;
+            if (v > best.v) {
+                best.v = v;
+                best.idx = i;
+            }
+        }
+        best = wave_argmax(best);
+        __syncthreads();
+        const int m = best.idx;
+        // ---- second peak outside the flat-index neighbourhood (B:346-358)
+        const int wv = p.val_win;
+        AM<float> second{-1.f, nn};
+#pragma unroll 4
+        for (int i = tid; i < nn; i += CT_T) {
+            // i = m + t + n j with |t|, |j| <= wv (2 wv < n: at most one such pair), or one of the two clamps
+            const int d = i - m + wv;                         // = t' + n j with t' = t + wv in [0, 2 wv]
+            const int j = (int)floorf(((float)d + 0.5f) * rcp_n);
+            const int t = d - j * n;                          // 0 <= t < n
+            bool excl = (t <= 2 * wv) & (j >= -wv) & (j <= wv);
+            excl |= (i == 0) & ((m - wv - wv * n) <= 0);
+            excl |= (i == nn - 1) & ((m + wv + wv * n) >= nn - 1);
+            const float v = map[i];
+            if (!excl && v > second.v) {
+                second.v = v;
+                second.idx = i;
+            }
+        }
+        second = wave_argmax(second);
+        __syncthreads();
+        if (tid < 8) {
+            int left = m + 1, right = m - 1, top = m + n, bot = m - n;    // B:385-392
+            if (left >= nn - 1) left = m;
+            if (right <= 0) right = m;
+            if (top >= nn - 1) top = m;
+            if (bot <= 0) bot = m;
+            int q = m;
+            q = (tid == 1) ? left : q;
+            q = (tid == 2) ? right : q;
+            q = (tid == 3) ? top : q;
+            q = (tid == 4) ? bot : q;
+            q = (tid == 5) ? (second.idx < nn ? second.idx : 0) : q;
+            float outv = map[q];
+            if (tid == 5 && second.idx >= nn && MODE == MODE_PASS1) outv = 0;       // (see xcorr_generic_kernel)
+            outv = (tid == 6) ? __int_as_float(m) : outv;
+            outv = (tid == 7) ? __int_as_float(dead ? 1 : 0) : outv;
+            p.peak_raw[fidx * 8 + tid] = outv;
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int CT_MAX_RADIX = 8;
+// n = n1 n2 with 2 <= n1 <= n2 <= CT_MAX_RADIX, n1 as large as possible; false if there is no such split
+bool ct_factors(int n, int& n1, int& n2) {
+    n1 = 0;
+    for (int a = 2; a * a <= n; ++a)
+        if (n % a == 0 && n / a <= CT_MAX_RADIX) n1 = a;
+    if (n1 == 0) return false;
+    n2 = n / n1;
+    return n1 >= 2 && n2 <= CT_MAX_RADIX;
+}
+size_t ct_smem_bytes(int n) { return (size_t)(2 * n * (n | 1) + n) * sizeof(cff); }     // (2 (n + 4)^2 patch bytes fit the second tile, n >= 4)
+bool ct_usable(int n, int precision) {
+    int a, b;
+    return precision == 0 && (n & 1) == 0 && n >= 4 && n <= 96 && ct_factors(n, a, b) && ct_smem_bytes(n) <= 160 * 1024;
+}
+
 }  // namespace
+
+// does (ws, float32) run the second-generation kernel?  (bench / profile labels, piv_launch.hip)
+bool generic_ct_usable(int ws) {
+    static const bool off = [] { const char* e_ = getenv("TPIV_GENERIC_CT"); return e_ && e_[0] == '0'; }();
+    return !off && ct_usable(ws, 0);
+}
 
 int generic_blocks(int ws, long long items, int n_cu, int elem_bytes) {
     // scratch = 2 * ws^2 complex per workgroup; keep it below 256 MiB
@@ -441,6 +799,28 @@ hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, void* s
         hipLaunchKernelGGL((xcorr_generic_kernel<MODE_PASS1, double>), dim3(blocks), dim3(GT), 0, stream, p,
                            static_cast<cplx<double>*>(scratch));
         return hipGetLastError();
+    }
+    static const bool ct_off = [] { const char* e_ = getenv("TPIV_GENERIC_CT"); return e_ && e_[0] == '0'; }();     // A/B runs
+    if (!ct_off && ct_usable(p.ws, 0)) {
+        int n1, n2;
+        ct_factors(p.ws, n1, n2);
+        const size_t smem = ct_smem_bytes(p.ws);
+        const int per_cu = (int)((160 * 1024) / smem) < 12 ? (int)((160 * 1024) / smem) : 12;     // one-wave workgroups, LDS-limited
+        long long blocks = (long long)n_cu * (per_cu < 1 ? 1 : per_cu);
+        if (blocks > items) blocks = items;
+        hipError_t e_ = hipSuccess;
+#define TPIV_CT_LAUNCH(M)                                                                                               \
+    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_generic_ct_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    if (e_ == hipSuccess) hipLaunchKernelGGL((xcorr_generic_ct_kernel<M>), dim3((unsigned)blocks), dim3(CT_T), smem, stream, p, n1, n2);
+        switch (mode) {
+            case MODE_PASS1: TPIV_CT_LAUNCH(MODE_PASS1) break;
+            case MODE_DWS: TPIV_CT_LAUNCH(MODE_DWS) break;
+            case MODE_CWS: TPIV_CT_LAUNCH(MODE_CWS) break;
+            case MODE_CWSF: TPIV_CT_LAUNCH(MODE_CWSF) break;
+            default: return hipErrorInvalidValue;
+        }
+#undef TPIV_CT_LAUNCH
+        return e_ != hipSuccess ? e_ : hipGetLastError();
     }
     const int blocks = generic_blocks(p.ws, items, n_cu, 4);
     cplx<float>* sc = static_cast<cplx<float>*>(scratch);
