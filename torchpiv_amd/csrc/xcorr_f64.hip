@@ -27,6 +27,10 @@
 #include "xcorr_tile.hpp"      // grp_reduce: wavefront reductions in the VALU (DPP / permlane swaps)
 #include "xcorr_f64_split.hpp" // 64 / 128: lines split over two threads, 32- / 64-point in-register codelets
 
+#ifndef TPIV_F64_WIDE64
+#define TPIV_F64_WIDE64 1      // 64x64: the parity branch spans the column stages through the T2 write (A/B: 0 = only the cross-spectrum)
+#endif
+
 namespace tpiv {
 
 namespace {
@@ -190,8 +194,26 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
             lds_barrier();                               // every thread has read its T1 column
             S::t2_write(t, TPIV_F64_TID() & (W - 1), G, plane);
         };
-        if (g) column_stages(std::integral_constant<int, 1>{});
-        else column_stages(std::integral_constant<int, 0>{});
+        if constexpr (W == 64 && TPIV_F64_WIDE64) {
+            if (g) column_stages(std::integral_constant<int, 1>{});
+            else column_stages(std::integral_constant<int, 0>{});
+        } else {
+            // 128x128 (one wavefront per SIMD, 512 registers): the branch only around the cross-spectrum, transforms shared
+            S::cols_forward(u, g);
+            {
+                const bool own = (TPIV_F64_TID() & (W - 1)) < 2;
+                auto sh = [&](double v, int, int) TPIV_LAMBDA_INLINE {
+                    const double r = f64s::dpp_xor1(v);
+                    return own ? v : r;
+                };
+                if (g) S::template cross_spectrum_g<1>(u, u, sh);
+                else S::template cross_spectrum_g<0>(u, u, sh);
+            }
+            cd t[M];
+            S::cols_inverse(u, g, t);
+            lds_barrier();
+            S::t2_write(t, TPIV_F64_TID() & (W - 1), g, plane);
+        }
         cd Y[M + 1];
         lds_barrier();
         S::t2_read(Y, TPIV_F64_TID() & (W - 1), plane);
