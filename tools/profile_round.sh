@@ -10,13 +10,19 @@
 #   other_configs/              configs[3] / configs[4] at both precisions: quick_bench lines, kernel stats, SQ counters
 #   stamps_f64.txt              per-phase cycle shares of the float64 pass-1 kernel (stamped diagnostic build)
 #   files_profile.txt           where the file path spends its time
+#   bench_e2e_gloo2.json        the GENERATOR path sharded over 2 gloo ranks on the one GPU (bench.py --gpus 2 --e2e): launch,
+#                               per-rank host budget and the end-of-run gather from device-resident fields -- a rehearsal
+#   generic_chain.txt           64/32 -> 42/21 -> 28/14 (multipass_scale 1.5) with the first- and second-generation generic kernel
+# PART=a: the bench lines and the kernel statistics; PART=b: other configs, stamps, file path, rehearsals (two gpurun calls)
 # Outputs: gpurun_out/$1/ ; tools/collect_profile.py copies what is to be judged into profiles/<round>/.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT/other_configs
 export TMPDIR=/tmp
 R="--kernel-include-regex xcorr|predict|finalize|postval"
+PART=${2:-ab}
+if [[ $PART == *a* ]]; then
 python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err || { tail $OUT/bench_n1.err; exit 1; }
 python3 bench.py --precision reference --no-cpu-baseline --no-fast --no-e2e > $OUT/bench_n1_reference.json 2> $OUT/bench_ref.err || exit 1
 python3 bench.py --config 2 --no-cpu-baseline --no-e2e > $OUT/bench_n1_config2.json 2> $OUT/bench_c2.err || exit 1
@@ -27,6 +33,8 @@ TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 4 --steps 10 --warmup 2 --batch 3
 python3 bench.py --steps 2000 --warmup 5 --pmc off --no-cpu-baseline --no-e2e --no-fast > $OUT/bench_soak2000.json 2> $OUT/soak.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv $R -d $OUT/stats -- python3 bench.py --steps 50 --warmup 5 --pmc off --no-cpu-baseline --no-e2e > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 cp $OUT/stats/*/*_kernel_stats.csv $OUT/rocprofv3_kernel_stats.csv && rm -rf $OUT/stats
+fi
+if [[ $PART == *b* ]]; then
 cfg() {   # name, quick_bench args
     local name=$1; shift
     python3 tools/quick_bench.py "$@" 2>&1 | grep -E "pairs/s|us/pair:" > $OUT/other_configs/$name.txt
@@ -42,6 +50,10 @@ cfg cfg4_128_64_fast --size 2048 --ws 128 --passes 2 --mode CWS --batch 64
 cfg cfg4_128_64_f64 --size 2048 --ws 128 --passes 2 --mode CWS --batch 64 --precision f64
 TPIV_LIB=tools/diag/libtorchpiv_hip_stamps.so python3 tools/stamp_f64.py > $OUT/stamps_f64.txt 2> $OUT/stamps.err || tail -3 $OUT/stamps.err
 python3 tools/dev/files_profile.py 8 8 8 spots 2 32 2> /dev/null | grep -v amdgpu.ids > $OUT/files_profile.txt
+TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --e2e --e2e-pairs 64 > $OUT/bench_e2e_gloo2.json 2> $OUT/e2e_g2.err || tail -3 $OUT/e2e_g2.err
+python3 bench.py --e2e --e2e-pairs 128 > $OUT/bench_e2e_n1.json 2> $OUT/e2e_n1.err || tail -3 $OUT/e2e_n1.err
+{ TPIV_GENERIC_CT=0 python3 tools/dev/generic_chain.py 16 1.5 CWS; python3 tools/dev/generic_chain.py 16 1.5 CWS; python3 tools/dev/generic_chain.py 16 1.5 DWS; } 2> /dev/null | grep -v amdgpu.ids > $OUT/generic_chain.txt
+fi
 python3 - $OUT <<'PY'
 import json, sys, glob, os
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):
