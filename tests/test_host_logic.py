@@ -506,3 +506,45 @@ def test_qhull_diamond_choice_is_not_a_local_rule():
         assert min(abs(val - ns), abs(val - ew)) < 1e-15
         seen["NS" if abs(val - ns) < abs(val - ew) else "EW"] = far
     assert set(seen) == {"NS", "EW"}, seen
+
+
+def test_hand_issued_lds_reads_are_not_touched_before_their_wait():
+    """The float64 kernels issue ds_read_b64 / ds_read_b128 through inline asm and wait with a separate counted
+    s_waitcnt (xcorr_f64_split.hpp): the compiler must not read, copy or spill a destination register in between -- it
+    cannot know the value has not landed.  tools/check_lds_inflight.py walks the device assembly of the
+    build; first on two crafted snippets (the checker must see a violation and pass a clean sequence), then on the real
+    translation unit."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_lds_inflight as C
+    bad = """
+_ZkernelA:
+	;;#ASMSTART
+	ds_read_b128 v[4:7], v1 offset:16
+	;;#ASMEND
+	scratch_store_dwordx2 off, v[6:7], off offset:8
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	;;#ASMEND
+	s_endpgm
+"""
+    good = """
+_ZkernelB:
+	;;#ASMSTART
+	ds_read_b128 v[4:7], v1 offset:16
+	;;#ASMEND
+	;;#ASMSTART
+	ds_read_b64 v[8:9], v1 offset:32
+	;;#ASMEND
+	v_add_f64 v[20:21], v[10:11], v[12:13]
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(1)
+	;;#ASMEND
+	v_add_f64 v[20:21], v[4:5], v[6:7]
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	;;#ASMEND
+	v_add_f64 v[20:21], v[8:9], v[6:7]
+	s_endpgm
+"""
+    assert len(C.check(bad)[0]) == 1 and C.check(good) == ([], 2)
+    assert C.main("xcorr_f64") == 0
