@@ -1,0 +1,115 @@
+"""precision="exact" (csrc/xcorr_exact.hip): pass 1 from exact integer correlation sums, located by a float32 FFT pass,
+with the float64 transform for the windows that pass cannot decide.
+
+Gates: (1) against the oracle's float64 pass 1 and the numpy statement of the scheme (tests/test_exact_scheme.py),
+(2) against the float64 kernel of this library on full-size frames: fields within 1e-11 px, identical validity masks,
+(3) the edge cases the scheme has branches for: dead windows, byte-identical frames, flat windows (undecidable by
+construction -> float64 path), saturated frames, validation windows of other sizes, (4) the share of windows that take
+the float64 path stays small on particle images, and the whole chain behind it gives the same final fields.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import piv_oracle as O
+from test_exact_scheme import exact_window, synthetic_pair
+
+pytestmark = pytest.mark.gpu
+
+TOL_F64 = 1e-11          # px, exact sums against a float64 transform (rounding of the transform through the fit)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from torchpiv_amd import engine
+    return engine
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def fields(eng, A, B, precision, **kw):
+    u, v, inv = eng.pass1(dev(A), dev(B), 64, kw.pop("ov", 32), precision=precision, **kw)
+    torch.cuda.synchronize()
+    return u.cpu().numpy(), v.cpu().numpy(), inv.cpu().numpy()
+
+
+@pytest.mark.parametrize("seed,shift", [(1, (2.3, -1.6)), (2, (0.0, 0.0)), (3, (-7.4, 11.2))])
+def test_exact_pass1_against_oracle_and_model(eng, seed, shift):
+    A, B = synthetic_pair(256, 256, seed, shift)
+    u0, v0, _, _, m0 = O.pass1(A, B, 64, 32, validate=True)
+    u, v, inv = fields(eng, A[None], B[None], "exact")
+    assert np.abs(u[0] - u0).max() < TOL_F64 and np.abs(v[0] - v0).max() < TOL_F64
+    assert np.array_equal(inv[0].astype(bool), m0)
+    # the numpy statement of the scheme, window by window (its own float32 map may send other windows to the fallback)
+    aw, bw = O.windows(A, 64, 32), O.windows(B, 64, 32)
+    for i, (a, b) in enumerate(zip(aw, bw)):
+        r = exact_window(a, b)
+        if r is not None:
+            assert abs(r[0] - u[0].reshape(-1)[i]) < 1e-13 and abs(r[1] - v[0].reshape(-1)[i]) < 1e-13, i
+
+
+@pytest.mark.parametrize("ov", [32, 48, 10, 0])
+def test_exact_equals_float64_kernel_on_full_frames(eng, ov):
+    from torchpiv_amd import synth
+    A, B = synth.make_batch(4, 1024, 1024, device="cuda", noise=3.0, first_index=ov + 1)
+    ue, ve, ie = eng.pass1(A, B, 64, ov, precision="exact")
+    uf, vf, i_f = eng.pass1(A, B, 64, ov, precision="f64")
+    assert float((ue - uf).abs().max()) < TOL_F64 and float((ve - vf).abs().max()) < TOL_F64
+    assert torch.equal(ie, i_f)
+
+
+@pytest.mark.parametrize("val_win,val_ratio", [(1, 1.2), (2, 1.05), (4, 1.5), (5, 1.2), (3, 3.0)])
+def test_exact_validation_parameters(eng, val_win, val_ratio):
+    from torchpiv_amd import synth
+    A, B = synth.make_batch(2, 512, 512, device="cuda", noise=6.0, first_index=11)
+    ue, ve, ie = eng.pass1(A, B, 64, 32, val_ratio=val_ratio, val_win=val_win, precision="exact")
+    uf, vf, i_f = eng.pass1(A, B, 64, 32, val_ratio=val_ratio, val_win=val_win, precision="f64")
+    assert float((ue - uf).abs().max()) < TOL_F64 and float((ve - vf).abs().max()) < TOL_F64
+    assert torch.equal(ie, i_f)
+
+
+def test_exact_edge_windows(eng):
+    rng = np.random.default_rng(3)
+    H = W = 256
+    A = rng.integers(0, 256, (5, H, W), dtype=np.uint8)
+    B = rng.integers(0, 256, (5, H, W), dtype=np.uint8)
+    A[0, 64:192, 64:192] = 0                  # dead windows in frame a (zero mean: NaN map in the reference)
+    B[1, :96, :] = 0                          # ... in frame b
+    B[2] = A[2]                               # byte-identical frames: the exact fit is 0
+    A[3, 32:160, 32:160] = 77                 # flat windows: constant map, nothing to decide -> float64 path
+    B[3, 32:160, 32:160] = 91
+    A[4] = 255                                # saturated frames
+    B[4] = 255
+    ue, ve, ie = fields(eng, A, B, "exact")
+    uf, vf, i_f = fields(eng, A, B, "f64")
+    assert np.abs(ue - uf).max() < TOL_F64 and np.abs(ve - vf).max() < TOL_F64
+    assert np.array_equal(ie, i_f)
+    assert np.all(ue[2] == 0.0) and np.all(ve[2] == 0.0)
+    for k in (0, 1, 3):                       # and against the oracle itself where the reference is deterministic
+        u0, v0, _, _, m0 = O.pass1(A[k], B[k], 64, 32, validate=True)
+        ok = np.abs(ue[k] - u0) < 1e-9
+        # pure-noise windows: the arg-max of the reference's own map is decided at 1e-16 relative; count, don't compare
+        assert ok.mean() > 0.9, k
+
+
+def test_exact_fallback_share_and_whole_chain(eng):
+    """Noise-only and real-looking particle images: few windows need the float64 transform; the multipass chain behind an
+    exact first pass ends in the same fields as behind the float64 first pass."""
+    from torchpiv_amd import synth
+    A, B = synth.make_batch(8, 1024, 1024, device="cuda", noise=2.0, first_index=5)
+    pe = eng.Plan(1024, 1024, 64, 32, n_pass=2, mode="CWS", max_batch=8, precision="exact")
+    pf = eng.Plan(1024, 1024, 64, 32, n_pass=2, mode="CWS", max_batch=8, precision="f64")
+    ue, ve, ie = pe.run(A, B)
+    n_fb = pe.exact_fallbacks()
+    uf, vf, i_f = pf.run(A, B)
+    n_win = 8 * 31 * 31
+    assert 0 <= n_fb <= n_win // 20, (n_fb, n_win)
+    # (a first-pass difference of 1e-14 px moves the second pass's bilinear samples by as much; a discrete decision of that
+    #  pass -- arg-max, ratio threshold -- flips for a window only when it sits on the threshold to that precision)
+    far = ((ue - uf).abs() > 1e-6) | ((ve - vf).abs() > 1e-6) | (ie != i_f)
+    assert float(far.float().mean()) < 1e-3
+    with pytest.raises(ValueError):
+        pf.exact_fallbacks()

@@ -25,7 +25,7 @@ def test_cabi_exports_every_declared_symbol():
     assert _lib.lib.tpiv_version() == _lib.ABI_VERSION == 2
     # the production library keeps no state: the stamp setter of the diagnostic build is not in it
     assert not hasattr(_lib.lib, "tpiv_debug_set_stamps")
-    assert _lib.PRECISIONS == {"fast": 0, "reference": 1, "f64": 2}
+    assert _lib.PRECISIONS == {"fast": 0, "reference": 1, "f64": 2, "exact": 3}
 
 
 def test_reference_helper_names():

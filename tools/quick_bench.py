@@ -14,7 +14,7 @@ ap.add_argument("--distinct", type=int, default=2)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--kind", default="wavy")
 ap.add_argument("--width", type=int, default=0, help="frame width when it differs from --size (row-pitch experiments)")
-ap.add_argument("--precision", default="fast", choices=("fast", "f64", "reference"))
+ap.add_argument("--precision", default="fast", choices=("fast", "f64", "reference", "exact"))
 a = ap.parse_args()
 H = a.size
 W = a.width or a.size

@@ -16,8 +16,8 @@ OK, EINVAL, EKEY, EHIP, ENOMEM, EUNSUPPORTED = 0, 1, 2, 3, 4, 5
 MODE_DWS, MODE_CWS, MODE_CWS_FAST = 1, 2, 3
 MODES = {"DWS": MODE_DWS, "CWS": MODE_CWS}           # the multipass modes of OfflinePIV (IterModMap, B:814-818)
 ITER_MODES = dict(MODES, CWS_Fast=MODE_CWS_FAST)     # + piv_iteration_CWS_Fast (function-level seam only)
-PREC_FAST, PREC_REFERENCE, PREC_F64 = 0, 1, 2
-PRECISIONS = {"fast": PREC_FAST, "reference": PREC_REFERENCE, "f64": PREC_F64}
+PREC_FAST, PREC_REFERENCE, PREC_F64, PREC_EXACT = 0, 1, 2, 3
+PRECISIONS = {"fast": PREC_FAST, "reference": PREC_REFERENCE, "f64": PREC_F64, "exact": PREC_EXACT}
 ABI_VERSION = 2
 
 
@@ -60,6 +60,7 @@ SIGNATURES = {
     "tpiv_plan_create": (C.c_int, [C.POINTER(C.c_void_p), _int, _int, _int, _int, _int, _int, _dbl, _dbl,
                                    _int, _int, _int]),
     "tpiv_plan_kernel_name": (C.c_char_p, [C.c_void_p, _int, C.c_char_p, _int]),
+    "tpiv_plan_exact_fallbacks": (_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     "tpiv_plan_destroy": (None, [C.c_void_p]),
     "tpiv_plan_n_pass": (C.c_int, [C.c_void_p]),
     "tpiv_plan_pass_geometry": (C.c_int, [C.c_void_p, _int, C.POINTER(C.c_int), C.POINTER(C.c_int),

@@ -205,7 +205,7 @@ int spline_matrix(int nc, const double* xc, int nf, const double* xf, double* A)
     return TPIV_OK;
 }
 
-bool valid_precision(int p) { return p == TPIV_PREC_FAST || p == TPIV_PREC_REFERENCE || p == TPIV_PREC_F64; }
+bool valid_precision(int p) { return p == TPIV_PREC_FAST || p == TPIV_PREC_REFERENCE || p == TPIV_PREC_F64 || p == TPIV_PREC_EXACT; }
 
 struct PassGeo {
     int ws, ov, n_rows, n_cols;
@@ -230,6 +230,9 @@ struct tpiv_plan {
     uint8_t* pmask = nullptr;                               // ... and the thresholded mask (PassParams::pmask)
     float* peak_raw = nullptr;           // [max_batch, max N_p, 8] hand-off tile kernel -> finalize
     size_t peak_raw_bytes = 0;
+    int last_batch = 0;                  // batch of the last tpiv_plan_run (tpiv_plan_exact_fallbacks)
+    unsigned* exact_count = nullptr;     // TPIV_PREC_EXACT: the float64-list length of the last run's first pass (copied out
+                                         // of peak_raw, which the later passes reuse)
     std::vector<void*> allocs;
     // optional per-kernel timing: events[run][2*slot + {0,1}]
     bool timing = false;
@@ -375,7 +378,7 @@ static int pass1_impl(const uint8_t* a, const uint8_t* b, int batch, int H, int 
                       void* work, size_t work_bytes, float* dbg_win, float* dbg_corr, void* stream) {
     int rc = check_window(H, W, ws, ov, val_win);
     if (rc) return rc;
-    if (!valid_precision(precision)) return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST, TPIV_PREC_REFERENCE or TPIV_PREC_F64");
+    if (!valid_precision(precision)) return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST, TPIV_PREC_REFERENCE, TPIV_PREC_F64 or TPIV_PREC_EXACT");
     if (batch <= 0) return TPIV_OK;
     tpiv::PassParams p{};
     p.dbg_win = dbg_win;
@@ -416,9 +419,10 @@ size_t tpiv_work_bytes(int H, int W, int ws, int ov, int batch) {
     if (ov >= ws || ws > H || ws > W || ws <= 0 || ov < 0 || batch <= 0 || !supported_ws(ws)) return 0;
     int nr, nc;
     field_shape(H, W, ws, ov, &nr, &nc);
-    const size_t a = tpiv::peak_raw_bytes(ws, batch, nr * nc, TPIV_PREC_REFERENCE);      // the larger of the two precisions
+    const size_t a = tpiv::peak_raw_bytes(ws, batch, nr * nc, TPIV_PREC_EXACT);          // the largest of the precisions
+    const size_t a1 = tpiv::peak_raw_bytes(ws, batch, nr * nc, TPIV_PREC_REFERENCE);
     const size_t b = tpiv::peak_raw_bytes(ws, batch, nr * nc, TPIV_PREC_FAST, true);     // TPIV_MODE_CWS_FAST: generic kernel
-    return a > b ? a : b;
+    return std::max(a, std::max(a1, b));
 }
 
 int tpiv_predict(int mode, int batch, int nrc, int ncc, int nrf, int ncf, const double* Ay,
@@ -459,7 +463,7 @@ static int run_iter(int mode, int precision, const uint8_t* a, const uint8_t* b,
     if (mode == TPIV_MODE_CWS_FAST && ws < 2) return fail(TPIV_EINVAL, "window too small");
     if (mode != TPIV_MODE_CWS_FAST && !pmask && (!u2 || !v2)) return fail(TPIV_EINVAL, "tpiv_iter: u2 / v2 missing");
     if (!u0 || !v0) return fail(TPIV_EINVAL, "tpiv_iter: u0 / v0 missing");
-    if (!valid_precision(precision)) return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST, TPIV_PREC_REFERENCE or TPIV_PREC_F64");
+    if (!valid_precision(precision)) return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST, TPIV_PREC_REFERENCE, TPIV_PREC_F64 or TPIV_PREC_EXACT");
     if (batch <= 0) return TPIV_OK;
     tpiv::PassParams p{};
     p.A = a;
@@ -547,7 +551,7 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
         return fail(TPIV_EKEY, "unknown multipass mode");
     if (max_batch < 1) return fail(TPIV_EINVAL, "max_batch must be >= 1");
     if (!(pass_scale > 0)) return fail(TPIV_EINVAL, "multipass_scale must be positive");
-    if (!valid_precision(precision)) return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST, TPIV_PREC_REFERENCE or TPIV_PREC_F64");
+    if (!valid_precision(precision)) return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST, TPIV_PREC_REFERENCE, TPIV_PREC_F64 or TPIV_PREC_EXACT");
     tpiv_plan* pl = new tpiv_plan();
     pl->precision = precision;
     pl->H = H;
@@ -632,6 +636,7 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
         }
         pl->peak_raw_bytes = raw;
         if (raw) rc = pl->alloc(&pl->peak_raw, raw / sizeof(float) + 64);
+        if (rc == TPIV_OK && precision == TPIV_PREC_EXACT && pl->geo[0].ws == 64) rc = pl->alloc(&pl->exact_count, 4);
     }
     if (rc == TPIV_OK && n_pass > 1) {
         rc = pl->alloc(&pl->u0, max_fine * max_batch);
@@ -669,6 +674,18 @@ const char* tpiv_plan_kernel_name(const tpiv_plan* plan, int pass, char* buf, in
     if (!plan || pass < 0 || pass >= plan->n_pass) return buf;
     const int mode = pass == 0 ? (int)tpiv::MODE_PASS1 : plan->mode;
     return tpiv::xcorr_kernel_name(plan->geo[pass].ws, mode, plan->precision, buf, len);
+}
+
+int tpiv_plan_exact_fallbacks(tpiv_plan* plan, long long* n_windows) {
+    if (!plan || !n_windows) return fail(TPIV_EINVAL, "null argument");
+    if (plan->precision != TPIV_PREC_EXACT || plan->geo[0].ws != 64)
+        return fail(TPIV_EINVAL, "not a TPIV_PREC_EXACT plan with 64x64 first-pass windows");
+    if (plan->last_batch <= 0) return fail(TPIV_EINVAL, "the plan has not run yet");
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned n = 0;
+    HIP_TRY(hipMemcpy(&n, plan->exact_count, sizeof(n), hipMemcpyDeviceToHost));
+    *n_windows = (long long)n;
+    return TPIV_OK;
 }
 
 int tpiv_plan_pass_fields(const tpiv_plan* plan, int pass, double** u, double** v, uint8_t** invalid) {
@@ -729,6 +746,7 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
     HIP_TRY(hipGetDevice(&dev));
     if (dev != plan->device) return fail(TPIV_EINVAL, "plan was created on another device");
     const int last = plan->n_pass - 1;
+    plan->last_batch = batch;
     hipStream_t st = (hipStream_t)stream;
     auto mark = [&](int slot, int end) {
         hipEvent_t e = plan->ev(slot, end);
@@ -746,6 +764,11 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
                             plan->precision, pu, pv, pval, plan->peak_raw, plan->peak_raw_bytes, nullptr, nullptr,
                             stream);
             mark(0, 1);
+            if (!rc && plan->exact_count) {
+                const size_t off = tpiv::exact_fallback_count_offset(batch, g.n_rows * g.n_cols);
+                HIP_TRY(hipMemcpyAsync(plan->exact_count, reinterpret_cast<const char*>(plan->peak_raw) + off,
+                                       sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+            }
         } else {
             const PassGeo& c = plan->geo[p - 1];
             mark(2 * p - 1, 0);

@@ -33,7 +33,7 @@ struct PassParams {
     double* dv;
     double val_ratio;
     int val_win;
-    int precision;         // pass 1 only: 0 = float32 kernels, 1 = float64 (TPIV_PREC_REFERENCE)
+    int precision;         // pass 1 only: 0 = float32 kernels, 1 = float64 (TPIV_PREC_REFERENCE), 3 = exact sums (64x64)
     // test hooks (nullptr in production)
     float* dbg_win;        // [batch, N, 2, ws, ws] staged windows (after the shift)
     float* dbg_corr;       // [batch, N, ws, ws] corr - min + eps, fftshift layout
@@ -43,6 +43,12 @@ struct PassParams {
     // (float64 pass 1: 8 doubles per window, m and dead stored as values)
     float* peak_raw;
     unsigned* work_ctr;      // 8 x 16 dwords: per-XCD item counters of the tile kernel (set by launch_xcorr)
+    // precision "exact" (64x64 pass 1, xcorr_exact.hip; all set by launch_xcorr): the float32 kernel's candidate cells
+    // per window (8 x int16: arg-max, 3 second-peak cells, 4 minimum cells; -1 = none, arg-max -1 = undecided, -2 = dead),
+    // and the windows that go to the float64 kernel instead (undecided ones)
+    uint4* cand;
+    int* fb_list;
+    unsigned* fb_count;
     // n / d for n < 2^31 as (n * magic) >> shift (set by the tile launcher; keeps the per-item index
     // arithmetic in the scalar unit instead of a hoisted float reciprocal that occupies a VGPR)
     unsigned groups_magic, ncols_magic;
@@ -169,6 +175,8 @@ __device__ __forceinline__ void pred_fallback(const PassParams& p, size_t i, dou
 const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len);
 // bytes of PassParams::peak_raw a pass needs (records, work-queue counters, generic-size DFT scratch)
 size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool force_generic = false);
+// precision "exact": byte offset of the float64-list counter (one unsigned) inside PassParams::peak_raw
+size_t exact_fallback_count_offset(int batch, int n_windows);
 // test hook: peak stage + finalize on caller-made maps; planar selects the LDS layout variant of the tile kernel
 hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream);
 hipError_t launch_predict_mfma(const BandedPredictParams& q, hipStream_t stream);

@@ -25,6 +25,10 @@ hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, void* s
 int generic_blocks(int ws, long long items, int n_cu, int elem_bytes);
 bool generic_ct_usable(int ws);
 hipError_t launch_xcorr_f64(const PassParams& p, int n_cu, hipStream_t stream);      // xcorr_f64.hip: 8..64, pass 1
+// precision "exact" (64x64 pass 1): float32 candidate pass, exact integer refinement, float64 pass for the undecided windows
+hipError_t launch_xcorr_cand_ws64(const PassParams& p, int n_cu, hipStream_t stream);       // xcorr_tile.hpp
+hipError_t launch_exact_refine(const PassParams& p, hipStream_t stream);                    // xcorr_exact.hip
+hipError_t launch_xcorr_f64_list(const PassParams& p, int n_cu, hipStream_t stream);        // xcorr_f64.hip
 
 // ---- finalize: sub-pixel fit, validation and multipass combine, one thread per window -----------
 // PIVbackend.py:385-422 (correlation_to_displacement) and B:728-738 / B:800-810 (combine).  Input:
@@ -169,7 +173,28 @@ hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_
 static constexpr size_t WORK_CTR_BYTES = 8 * 16 * sizeof(unsigned);
 static size_t work_ctr_offset(int batch, int n_windows) { return (peak_bytes(batch, n_windows) + 127) / 128 * 128; }
 
+// precision "exact": float64 records | candidate cells (16 B per window) | float64 list | its counter | tile work counters
+struct ExactLayout {
+    size_t cand, list, count, ctr, total;
+};
+static ExactLayout exact_layout(int batch, int n_windows) {
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    ExactLayout l;
+    l.cand = peak_bytes(batch, n_windows, 1);
+    l.list = l.cand + up((size_t)batch * n_windows * sizeof(uint4));
+    l.count = l.list + up((size_t)batch * n_windows * sizeof(int));
+    l.ctr = l.count + 256;
+    l.total = l.ctr + WORK_CTR_BYTES;
+    return l;
+}
+static bool exact_size(int ws) { return ws == 64; }
+size_t exact_fallback_count_offset(int batch, int n_windows) { return exact_layout(batch, n_windows).count; }
+
 size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool force_generic) {
+    if (precision == 3) {
+        if (exact_size(ws) && !force_generic) return exact_layout(batch, n_windows).total;
+        precision = 1;                                                              // other sizes: the float64 kernels
+    }
     if (tile_size(ws) && !force_generic) {
         if (precision) return peak_bytes(batch, n_windows, 1);                      // float64 records only
         return work_ctr_offset(batch, n_windows) + WORK_CTR_BYTES;                  // records + item counters
@@ -183,14 +208,18 @@ size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool forc
 // (in the demangled form rocprofv3 prints, so that profile rows can be matched by substring; the MODE
 //  template argument is the tpiv::MODE_* value: 0 pass 1, 1 DWS, 2 CWS)
 // TPIV_PREC_F64 (2): float64 pass 1, fast operation order in the shifted passes
-static int pass_precision(int precision, int mode) {
+// TPIV_PREC_EXACT (3): exact integer sums in pass 1 (64x64; float64 kernels for the other sizes), shifted passes as (2)
+static int pass_precision(int precision, int mode, int ws) {
     if (precision == 2) return mode == MODE_PASS1 ? 1 : 0;
+    if (precision == 3) return mode == MODE_PASS1 ? (exact_size(ws) ? 3 : 1) : 0;
     return precision;
 }
 
 const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len) {
-    precision = pass_precision(precision, mode);
-    if (precision && mode == MODE_PASS1) {
+    precision = pass_precision(precision, mode, ws);
+    if (precision == 3 && mode == MODE_PASS1) {
+        snprintf(buf, len, "xcorr_tile_cand_kernel<%d>", ws);
+    } else if (precision && mode == MODE_PASS1) {
         if (ws == 64 || ws == 128) snprintf(buf, len, "xcorr_f64_split_kernel<%d>", ws);
         else if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_tile_kernel<%d>", ws);
         else snprintf(buf, len, "xcorr_generic_kernel<0, double>");
@@ -211,7 +240,7 @@ const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int le
 hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t stream) {
     hipError_t e;
     PassParams p = p_in;
-    p.precision = pass_precision(p.precision, mode);
+    p.precision = pass_precision(p.precision, mode, p.ws);
     // float64 exists for pass 1 only (the reference's later passes are float32, B:249-257); for shifted
     // passes precision != 0 selects the tile kernel's reference-order arithmetic (xcorr_tile.hpp)
     const bool f64 = p.precision != 0 && mode == MODE_PASS1;
@@ -224,6 +253,20 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
     };
     if (mode == MODE_CWSF) {
         e = generic();
+    } else if (p.precision == 3) {
+        const ExactLayout l = exact_layout(p.batch, p.n_rows * p.n_cols);
+        char* const base = reinterpret_cast<char*>(p.peak_raw);
+        p.cand = reinterpret_cast<uint4*>(base + l.cand);
+        p.fb_list = reinterpret_cast<int*>(base + l.list);
+        p.fb_count = reinterpret_cast<unsigned*>(base + l.count);
+        p.work_ctr = reinterpret_cast<unsigned*>(base + l.ctr);
+        e = hipMemsetAsync(p.fb_count, 0, 256 + WORK_CTR_BYTES, stream);
+        if (e != hipSuccess) return e;
+        e = launch_xcorr_cand_ws64(p, n_cu, stream);
+        if (e != hipSuccess) return e;
+        e = launch_exact_refine(p, stream);
+        if (e != hipSuccess) return e;
+        e = launch_xcorr_f64_list(p, n_cu, stream);
     } else if (f64) {
         // (TPIV_F64_GENERIC128=1: the generic-size DFT kernel for 128x128, as before the split kernel existed -- A/B runs)
         static const bool gen128 = [] {

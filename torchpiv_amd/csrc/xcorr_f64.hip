@@ -57,8 +57,9 @@ struct __attribute__((aligned(16))) F64SplitShared {
 //          one workgroup per CU and one wavefront per SIMD with up to 512 registers (64-point codelets hold 256).
 // Seven workgroup barriers per window: T1 three (real plane written / read / imaginary plane written), T2 two (plane free /
 // written), peak analysis two.
-template <int W>
-__global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel(PassParams p) {
+// LIST: the windows are those of PassParams::fb_list (precision "exact": the ones its float32 pass left undecided)
+template <int W, bool LIST>
+__device__ __forceinline__ void xcorr_f64_split_body(const PassParams& p) {
     using S = f64s::Split<W>;
     using f64s::dmax2;
     using f64s::dmin2;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
     const int g = 1 - half;                      // parity of the column bins this thread owns
 
     const int N = p.n_rows * p.n_cols;
-    const long long items = (long long)p.batch * N;
+    const long long items = LIST ? (long long)*p.fb_count : (long long)p.batch * N;
     const int st = p.ws - p.ov;
     const int HW = p.H * p.W;
     const int wv = p.val_win;
@@ -103,7 +104,9 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
     // both threads of a line load the whole image row; the next window's rows are fetched while the peak analysis of
     // the current one runs
     uint32_t da[NDW], db[NDW];
-    auto fetch = [&](long long it) TPIV_LAMBDA_INLINE {
+    auto window_of = [&](long long it) TPIV_LAMBDA_INLINE { return LIST ? (long long)p.fb_list[it] : it; };
+    auto fetch = [&](long long it_) TPIV_LAMBDA_INLINE {
+        const long long it = window_of(it_);
         const int pair_ = (int)(it / N), win_ = (int)(it % N);
         const int yy0 = (win_ / p.n_cols) * st, xx0 = (win_ % p.n_cols) * st;
         const int t_ = W == 64 ? tid : TPIV_F64_TID();
@@ -339,13 +342,22 @@ __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel
         {
             const int t_ = W == 64 ? tid : TPIV_F64_TID();
             if (t_ < 8)
-                reinterpret_cast<double*>(p.peak_raw)[(size_t)item * 8 + t_] =
+                reinterpret_cast<double*>(p.peak_raw)[(size_t)window_of(item) * 8 + t_] =
                     S::peak_record_slot(t_, m, sv, dead, zone, zlo, cmin, map_scale);
         }
         TPIV_STAMP(7);      // peak analysis incl. the issue of the next window's loads
 #undef TPIV_F64_TID
     }
     TPIV_STAMP_FLUSH(p);
+}
+
+template <int W>
+__global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel(PassParams p) {
+    xcorr_f64_split_body<W, false>(p);
+}
+template <int W>
+__global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_list_kernel(PassParams p) {
+    xcorr_f64_split_body<W, true>(p);
 }
 
 template <int W>
@@ -677,6 +689,17 @@ static hipError_t launch_f64_tile(const PassParams& p, int n_cu, hipStream_t str
 }
 
 }  // namespace
+
+// the 64x64 float64 transform for the windows of PassParams::fb_list (their number is known on the device only: the grid
+// is the resident set, workgroups without a window leave at once)
+hipError_t launch_xcorr_f64_list(const PassParams& p, int n_cu, hipStream_t stream) {
+    if (p.ws != 64 || p.fb_list == nullptr || p.fb_count == nullptr) return hipErrorInvalidValue;
+    const long long items = (long long)p.batch * p.n_rows * p.n_cols;
+    long long blocks = items < (long long)n_cu * 4 ? items : (long long)n_cu * 4;
+    blocks = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((xcorr_f64_list_kernel<64>), dim3((unsigned)blocks), dim3(128), 0, stream, p);
+    return hipGetLastError();
+}
 
 hipError_t launch_xcorr_f64(const PassParams& p, int n_cu, hipStream_t stream) {
     switch (p.ws) {

@@ -1183,11 +1183,161 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
     }
 }
 
+
+// ---- exact first pass (precision "exact", xcorr_exact.hip): the float32 map only LOCATES cells ------------------
+// Instead of the record of peak_analysis the window gets the flat indices (fftshift layout) of
+//   * the arg-max, if exactly one cell lies within EXACT_BAND x (max - min) of the maximum,
+//   * up to EXACT_MAX_SECOND cells outside the exclusion zone of B:346-358 within the band of their maximum,
+//   * up to EXACT_MAX_MIN cells within the band of the minimum;
+// exact_refine_kernel then evaluates those cells (and the arg-max's flat-index neighbours) as exact integer sums of the
+// uint8 windows.  The float32 transform's error on a 64x64 map is ~3e-7 of the map's range (tests/test_exact_scheme.py
+// measures it; the band leaves two orders of magnitude), and the refinement re-checks every decision on the exact values.
+// A window with more cells inside a band than the record holds, or a flat / NaN map, is marked undecided (-1): it goes
+// through the float64 transform (xcorr_f64_split_kernel<64, true>).  Dead windows (B:513: zero mean) are marked -2.
+// One window per wavefront (WS = 64): every ballot below spans exactly the window.
+constexpr float EXACT_BAND = 3.0e-5f;
+constexpr int EXACT_MAX_SECOND = 3, EXACT_MAX_MIN = 4;
+
+// columns of map row ys (fftshift layout) that B:346-358 zeroes around the first peak m: q = clamp(m + i + WS j),
+// |i|, |j| <= wv -- in row y' the columns mx+i (j = y'-my), mx+i+WS (j = y'-my+1), mx+i-WS (j = y'-my-1), plus the clamps
+template <int WS>
+__device__ __forceinline__ unsigned long long exclusion_row_mask(int m, int ys, int wv) {
+    static_assert(WS == 64, "one 64-bit mask per row");
+    const int my_ = m / WS, mx_ = m % WS, KD = WS * WS;
+    const int dj = ys - my_;
+    unsigned long long ex = 0ull;
+    auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
+        lo_ = lo_ < 0 ? 0 : lo_;
+        hi_ = hi_ > WS - 1 ? WS - 1 : hi_;
+        if (lo_ > hi_) return 0ull;
+        const unsigned long long ones = (hi_ - lo_ + 1) >= 64 ? ~0ull : ((1ull << (hi_ - lo_ + 1)) - 1ull);
+        return ones << lo_;
+    };
+    if (dj >= -wv && dj <= wv) ex |= span(mx_ - wv, mx_ + wv);
+    if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(mx_ - wv + WS, mx_ + wv + WS);
+    if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx_ - wv - WS, mx_ + wv - WS);
+    if (ys == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;
+    if (ys == WS - 1 && (m + wv + wv * WS) >= KD - 1) ex |= 1ull << (WS - 1);
+    return ex;
+}
+
+template <int WS>
+__device__ __forceinline__ void peak_candidates(const PassParams& p, const float (&row)[WS], float* tile, int r, bool dead,
+                                                size_t fidx) {
+    static_assert(WS == 64, "one window per wavefront");
+    const int ys = (r + WS / 2) % WS;
+    float rmin = 3.4e38f, rmax = -3.4e38f;
+#pragma unroll
+    for (int k = 0; k < WS; ++k) {
+        rmin = fminf(rmin, row[k]);
+        rmax = fmaxf(rmax, row[k]);
+    }
+    const float cmin = grp_min<WS>(rmin);
+    const float gmax = grp_reduce<WS>(rmax, [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); });
+    const float band = EXACT_BAND * (gmax - cmin);
+    bool open = !(band > 0.0f);                       // flat or NaN map
+    // map row of lane rl (fftshift column order) through LDS: lane r receives column r
+    auto park = [&](int rl) TPIV_LAMBDA_INLINE {
+        wave_sync();
+        if (r == rl) {
+#pragma unroll
+            for (int k = 0; k < WS; ++k) tile[(k + WS / 2) % WS] = row[k];
+        }
+        wave_sync();
+        return tile[r];
+    };
+    auto row_of_lane = [](int rl) TPIV_LAMBDA_INLINE { return (rl + WS / 2) % WS; };
+    // ---- arg-max: one row, one column inside the band, or undecided
+    int m = 0;
+    {
+        const unsigned long long rows = __ballot(rmax >= gmax - band);
+        open = open || __popcll(rows) != 1;
+        const int rl = rows ? (int)__builtin_ctzll(rows) : 0;
+        const unsigned long long cols = __ballot(park(rl) >= gmax - band);
+        open = open || __popcll(cols) != 1;
+        m = row_of_lane(rl) * WS + (cols ? (int)__builtin_ctzll(cols) : 0);
+    }
+    const int wv = p.val_win;
+    // ---- second peak: this lane's row maximum outside the exclusion zone, on c = row - min >= 0 (non-negative floats
+    //      order like their bit patterns; excluded cells become -1, so a result >= 0 means "a cell exists")
+    int s[EXACT_MAX_SECOND] = {-1, -1, -1};
+    {
+        const unsigned long long ex = exclusion_row_mask<WS>(m, ys, wv);
+        const int exl = (int)(unsigned)ex, exh = (int)(unsigned)(ex >> 32);
+        int smax = -1;
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int xsft = decltype(kc)::value;
+            constexpr int xo = (xsft + WS / 2) % WS;
+            const int kill = __builtin_amdgcn_sbfe(xsft < 32 ? exl : exh, xsft & 31, 1);
+            const int cnd = __float_as_int(__fsub_rn(row[xo], cmin)) | kill;
+            smax = cnd > smax ? cnd : smax;
+        });
+        const int sall = grp_reduce<WS>(smax, [](int a, int b) TPIV_LAMBDA_INLINE { return a > b ? a : b; });
+        if (sall >= 0) {                               // (wave-uniform)
+            const float thr = __int_as_float(sall) - band;
+            unsigned long long rows = __ballot(smax >= 0 && __int_as_float(smax) >= thr);
+            open = open || __popcll(rows) > EXACT_MAX_SECOND;
+            int ns = 0;
+            for (int it = 0; it < EXACT_MAX_SECOND && rows; ++it) {
+                const int rl = (int)__builtin_ctzll(rows);
+                rows &= rows - 1;
+                const int yr = row_of_lane(rl);
+                const unsigned long long exr = exclusion_row_mask<WS>(m, yr, wv);
+                unsigned long long cols = __ballot(__fsub_rn(park(rl), cmin) >= thr) & ~exr;
+                while (cols) {
+                    const int q = yr * WS + (int)__builtin_ctzll(cols);
+                    cols &= cols - 1;
+                    s[0] = ns == 0 ? q : s[0];
+                    s[1] = ns == 1 ? q : s[1];
+                    s[2] = ns == 2 ? q : s[2];
+                    ++ns;
+                }
+            }
+            open = open || ns > EXACT_MAX_SECOND;
+        }
+    }
+    // ---- minimum: the cells within the band of it (only the VALUE of the exact minimum is needed)
+    int n[EXACT_MAX_MIN] = {-1, -1, -1, -1};
+    {
+        const float thr = cmin + band;
+        unsigned long long rows = __ballot(rmin <= thr);
+        open = open || __popcll(rows) > EXACT_MAX_MIN;
+        int nn = 0;
+        for (int it = 0; it < EXACT_MAX_MIN && rows; ++it) {
+            const int rl = (int)__builtin_ctzll(rows);
+            rows &= rows - 1;
+            const int yr = row_of_lane(rl);
+            unsigned long long cols = __ballot(park(rl) <= thr);
+            while (cols) {
+                const int q = yr * WS + (int)__builtin_ctzll(cols);
+                cols &= cols - 1;
+                n[0] = nn == 0 ? q : n[0];
+                n[1] = nn == 1 ? q : n[1];
+                n[2] = nn == 2 ? q : n[2];
+                n[3] = nn == 3 ? q : n[3];
+                ++nn;
+            }
+        }
+        open = open || nn > EXACT_MAX_MIN;
+    }
+    if (r == 0) {
+        const int m_out = dead ? -2 : (open ? -1 : m);
+        auto pack = [](int lo_, int hi_) TPIV_LAMBDA_INLINE { return ((unsigned)lo_ & 0xffffu) | ((unsigned)hi_ << 16); };
+        uint4 rec;
+        rec.x = pack(m_out, s[0]);
+        rec.y = pack(s[1], s[2]);
+        rec.z = pack(n[0], n[1]);
+        rec.w = pack(n[2], n[3]);
+        p.cand[fidx] = rec;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // FAST (PassParams::precision == 0): cheaper arithmetic that differs from the !FAST form by float32
 // rounding only -- see convert_rows, the mean handling after the row transform and peak_analysis<.., SCALED>.
-template <int WS, int MODE, int OCC, bool FAST>
-__global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
+// CAND: the peak stage writes candidate cells for the exact refinement (peak_candidates) instead of the 8-float record
+template <int WS, int MODE, int OCC, bool FAST, bool CAND>
+__device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
     constexpr bool PLANAR = OCC > 2;
     using G = TileGeo<WS, PLANAR>;
     static_assert(WS == 8 || WS == 16 || WS == 32 || WS == 64, "tile sizes of this kernel");
@@ -1501,7 +1651,8 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
             const bool active_e = win_raw_e < N;
             const int win_e = active_e ? win_raw_e : N - 1;
             const size_t fidx_e = (size_t)pair_e * N + win_e;
-            peak_analysis<WS, PLANAR, FASTN>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e, end_scale);
+            if constexpr (CAND) peak_candidates<WS>(p, crow, tile, r_e, dead, fidx_e);
+            else peak_analysis<WS, PLANAR, FASTN>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e, end_scale);
         } else {
             peak_analysis<WS, PLANAR, FASTN>(p, crow, tile, w, r, active, dead, fidx, end_scale);
         }
@@ -1510,6 +1661,17 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
         TPIV_STAMP(13);     // sub-pixel fit, combine, stores
     }
     TPIV_STAMP_FLUSH(p);
+}
+
+template <int WS, int MODE, int OCC, bool FAST>
+__global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
+    xcorr_tile_body<WS, MODE, OCC, FAST, false>(p);
+}
+// float32 first pass of the exact scheme: same transforms, candidate cells out
+template <int WS>
+__global__ __launch_bounds__(64, 3) void xcorr_tile_cand_kernel(PassParams p) {
+    static_assert(tile_occ_c(WS, MODE_PASS1) == 3, "built for the three-wavefront planar layout");
+    xcorr_tile_body<WS, MODE_PASS1, 3, true, true>(p);
 }
 
 // ---- test hook: feed hand-made correlation maps straight into peak_analysis ------------------------
@@ -1611,6 +1773,22 @@ static hipError_t launch_tile(const PassParams& p_in, int n_cu, hipStream_t stre
     }
 #endif
     hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, OCC, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+// the candidate-cell variant of the float32 first pass (precision "exact"); same grid and work queue as launch_tile
+template <int WS>
+hipError_t launch_xcorr_tile_cand_ws(const PassParams& p_in, int n_cu, hipStream_t stream) {
+    using G = TileGeo<WS>;
+    static_assert(G::WPW == 1, "one window per wavefront");
+    PassParams p = p_in;
+    const long long items = (long long)p.batch * p.n_rows * p.n_cols;
+    if (items <= 0 || items >= (1ll << 31) - 64 || p.cand == nullptr) return hipErrorInvalidValue;
+    fast_div_setup((unsigned)(p.n_rows * p.n_cols), p.groups_magic, p.groups_shift);
+    fast_div_setup((unsigned)p.n_cols, p.ncols_magic, p.ncols_shift);
+    long long blocks = items < (long long)n_cu * 64 ? items : (long long)n_cu * 64;
+    blocks = (blocks + 7) / 8 * 8;
+    hipLaunchKernelGGL((xcorr_tile_cand_kernel<WS>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -353,6 +353,12 @@ class Plan:
         lib.tpiv_plan_kernel_name(self._h, p, buf, 128)
         return buf.value.decode()
 
+    def exact_fallbacks(self):
+        """precision="exact": windows of the last run whose first pass took the float64 transform (waits for the device)."""
+        n = C.c_longlong()
+        check(lib.tpiv_plan_exact_fallbacks(self._h, C.byref(n)))
+        return n.value
+
     def debug_predict(self, p, u_c, v_c, inv_c):
         """Test hook: the plan's banded predictor of pass p on given coarse fields."""
         B = u_c.shape[0]
