@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the PIV cross-correlation hot path (driver contract).
 
-    python bench.py --gpus N --steps K --warmup W [--config 1|2] [--precision f64|fast|reference]
+    python bench.py --gpus N --steps K --warmup W [--config 1|2] [--precision exact|f64|fast|reference]
 
 Metric (BASELINE.json): image-pairs/sec at 4 MP, wind=64 ov=32, 2-pass CWS x2.0.
 
@@ -19,10 +19,13 @@ N > 1 without a launcher: `python bench.py --gpus N` starts the N ranks itself (
 touches the GPU runs `python -m torch.distributed.run --nproc-per-node N bench.py ...`); under
 torchrun (WORLD_SIZE set) it is a rank.  The line is refused unless n_gpus == --gpus.
 
-Precision.  `value` is measured at --precision f64 (the default): the reference's own arithmetic types -- pass 1 in
-float64 (PIVbackend.py:513-514), shifted passes float32 with the float64 epilogue (B:249-257, B:382) -- `dtype
-"f64/f32"`.  At N = 1 the same process then times the all-float32 mode as well and reports it BESIDE the headline as
-`fast: {value, ms_per_step, kernel_ms, roofline}` (never as `value`), followed by `end_to_end` (the generator through
+Precision.  `value` is measured at --precision exact (the default of the library): every transform of the shifted
+passes in the reference's types (float32 with the float64 epilogue, B:249-257, B:382), and pass 1 -- float64 in the
+reference, B:513-514 -- from EXACT integer correlation sums at the map cells that reach the result (a float32 FFT pass only
+locates them inside an error band; undecided windows run the float64 transform; csrc/xcorr_exact.hip).  The fields are
+within 1e-14 px of the float64 pass 1 (tests/test_gpu_exact.py) -- not a narrower type.  At N = 1 the same process then
+times the same workload with pass 1 through the float64 FFT kernel (`f64_transform`, the headline of rounds 2-3) and
+with pass 1 in float32 (`fast`), reported BESIDE the headline, never as `value`; then `end_to_end` (the generator through
 post-validation and yield, tools/e2e_generator.py) and `cpu_baseline`.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel: HIP-event durations on the
@@ -75,10 +78,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for config 1, 10 for config 2)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=1, choices=(1, 2))
-    ap.add_argument("--precision", default="f64",
-                    help="f64 (default): pass 1 in float64 like the reference (PIVbackend.py:513-514), shifted passes float32; "
+    ap.add_argument("--precision", default="exact",
+                    help="exact (default): pass 1 from exact integer correlation sums (64x64 windows), shifted passes float32; "
+                         "f64: pass 1 through a float64 FFT like the reference (PIVbackend.py:513-514); "
                          "reference: the same with the reference's operation order in the CWS sampling; fast: pass 1 in float32 too")
-    ap.add_argument("--no-fast", action="store_true", help="N = 1: skip the all-float32 run reported beside the headline")
+    ap.add_argument("--no-fast", action="store_true", help="N = 1: skip the float64-FFT and all-float32 runs reported beside the headline")
     ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end_to_end block (generator rates)")
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per launch (config 1: 256; config 2: shard 500)")
     ap.add_argument("--stream", type=int, default=4000, help="config 2: pairs in the stream (all ranks together)")
@@ -97,8 +101,8 @@ def parse_args():
     ap.add_argument("--fill-workers", type=int, default=8)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
-    if not all(p_ in ("f64", "fast", "reference") for p_ in a.precision.split(",")):
-        ap.error("--precision must be f64, fast or reference")
+    if not all(p_ in ("exact", "f64", "fast", "reference") for p_ in a.precision.split(",")):
+        ap.error("--precision must be exact, f64, fast or reference")
     if a.mode is None:
         a.mode = "CWS" if a.config == 1 else "DWS"
     if a.batch is None:
@@ -263,7 +267,7 @@ def pmc_for(pmc, kernel_name):
 
 
 def e2e_cases(n, workers, files=True, budget_s=150.0):
-    """Generator rates end to end (tools/e2e_generator.py) at the default precision of the drop-in ("f64")."""
+    """Generator rates end to end (tools/e2e_generator.py) at the default precision of the drop-in ("exact")."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import contextlib
     import io as _io
@@ -275,7 +279,7 @@ def e2e_cases(n, workers, files=True, budget_s=150.0):
 
 
 def e2e_block(r, log, n, workers):
-    return {"unit": "pairs/s", "pairs_per_case": r.get("pairs_streamed", n), "distinct_pairs": n, "batch": 32, "fill_workers": workers, "precision": r.get("precision", "f64"),
+    return {"unit": "pairs/s", "pairs_per_case": r.get("pairs_streamed", n), "distinct_pairs": n, "batch": 32, "fill_workers": workers, "precision": r.get("precision", "exact"),
             "what": "generator end to end at 4 MP, wind=64 ov=32 2-pass CWS: passes + device post-validation + counted host "
                     "fallbacks + flip/scale + yield (ResidentPIV / OfflinePIV.batched)",
             "resident_clean_all_dropped": r.get("clean"), "resident_straight_runs": r.get("runs"),
@@ -391,8 +395,12 @@ def e2e_mode(args):
     print(json.dumps(rec), flush=True)
 
 
-DTYPE = {"fast": "f32", "f64": "f64/f32", "reference": "f64/f32"}
+DTYPE = {"exact": "u32 exact sums + f64 / f32", "fast": "f32", "f64": "f64/f32", "reference": "f64/f32"}
 PREC_NOTE = {
+    "exact": "exact (pass 1: the map cells behind the result -- arg-max, neighbours, second peak, minimum -- as exact uint8 "
+             "correlation sums (u32), located by a float32 FFT pass inside an error band, float64 epilogue; undecided windows "
+             "through the float64 FFT; within 1e-14 px of the reference's float64 pass 1, B:513-518; passes >= 2 float32 + float64 "
+             "epilogue as in the reference, B:249-257 / B:382)",
     "fast": "fast (pass 1 float32; passes >= 2 float32 + float64 epilogue as in the reference)",
     "f64": "f64 (pass 1 float64 as in the reference, B:513-514; passes >= 2 float32 + float64 epilogue as in the reference, "
            "B:249-257 / B:382, CWS sample formed as row lerps + column lerp)",
@@ -509,6 +517,11 @@ def main():
         res = {"precision": precision, "elapsed": elapsed, "step_ms": step_ms, "timing": timing, "n_runs": n_runs,
                "geometry": list(plan.geometry), "names": [plan.kernel_name(p_) for p_ in range(plan.n_pass)],
                "n_pass": plan.n_pass}
+        if precision == "exact" and plan.geometry[0][0] == 64:
+            # slot pass1_xcorr taken apart (events behind each kernel), and how many windows the float64 transform decided
+            res["exact_timing"] = plan.exact_timing()
+            res["exact_fallbacks"] = {"windows": plan.exact_fallbacks(), "of": shards[-1][1] * plan.geometry[0][2] * plan.geometry[0][3],
+                                      "note": "first-pass windows of the last launch that took the float64 transform"}
         plan.close()
         del u_all, v_all, i_all
         return res
@@ -522,6 +535,8 @@ def main():
 
     head = measure(args.precision, args.steps, args.warmup)
     also_fast = world == 1 and args.config == 1 and not args.no_fast and args.precision != "fast"
+    also_f64 = also_fast and args.precision == "exact"
+    f64_run = measure("f64", args.steps, args.warmup) if also_f64 else None
     fast = measure("fast", args.steps, args.warmup) if also_fast else None
 
     # who ran: backend and devices as torch.distributed saw them (every rank reports, rank 0 prints)
@@ -536,7 +551,7 @@ def main():
         # ---- PMC counters (N = 1): one set of child passes covers both precisions
         pmc, pmc_src = None, "off"
         if world == 1 and args.pmc == "live":
-            pmc, pmc_src = collect_pmc_live(args, [args.precision] + (["fast"] if also_fast else []))
+            pmc, pmc_src = collect_pmc_live(args, [args.precision] + (["f64"] if also_f64 else []) + (["fast"] if also_fast else []))
         if pmc is None and args.pmc in ("live", "file") and os.path.exists(PMC_FILE):
             try:
                 with open(PMC_FILE) as f:
@@ -555,15 +570,18 @@ def main():
                 g_ws, g_ov, g_nr, g_nc = m["geometry"][p_idx]
                 n_win = g_nr * g_nc
                 launch_pairs = shards[0][1]                   # pairs per launch (full shards)
-                f64 = p_idx == 0 and m["precision"] != "fast"
+                exact = p_idx == 0 and "exact_timing" in m
+                f64 = p_idx == 0 and m["precision"] not in ("fast",) and not exact
                 b_launch = alg_bytes(H, W, n_win, p_idx == 0) * launch_pairs
                 f_launch = alg_flops(g_ws, n_win, args.mode == "CWS" and p_idx > 0) * launch_pairs
-                t_k = m["timing"][slot] * 1e-3
+                # (exact: this entry is the float32 locating kernel alone; the other kernels of the slot follow below)
+                slot_ms = m["exact_timing"]["locate_f32"] if exact else m["timing"][slot]
+                t_k = slot_ms * 1e-3
                 peak_tf = FP64_VALU_PEAK_TFLOPS if f64 else FP32_VALU_PEAK_TFLOPS
                 name = m["names"][p_idx]
                 ctr = pmc_for(pmc, name)
                 ent = {
-                    "kernel": name, "arith": "f64" if f64 else "f32", "launch_ms": m["timing"][slot],
+                    "kernel": name, "arith": "f64" if f64 else "f32", "launch_ms": slot_ms,
                     "launches_timed": m["n_runs"], "pairs_per_launch": launch_pairs,
                     "alg_flops_per_launch": f_launch, "alg_bytes_per_launch": b_launch,
                     "valu": {"achieved": f_launch / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
@@ -587,8 +605,22 @@ def main():
                     if "SQ_LDS_BANK_CONFLICT" in ctr and ctr.get("SQ_ACTIVE_INST_LDS"):
                         ent["lds_conflict_share"] = ctr["SQ_LDS_BANK_CONFLICT"] / ctr["SQ_ACTIVE_INST_LDS"]
                     ent["counters_per_launch"] = {k: v * scale for k, v in ctr.items()}
-                kernels[slot] = ent
-            dom = max(kernels, key=lambda k: kernels[k]["launch_ms"])
+                kernels["pass1_locate" if exact else slot] = ent
+                if exact:
+                    et = m["exact_timing"]
+                    # the refinement: ~8 cells per window (arg-max + 4 neighbours + second peak + minimum ...), 4096 u8
+                    # multiply-adds each; it re-reads both windows (L2 hits next to the locating pass: the images once)
+                    kernels["pass1_refine"] = {
+                        "kernel": "xcorr_exact_refine_kernel", "arith": "u8 dot4 -> u32", "launch_ms": et["refine_exact"],
+                        "launches_timed": m["n_runs"], "pairs_per_launch": launch_pairs,
+                        "alg_int_ops_per_launch": 2.0 * 8 * g_ws * g_ws * n_win * launch_pairs,
+                        "alg_bytes_per_launch": (2 * H * W + 64 * n_win) * launch_pairs,
+                        "counters_per_launch": pmc_for(pmc, "xcorr_exact_refine_kernel")}
+                    kernels["pass1_undecided_f64"] = {
+                        "kernel": "xcorr_f64_list_kernel<64>", "arith": "f64", "launch_ms": et["undecided_f64"],
+                        "launches_timed": m["n_runs"], "windows": m["exact_fallbacks"]}
+                    kernels["pass1_finalize"] = {"kernel": "finalize_kernel<true>", "launch_ms": et["finalize"]}
+            dom = max((k for k in kernels if "valu" in kernels[k]), key=lambda k: kernels[k]["launch_ms"])
             d = kernels[dom]
             roof = {
                 "bound": "valu",
@@ -663,6 +695,22 @@ def main():
                               "note": "'>6.7 pairs/s' incl. file I/O, GPU unnamed (GTX 1660 Ti era), "
                                       "reference README.md:58; not this exact metric, so vs_baseline is null"},
         }
+        if "exact_timing" in head:
+            rec["exact"] = {"pass1_ms": head["exact_timing"], "float64_path": head["exact_fallbacks"],
+                            "band": 1.0e-4, "min_contrast": 0.028,
+                            "note": "pass1_xcorr of kernel_ms = locate_f32 + refine_exact + undecided_f64 + finalize (HIP events "
+                                    "behind each kernel); parity gates: tests/test_gpu_exact.py (<= 1e-11 px against the float64 "
+                                    "kernel and the oracle, identical masks), error model: tools/research/exact_band.py"}
+        if f64_run is not None:
+            k64, roof64 = analyse(f64_run)
+            rec["f64_transform"] = {"dtype": DTYPE["f64"], "precision": PREC_NOTE["f64"],
+                                    "value": total_per_step * args.steps / f64_run["elapsed"], "unit": "pairs/s",
+                                    "steps": args.steps, "warmup": args.warmup,
+                                    "ms_per_step": f64_run["elapsed"] / args.steps * 1e3, "step_ms": stats(f64_run),
+                                    "kernel_ms": f64_run["timing"], "roofline": roof64, "kernels": k64,
+                                    "note": "the same workload, same process, pass 1 through the float64 FFT kernel "
+                                            "(--precision f64: the headline of rounds 2-3, and the path the exact mode's undecided "
+                                            "windows take)"}
         if fast is not None:
             fk, froof = analyse(fast)
             rec["fast"] = {"dtype": DTYPE["fast"], "precision": PREC_NOTE["fast"],

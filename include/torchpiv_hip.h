@@ -257,6 +257,10 @@ int tpiv_plan_get_timing(tpiv_plan* plan, double* avg_ms, int n_slots, int* n_ru
  * went through the float64 transform (undecided by the float32 locating pass).  Waits for the device.  TPIV_EINVAL for
  * other plans or before the first run.  (Diagnostics: bench.py reports the share.) */
 int tpiv_plan_exact_fallbacks(tpiv_plan* plan, long long* n_windows);
+/* TPIV_PREC_EXACT plans with 64x64 first-pass windows: slot 0 of tpiv_plan_get_timing taken apart, as of the last call of
+ * that function: ms4 = mean milliseconds of {float32 locating pass, exact refinement, float64 pass of the undecided
+ * windows, finalize}. */
+int tpiv_plan_exact_timing(const tpiv_plan* plan, double* ms4);
 
 /* ---- test hook ------------------------------------------------------------------ */
 

@@ -15,7 +15,8 @@ import torch
 
 from oracle import piv_oracle as O
 
-KAPPA = 3.0e-5          # band half-width relative to the map range (xcorr_exact.hip: EXACT_BAND)
+KAPPA = 1.0e-4          # band half-width relative to the map range (xcorr_tile.hpp: EXACT_BAND)
+MIN_CONTRAST = 0.028    # (S(m) - S_min) / (|a - mean a| |b - mean b|) below which the float64 transform decides (EXACT_MIN_CONTRAST)
 MAX_SECOND = 3          # candidates carried per window (more -> float64 fallback)
 MAX_MIN = 4
 
@@ -95,6 +96,10 @@ def exact_window(a, b, wv=3, val_ratio=1.2):
     smin = min(S[q] for q in mins)
     if min(S.values()) < smin:
         return None
+    ai, bi = a.astype(np.int64), b.astype(np.int64)
+    e2 = (float((ai * ai).sum()) - float(sa) ** 2 / KD) * (float((bi * bi).sum()) - float(sb) ** 2 / KD)
+    if not float(S[m] - smin) ** 2 >= MIN_CONTRAST ** 2 * e2:
+        return None                                 # the float32 transform's error is not small against this map's range
     scale = float(W) ** 4 / (float(sa) * float(sb))
     val = lambda q: (S[q] - smin) * scale + 1e-7
     cm, cl, cr, ct, cb = val(m), val(left), val(right), val(top), val(bot)

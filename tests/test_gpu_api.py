@@ -118,7 +118,7 @@ def strict_chain(a, b, ws, ov, n_pass, mode, precision, unit, got_u, got_v, name
 DEGENERATE = {("r2", 3), ("r3", 3), ("r4", 3)}
 
 
-@pytest.mark.parametrize("precision", ["fast", "f64", "reference"])
+@pytest.mark.parametrize("precision", ["fast", "f64", "reference", "exact"])
 @pytest.mark.parametrize("run", ["r1", "r2", "r3", "r4"])
 def test_offline_piv_generator(folder, golden, run, precision):
     """The generator against the reference's own OfflinePIV runs: same pairs dropped, same coordinates,

@@ -1,5 +1,5 @@
-"""precision="exact" (csrc/xcorr_exact.hip): pass 1 from exact integer correlation sums, located by a float32 FFT pass,
-with the float64 transform for the windows that pass cannot decide.
+"""precision="exact" (csrc/xcorr_exact.hip; 32x32, 64x64 and 128x128 first-pass windows): pass 1 from exact integer
+correlation sums, located by a float32 FFT pass, with the float64 transform for the windows that pass cannot decide.
 
 Gates: (1) against the oracle's float64 pass 1 and the numpy statement of the scheme (tests/test_exact_scheme.py),
 (2) against the float64 kernel of this library on full-size frames: fields within 1e-11 px, identical validity masks,
@@ -30,33 +30,34 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def fields(eng, A, B, precision, **kw):
-    u, v, inv = eng.pass1(dev(A), dev(B), 64, kw.pop("ov", 32), precision=precision, **kw)
+def fields(eng, A, B, precision, ws=64, **kw):
+    u, v, inv = eng.pass1(dev(A), dev(B), ws, kw.pop("ov", ws // 2), precision=precision, **kw)
     torch.cuda.synchronize()
     return u.cpu().numpy(), v.cpu().numpy(), inv.cpu().numpy()
 
 
+@pytest.mark.parametrize("ws", [32, 64, 128])
 @pytest.mark.parametrize("seed,shift", [(1, (2.3, -1.6)), (2, (0.0, 0.0)), (3, (-7.4, 11.2))])
-def test_exact_pass1_against_oracle_and_model(eng, seed, shift):
+def test_exact_pass1_against_oracle_and_model(eng, seed, shift, ws):
     A, B = synthetic_pair(256, 256, seed, shift)
-    u0, v0, _, _, m0 = O.pass1(A, B, 64, 32, validate=True)
-    u, v, inv = fields(eng, A[None], B[None], "exact")
+    u0, v0, _, _, m0 = O.pass1(A, B, ws, ws // 2, validate=True)
+    u, v, inv = fields(eng, A[None], B[None], "exact", ws)
     assert np.abs(u[0] - u0).max() < TOL_F64 and np.abs(v[0] - v0).max() < TOL_F64
     assert np.array_equal(inv[0].astype(bool), m0)
     # the numpy statement of the scheme, window by window (its own float32 map may send other windows to the fallback)
-    aw, bw = O.windows(A, 64, 32), O.windows(B, 64, 32)
-    for i, (a, b) in enumerate(zip(aw, bw)):
+    aw, bw = O.windows(A, ws, ws // 2), O.windows(B, ws, ws // 2)
+    for i, (a, b) in list(enumerate(zip(aw, bw)))[:: max(1, len(aw) // 50)]:
         r = exact_window(a, b)
         if r is not None:
             assert abs(r[0] - u[0].reshape(-1)[i]) < 1e-13 and abs(r[1] - v[0].reshape(-1)[i]) < 1e-13, i
 
 
-@pytest.mark.parametrize("ov", [32, 48, 10, 0])
-def test_exact_equals_float64_kernel_on_full_frames(eng, ov):
+@pytest.mark.parametrize("ws,ov", [(64, 32), (64, 48), (64, 10), (64, 0), (32, 16), (32, 7), (128, 64), (128, 100)])
+def test_exact_equals_float64_kernel_on_full_frames(eng, ws, ov):
     from torchpiv_amd import synth
     A, B = synth.make_batch(4, 1024, 1024, device="cuda", noise=3.0, first_index=ov + 1)
-    ue, ve, ie = eng.pass1(A, B, 64, ov, precision="exact")
-    uf, vf, i_f = eng.pass1(A, B, 64, ov, precision="f64")
+    ue, ve, ie = eng.pass1(A, B, ws, ov, precision="exact")
+    uf, vf, i_f = eng.pass1(A, B, ws, ov, precision="f64")
     assert float((ue - uf).abs().max()) < TOL_F64 and float((ve - vf).abs().max()) < TOL_F64
     assert torch.equal(ie, i_f)
 
@@ -71,25 +72,26 @@ def test_exact_validation_parameters(eng, val_win, val_ratio):
     assert torch.equal(ie, i_f)
 
 
-def test_exact_edge_windows(eng):
+@pytest.mark.parametrize("ws", [32, 64, 128])
+def test_exact_edge_windows(eng, ws):
     rng = np.random.default_rng(3)
-    H = W = 256
+    H = W = 4 * ws
     A = rng.integers(0, 256, (5, H, W), dtype=np.uint8)
     B = rng.integers(0, 256, (5, H, W), dtype=np.uint8)
-    A[0, 64:192, 64:192] = 0                  # dead windows in frame a (zero mean: NaN map in the reference)
-    B[1, :96, :] = 0                          # ... in frame b
+    A[0, ws:3 * ws, ws:3 * ws] = 0            # dead windows in frame a (zero mean: NaN map in the reference)
+    B[1, :3 * ws // 2, :] = 0                 # ... in frame b
     B[2] = A[2]                               # byte-identical frames: the exact fit is 0
-    A[3, 32:160, 32:160] = 77                 # flat windows: constant map, nothing to decide -> float64 path
-    B[3, 32:160, 32:160] = 91
+    A[3, ws // 2:5 * ws // 2, ws // 2:5 * ws // 2] = 77      # flat windows: constant map, nothing to decide -> float64 path
+    B[3, ws // 2:5 * ws // 2, ws // 2:5 * ws // 2] = 91
     A[4] = 255                                # saturated frames
     B[4] = 255
-    ue, ve, ie = fields(eng, A, B, "exact")
-    uf, vf, i_f = fields(eng, A, B, "f64")
+    ue, ve, ie = fields(eng, A, B, "exact", ws)
+    uf, vf, i_f = fields(eng, A, B, "f64", ws)
     assert np.abs(ue - uf).max() < TOL_F64 and np.abs(ve - vf).max() < TOL_F64
     assert np.array_equal(ie, i_f)
     assert np.all(ue[2] == 0.0) and np.all(ve[2] == 0.0)
     for k in (0, 1, 3):                       # and against the oracle itself where the reference is deterministic
-        u0, v0, _, _, m0 = O.pass1(A[k], B[k], 64, 32, validate=True)
+        u0, v0, _, _, m0 = O.pass1(A[k], B[k], ws, ws // 2, validate=True)
         ok = np.abs(ue[k] - u0) < 1e-9
         # pure-noise windows: the arg-max of the reference's own map is decided at 1e-16 relative; count, don't compare
         assert ok.mean() > 0.9, k
@@ -113,3 +115,17 @@ def test_exact_fallback_share_and_whole_chain(eng):
     assert float(far.float().mean()) < 1e-3
     with pytest.raises(ValueError):
         pf.exact_fallbacks()
+
+
+@pytest.mark.parametrize("ws,size,batch", [(32, 1024, 4), (128, 1024, 8)])
+def test_exact_other_sizes_fallback_share(eng, ws, size, batch):
+    from torchpiv_amd import synth
+    A, B = synth.make_batch(batch, size, size, device="cuda", noise=2.0, first_index=17)
+    pe = eng.Plan(size, size, ws, ws // 2, n_pass=1, max_batch=batch, precision="exact")
+    assert "cand" in pe.kernel_name(0)
+    ue, ve, ie = pe.run(A, B)
+    n_fb, n_win = pe.exact_fallbacks(), batch * pe.geometry[0][2] * pe.geometry[0][3]
+    uf, vf, i_f = eng.pass1(A, B, ws, ws // 2, precision="f64")
+    print(f"ws {ws}: {n_fb} of {n_win} windows through the float64 transform")
+    assert n_fb <= n_win // 20
+    assert float((ue - uf).abs().max()) < TOL_F64 and float((ve - vf).abs().max()) < TOL_F64 and torch.equal(ie, i_f)

@@ -28,7 +28,7 @@ def _oracle_fields(an, bn, geo, mode, name):
     return g
 
 
-@pytest.mark.parametrize("precision", ["reference", "f64", "fast"])
+@pytest.mark.parametrize("precision", ["reference", "f64", "fast", "exact"])
 @pytest.mark.parametrize("mode", ["CWS", "DWS"])
 def test_cfg2_against_oracle(pair, mode, precision):
     """configs[1]/[2] geometry at full size (2048^2, 64/32 -> 32/16, 16 129 vectors) against the oracle by the three
@@ -103,7 +103,7 @@ def _cfg2_stream(n, distinct, picks):
     order = torch.from_numpy(np.random.default_rng(4).permutation(n) % distinct).cuda()
     A, B = A0[order], B0[order]
     del A0, B0
-    plan = engine.Plan(H, W, 64, 32, n_pass=2, mode="DWS", max_batch=500, precision="f64")
+    plan = engine.Plan(H, W, 64, 32, n_pass=2, mode="DWS", max_batch=500, precision="exact")
 
     def stream(step):
         us, vs, ivs = [], [], []
@@ -121,7 +121,7 @@ def _cfg2_stream(n, distinct, picks):
           f"invalid vectors {int(i5.sum())} of {i5.numel()}")
     u5b, v5b, _ = stream(500)
     assert torch.equal(u5, u5b) and torch.equal(v5, v5b)                       # run to run
-    one = engine.Plan(H, W, 64, 32, n_pass=2, mode="DWS", max_batch=1, precision="f64")
+    one = engine.Plan(H, W, 64, 32, n_pass=2, mode="DWS", max_batch=1, precision="exact")
     worst = 0.0
     for k in picks:
         u1, v1, i1 = one.run(A[k], B[k])

@@ -145,7 +145,7 @@ def check_fields(u, v, inv, ru, rv, rinv, what, max_flip_frac=0.0, excused=None,
     return (float(err[ok].max()) if ok.any() else 0.0), int(flips.sum())
 
 
-@pytest.mark.parametrize("precision", ["fast", "f64"])
+@pytest.mark.parametrize("precision", ["fast", "f64", "exact"])
 def test_pass1_golden(eng, golden, precision):
     g = golden("g3_pass1")
     for name in g["names"]:
@@ -486,7 +486,7 @@ def cascade_check(eng, g, name, mode, precision, geo, scale=2.0, cap=EXCUSE_CAP,
     return counts
 
 
-@pytest.mark.parametrize("precision", ["reference", "f64", "fast"])
+@pytest.mark.parametrize("precision", ["reference", "f64", "fast", "exact"])
 @pytest.mark.parametrize("mode", ["DWS", "CWS"])
 def test_multipass_plan_end_to_end(eng, golden, mode, precision):
     """Whole-plan cascade on every multipass golden; see cascade_check for the three gates (reference chain,

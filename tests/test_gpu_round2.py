@@ -44,15 +44,15 @@ def exact_tie_windows(a, b, ws, ov):
     return tie.reshape(nr, nc)
 
 
-def check_reference_precision(eng, a, b, ws, ov, ru, rv, rmask, what):
-    u, v, inv = eng.pass1(dev(a), dev(b), ws, ov, precision="reference")
+def check_reference_precision(eng, a, b, ws, ov, ru, rv, rmask, what, precision="reference"):
+    u, v, inv = eng.pass1(dev(a), dev(b), ws, ov, precision=precision)
     u, v, inv = u[0].cpu().numpy(), v[0].cpu().numpy(), inv[0].cpu().numpy().astype(bool)
     const = pass1_constant(a, b, ws, ov)           # flat maps (saturated / black blocks): every cell ties
     tie = exact_tie_windows(a, b, ws, ov) | const
     err = np.maximum(np.abs(u - ru), np.abs(v - rv))
     flips = inv != rmask
     n_tie = int((tie & ~const).sum())
-    print(f"  reference precision {what} (ws {ws}): max |d| {err[~tie].max() if (~tie).any() else 0:.2e} px over "
+    print(f"  {precision} precision {what} (ws {ws}): max |d| {err[~tie].max() if (~tie).any() else 0:.2e} px over "
           f"{err.size - int(tie.sum())} windows, mask flips {int((flips & ~tie).sum())}, exact float64 ties {n_tie}, "
           f"constant-input windows {int(const.sum())} (of which differing: {int((const & (flips | (err > TOL_REF))).sum())})")
     assert n_tie <= 0.01 * tie.size, (what, n_tie)          # genuine ties are rare (the same 1 % cap as elsewhere)
@@ -60,33 +60,35 @@ def check_reference_precision(eng, a, b, ws, ov, ru, rv, rmask, what):
     assert err[~tie].max() <= TOL_REF, (what, float(err[~tie].max()), np.argwhere((err > TOL_REF) & ~tie)[:5].tolist())
 
 
-def test_pass1_reference_precision_goldens(eng, golden):
+@pytest.mark.parametrize("precision", ["reference", "exact"])
+def test_pass1_reference_precision_goldens(eng, golden, precision):
     """Every pass-1 golden (tile sizes 8..128, generic sizes 6..256, black / saturated blocks) at the
-    reference's own precision: <= 1e-9 px and identical validity masks, no excuse set."""
+    reference's own precision, and at the library's default ("exact": exact sums for 64x64 windows, the float64 kernels
+    for the other sizes): <= 1e-9 px and identical validity masks, no excuse set."""
     g = golden("g3_pass1")
     for name in g["names"]:
         ws, ov = (int(t) for t in g[name + "_cfg"])
         check_reference_precision(eng, g[name + "_a"], g[name + "_b"], ws, ov, g[name + "_u"], g[name + "_v"],
-                                  g[name + "_mask"], name)
+                                  g[name + "_mask"], name, precision)
     g = golden("g7_generic")
     for name in g["p1_names"]:
         ws, ov = (int(t) for t in g[name + "_cfg"])
         check_reference_precision(eng, g[name + "_a"], g[name + "_b"], ws, ov, g[name + "_u"], g[name + "_v"],
-                                  g[name + "_mask"], name)        # (incl. the odd size ws33)
+                                  g[name + "_mask"], name, precision)        # (incl. the odd size ws33)
     g = golden("g4_multipass")
     for name in g["names"]:
         ws, ov, _ = (int(t) for t in g[name + "_cfg"])
         check_reference_precision(eng, g[name + "_a"], g[name + "_b"], ws, ov, g[name + "_DWS_p0_u"],
-                                  g[name + "_DWS_p0_v"], g[name + "_DWS_p0_val"], name + " p0")
+                                  g[name + "_DWS_p0_v"], g[name + "_DWS_p0_val"], name + " p0", precision)
 
 
-@pytest.mark.parametrize("ws,H,W", [(64, 2048, 2048), (32, 1024, 1536)])
-def test_reference_precision_vs_oracle_large(eng, ws, H, W):
+@pytest.mark.parametrize("ws,H,W,precision", [(64, 2048, 2048, "reference"), (64, 2048, 2048, "exact"), (32, 1024, 1536, "reference")])
+def test_reference_precision_vs_oracle_large(eng, ws, H, W, precision):
     """A full-size frame (configs[1] geometry for ws = 64) against the float64 oracle."""
     from torchpiv_amd import synth
     a, b = synth.make_pair(H, W, 5000 + ws, kind="wavy", noise=2.0)
     ou, ov_, _, _, om = O.pass1(a.numpy(), b.numpy(), ws, ws // 2, validate=True)
-    check_reference_precision(eng, a.numpy(), b.numpy(), ws, ws // 2, ou, ov_, om, f"{H}x{W}")
+    check_reference_precision(eng, a.numpy(), b.numpy(), ws, ws // 2, ou, ov_, om, f"{H}x{W}", precision)
 
 
 def test_reference_precision_errors(eng):
@@ -94,7 +96,7 @@ def test_reference_precision_errors(eng):
     with pytest.raises(KeyError):
         eng.pass1(a, a, 32, 16, precision="double")
     with pytest.raises(KeyError):
-        eng.Plan(64, 64, 32, 16, precision="exact")
+        eng.Plan(64, 64, 32, 16, precision="quad")
 
 
 @pytest.mark.parametrize("mode", ["DWS", "CWS"])
@@ -401,7 +403,7 @@ def test_resident_generator_equals_host_post_validation(eng):
         A.append(a)
         B.append(b)
     A, B = torch.stack(A).cuda(), torch.stack(B).cuda()
-    piv = T.ResidentPIV(A, B, 32, 16, multipass=2, multipass_mode="CWS", dt=2, scale=0.5)       # (default precision: "f64")
+    piv = T.ResidentPIV(A, B, 32, 16, multipass=2, multipass_mode="CWS", dt=2, scale=0.5)       # (default precision: "exact" = "f64" for 32x32 windows)
     res = {i: (x, y, u, v) for i, x, y, u, v in piv.batched(4)}
     plan = eng.Plan(H, W, 32, 16, n_pass=2, mode="CWS", max_batch=6, precision="f64")
     u, v, inv = plan.run(A, B)

@@ -1,0 +1,11 @@
+# fallback share and pass-1 time of precision="exact" against the width of the decision band (TPIV_EXACT_BAND)
+mkdir -p gpurun_out
+L=gpurun_out/r4_band2.log
+timeout -k 10 300 python tools/research/exact_band.py > $L 2>&1 || exit 1
+for band in 3e-5 1e-4 3e-4; do
+  for noise in 0 8; do
+    echo "== band $band noise $noise" >> $L
+    TPIV_EXACT_BAND=$band timeout -k 10 300 python tools/quick_bench.py --size 2048 --ws 64 --passes 2 --mode CWS --batch 256 --distinct 16 --noise $noise --precision exact >> $L 2>&1 || exit 1
+  done
+done
+grep -v amdgpu.ids $L | grep "==\|exact:\|per-kernel\|pairs/s\|family\|e-0\|e+0"

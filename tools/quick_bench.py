@@ -13,12 +13,13 @@ ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--distinct", type=int, default=2)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--kind", default="wavy")
+ap.add_argument("--noise", type=float, default=0.0)
 ap.add_argument("--width", type=int, default=0, help="frame width when it differs from --size (row-pitch experiments)")
 ap.add_argument("--precision", default="fast", choices=("fast", "f64", "reference", "exact"))
 a = ap.parse_args()
 H = a.size
 W = a.width or a.size
-A0, B0 = synth.make_batch(a.distinct, H, W, device="cuda", kind=a.kind)
+A0, B0 = synth.make_batch(a.distinct, H, W, device="cuda", kind=a.kind, noise=a.noise)
 A = A0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
 B = B0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
 plan = engine.Plan(H, W, a.ws, a.ws // 2, n_pass=a.passes, mode=a.mode, max_batch=a.batch, precision=a.precision)
@@ -44,4 +45,8 @@ tm, n = plan.get_timing()
 print("per-kernel ms per batch:", {k: round(v, 3) for k, v in tm.items()}, " us/pair:",
       {k: round(v / a.batch * 1000, 1) for k, v in tm.items()})
 u, v, inv = out
+if a.precision == "exact" and a.ws == 64:
+    n_fb = plan.exact_fallbacks()
+    n_w = a.batch * plan.geometry[0][2] * plan.geometry[0][3]
+    print(f"exact: {n_fb} of {n_w} first-pass windows took the float64 transform ({100.0 * n_fb / n_w:.3f} %)")
 print("invalid frac", inv.float().mean().item(), "u mean", u.mean().item(), "v mean", v.mean().item())

@@ -61,6 +61,7 @@ SIGNATURES = {
                                    _int, _int, _int]),
     "tpiv_plan_kernel_name": (C.c_char_p, [C.c_void_p, _int, C.c_char_p, _int]),
     "tpiv_plan_exact_fallbacks": (_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
+    "tpiv_plan_exact_timing": (_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "tpiv_plan_destroy": (None, [C.c_void_p]),
     "tpiv_plan_n_pass": (C.c_int, [C.c_void_p]),
     "tpiv_plan_pass_geometry": (C.c_int, [C.c_void_p, _int, C.POINTER(C.c_int), C.POINTER(C.c_int),

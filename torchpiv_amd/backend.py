@@ -124,11 +124,13 @@ def moving_window_array(array: torch.Tensor, window_size, overlap) -> torch.Tens
 # pass 1 (B:459-520)
 # ----------------------------------------------------------------------------------------
 def extended_search_area_piv(frame_a, frame_b, window_size=32, overlap=0, validate: bool = False,
-                             validation_ratio: float = 1.2, precision: str = "f64"):
+                             validation_ratio: float = 1.2, precision: str = "exact"):
     """First-pass PIV of one pair.  frame_a / frame_b: uint8 tensors [H, W] on a ROCm device.
     Returns (u, v, x, y, mask) as numpy arrays like the reference (mask None if not validate).
     Raises ValueError for overlap >= window_size or a window larger than the image.
-    precision (extension): "f64" / "reference" = float64 like B:513-514 (the default), "fast" = float32 transforms."""
+    precision (extension): "exact" (default) = the map cells behind the result as exact integer correlation sums (64x64
+    windows; within 1e-14 px of the reference's float64 pass, bit-identical for most windows), "f64" / "reference" = float64
+    transforms like B:513-514 (what "exact" runs for other window sizes), "fast" = float32 transforms."""
     H, W = frame_a.shape[-2], frame_a.shape[-1]
     u, v, inv = engine.pass1(frame_a, frame_b, int(window_size), int(overlap),
                              val_ratio=float(validation_ratio), precision=precision)
@@ -336,10 +338,13 @@ class OfflinePIV:
 
     def __init__(self, folder: str, device: str, file_fmt: str, wind_size: int, overlap: int,
                  multipass: int = 1, multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.,
-                 multipass_scale: float = 2., folder_mode: str = "pairs", precision: str = "f64",
+                 multipass_scale: float = 2., folder_mode: str = "pairs", precision: str = "exact",
                  validation_ratio: float = 1.2, validation_window: int = 3) -> None:
-        # precision (extension, keyword after the reference's arguments).  "f64" (default): the reference's own
-        # arithmetic types -- pass 1 in float64 (B:513-514), later passes float32 with a float64 epilogue.
+        # precision (extension, keyword after the reference's arguments).  "exact" (default): as "f64", with the map cells
+        # that reach the result of a 64x64 first pass evaluated as exact integer correlation sums instead of through a
+        # float64 FFT (csrc/xcorr_exact.hip: within 1e-14 px of the reference's float64 pass 1, about 1.5x the rate of
+        # "f64"; other first-pass sizes run as "f64").  "f64": the reference's own arithmetic types in every transform --
+        # pass 1 in float64 (B:513-514), later passes float32 with a float64 epilogue.
         # "reference": the same plus the reference's operation order in the CWS sampling (bit-identical staged
         # windows).  "fast": pass 1 in float32 too (~1e-6 px from the float64 pass 1, about 1.9x the rate).
         # validation_ratio / validation_window (extensions): the constants the reference hides inside
@@ -853,7 +858,7 @@ class ResidentPIV(OfflinePIV):
 
     def __init__(self, frames_a: torch.Tensor, frames_b: torch.Tensor, wind_size: int, overlap: int,
                  multipass: int = 1, multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.,
-                 multipass_scale: float = 2., precision: str = "f64", validation_ratio: float = 1.2,
+                 multipass_scale: float = 2., precision: str = "exact", validation_ratio: float = 1.2,
                  validation_window: int = 3) -> None:
         if frames_a.shape != frames_b.shape or frames_a.dim() != 3 or frames_a.dtype != torch.uint8 \
                 or frames_b.dtype != torch.uint8:

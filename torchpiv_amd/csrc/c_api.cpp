@@ -245,11 +245,17 @@ struct tpiv_plan {
             for (hipEvent_t e : r) (void)hipEventDestroy(e);
     }
     int n_slots() const { return 2 * n_pass - 1; }
+    // TPIV_PREC_EXACT: three more events per run inside slot 0 (behind the locating pass, the refinement, the float64 list pass)
+    double exact_ms[4] = {0, 0, 0, 0};   // their mean durations at the last tpiv_plan_get_timing (+ finalize)
+    hipEvent_t* sub_events() {
+        if (!exact_count || !ev(0, 0)) return nullptr;
+        return events[runs_recorded].data() + 2 * n_slots();
+    }
     // event for (current run, slot, begin/end); nullptr when timing is off or the record is full
     hipEvent_t ev(int slot, int end) {
         if (!timing || runs_recorded >= 512) return nullptr;
         if (events.size() <= runs_recorded) {
-            std::vector<hipEvent_t> r(2 * n_slots(), nullptr);
+            std::vector<hipEvent_t> r(2 * n_slots() + 3, nullptr);
             for (auto& e : r)
                 if (hipEventCreate(&e) != hipSuccess) return nullptr;
             events.push_back(std::move(r));
@@ -375,7 +381,8 @@ int tpiv_spline_matrix(int nc, const double* xc, int nf, const double* xf, doubl
 
 static int pass1_impl(const uint8_t* a, const uint8_t* b, int batch, int H, int W, int ws, int ov,
                       double val_ratio, int val_win, int precision, double* u, double* v, uint8_t* invalid,
-                      void* work, size_t work_bytes, float* dbg_win, float* dbg_corr, void* stream) {
+                      void* work, size_t work_bytes, float* dbg_win, float* dbg_corr, void* stream,
+                      hipEvent_t* sub_events = nullptr) {
     int rc = check_window(H, W, ws, ov, val_win);
     if (rc) return rc;
     if (!valid_precision(precision)) return fail(TPIV_EINVAL, "precision must be TPIV_PREC_FAST, TPIV_PREC_REFERENCE, TPIV_PREC_F64 or TPIV_PREC_EXACT");
@@ -398,6 +405,7 @@ static int pass1_impl(const uint8_t* a, const uint8_t* b, int batch, int H, int 
     p.val_win = val_win;
     p.stamps = g_stamps;
     p.precision = precision;
+    p.sub_events = sub_events;
     rc = check_work(work, work_bytes, tpiv::peak_raw_bytes(ws, batch, p.n_rows * p.n_cols, precision));
     if (rc) return rc;
     p.peak_raw = static_cast<float*>(work);
@@ -636,7 +644,8 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
         }
         pl->peak_raw_bytes = raw;
         if (raw) rc = pl->alloc(&pl->peak_raw, raw / sizeof(float) + 64);
-        if (rc == TPIV_OK && precision == TPIV_PREC_EXACT && pl->geo[0].ws == 64) rc = pl->alloc(&pl->exact_count, 4);
+        if (rc == TPIV_OK && precision == TPIV_PREC_EXACT && (pl->geo[0].ws == 32 || pl->geo[0].ws == 64 || pl->geo[0].ws == 128))
+            rc = pl->alloc(&pl->exact_count, 4);
     }
     if (rc == TPIV_OK && n_pass > 1) {
         rc = pl->alloc(&pl->u0, max_fine * max_batch);
@@ -678,8 +687,8 @@ const char* tpiv_plan_kernel_name(const tpiv_plan* plan, int pass, char* buf, in
 
 int tpiv_plan_exact_fallbacks(tpiv_plan* plan, long long* n_windows) {
     if (!plan || !n_windows) return fail(TPIV_EINVAL, "null argument");
-    if (plan->precision != TPIV_PREC_EXACT || plan->geo[0].ws != 64)
-        return fail(TPIV_EINVAL, "not a TPIV_PREC_EXACT plan with 64x64 first-pass windows");
+    if (!plan->exact_count)
+        return fail(TPIV_EINVAL, "not a TPIV_PREC_EXACT plan with 32x32, 64x64 or 128x128 first-pass windows");
     if (plan->last_batch <= 0) return fail(TPIV_EINVAL, "the plan has not run yet");
     HIP_TRY(hipDeviceSynchronize());
     unsigned n = 0;
@@ -762,7 +771,7 @@ int tpiv_plan_run(tpiv_plan* plan, const uint8_t* a, const uint8_t* b, int batch
             mark(0, 0);
             rc = pass1_impl(a, b, batch, plan->H, plan->W, g.ws, g.ov, plan->val_ratio, plan->val_win,
                             plan->precision, pu, pv, pval, plan->peak_raw, plan->peak_raw_bytes, nullptr, nullptr,
-                            stream);
+                            stream, plan->sub_events());
             mark(0, 1);
             if (!rc && plan->exact_count) {
                 const size_t off = tpiv::exact_fallback_count_offset(batch, g.n_rows * g.n_cols);
@@ -1027,8 +1036,27 @@ int tpiv_plan_get_timing(tpiv_plan* plan, double* avg_ms, int n_slots, int* n_ru
     }
     if (n)
         for (int s = 0; s < n_slots; ++s) avg_ms[s] /= (double)n;
+    for (double& m : plan->exact_ms) m = 0.0;
+    if (plan->exact_count && n) {
+        for (size_t r = 0; r < n; ++r) {
+            const hipEvent_t* sub = plan->events[r].data() + 2 * n_slots;
+            const hipEvent_t chain[5] = {plan->events[r][0], sub[0], sub[1], sub[2], plan->events[r][1]};
+            for (int s = 0; s < 4; ++s) {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, chain[s], chain[s + 1]));
+                plan->exact_ms[s] += ms / (double)n;
+            }
+        }
+    }
     if (n_runs) *n_runs = (int)n;
     plan->runs_recorded = 0;
+    return TPIV_OK;
+}
+
+int tpiv_plan_exact_timing(const tpiv_plan* plan, double* ms4) {
+    if (!plan || !ms4) return fail(TPIV_EINVAL, "null argument");
+    if (!plan->exact_count) return fail(TPIV_EINVAL, "not a TPIV_PREC_EXACT plan with 32x32, 64x64 or 128x128 first-pass windows");
+    for (int s = 0; s < 4; ++s) ms4[s] = plan->exact_ms[s];
     return TPIV_OK;
 }
 

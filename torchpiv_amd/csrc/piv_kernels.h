@@ -49,11 +49,25 @@ struct PassParams {
     uint4* cand;
     int* fb_list;
     unsigned* fb_count;
+    float exact_band;        // half-width of the decision band of the locating pass, relative to the map range (EXACT_BAND)
+    hipEvent_t* sub_events;  // host side only, optional: [3] recorded behind the locating pass, the refinement, the float64 list pass
     // n / d for n < 2^31 as (n * magic) >> shift (set by the tile launcher; keeps the per-item index
     // arithmetic in the scalar unit instead of a hoisted float reciprocal that occupies a VGPR)
     unsigned groups_magic, ncols_magic;
     int groups_shift, ncols_shift;
 };
+
+// ---- precision "exact": constants shared by the locating pass (xcorr_tile.hpp, peak_candidates), the refinement
+// (xcorr_exact.hip) and the launcher
+// The band.  A decision of the locating pass is right whenever every cell of the float32 map is within band / 2 of the
+// exact one.  The float32 transform's cell error follows E = |a - mean a| |b - mean b| / (mean a mean b), not the map's
+// range R: tools/research/exact_band.py measures err <= 6.7e-7 E over particle images, noise, two-level and saturated
+// frames, sinusoids and nearly orthogonal patterns (R / E from 1.7 down to 8e-6).  With EXACT_BAND = 1e-4 of the range
+// the band covers twice that error for every window with R >= EXACT_MIN_CONTRAST x E = 0.028 E; the refinement computes
+// R and E exactly and sends the windows below that contrast (pure-noise windows sit at 0.1) to the float64 transform.
+constexpr float EXACT_BAND = 1.0e-4f;
+constexpr double EXACT_MIN_CONTRAST = 0.028;
+constexpr int EXACT_MAX_SECOND = 3, EXACT_MAX_MIN = 4;
 
 struct PredictParams {
     int batch, mode;

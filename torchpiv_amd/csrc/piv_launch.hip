@@ -26,7 +26,9 @@ int generic_blocks(int ws, long long items, int n_cu, int elem_bytes);
 bool generic_ct_usable(int ws);
 hipError_t launch_xcorr_f64(const PassParams& p, int n_cu, hipStream_t stream);      // xcorr_f64.hip: 8..64, pass 1
 // precision "exact" (64x64 pass 1): float32 candidate pass, exact integer refinement, float64 pass for the undecided windows
-hipError_t launch_xcorr_cand_ws64(const PassParams& p, int n_cu, hipStream_t stream);       // xcorr_tile.hpp
+hipError_t launch_xcorr_cand_ws32(const PassParams& p, int n_cu, hipStream_t stream);       // xcorr_tile.hpp
+hipError_t launch_xcorr_cand_ws64(const PassParams& p, int n_cu, hipStream_t stream);
+hipError_t launch_xcorr_cand_ws128(const PassParams& p, int n_cu, hipStream_t stream);      // xcorr_big.hpp
 hipError_t launch_exact_refine(const PassParams& p, hipStream_t stream);                    // xcorr_exact.hip
 hipError_t launch_xcorr_f64_list(const PassParams& p, int n_cu, hipStream_t stream);        // xcorr_f64.hip
 
@@ -187,7 +189,7 @@ static ExactLayout exact_layout(int batch, int n_windows) {
     l.total = l.ctr + WORK_CTR_BYTES;
     return l;
 }
-static bool exact_size(int ws) { return ws == 64; }
+static bool exact_size(int ws) { return ws == 32 || ws == 64 || ws == 128; }
 size_t exact_fallback_count_offset(int batch, int n_windows) { return exact_layout(batch, n_windows).count; }
 
 size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool force_generic) {
@@ -218,7 +220,8 @@ static int pass_precision(int precision, int mode, int ws) {
 const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len) {
     precision = pass_precision(precision, mode, ws);
     if (precision == 3 && mode == MODE_PASS1) {
-        snprintf(buf, len, "xcorr_tile_cand_kernel<%d>", ws);
+        if (ws == 128) snprintf(buf, len, "xcorr_big128_cand_kernel");
+        else snprintf(buf, len, "xcorr_tile_cand_kernel<%d>", ws);
     } else if (precision && mode == MODE_PASS1) {
         if (ws == 64 || ws == 128) snprintf(buf, len, "xcorr_f64_split_kernel<%d>", ws);
         else if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_tile_kernel<%d>", ws);
@@ -260,13 +263,26 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
         p.fb_list = reinterpret_cast<int*>(base + l.list);
         p.fb_count = reinterpret_cast<unsigned*>(base + l.count);
         p.work_ctr = reinterpret_cast<unsigned*>(base + l.ctr);
+        // (TPIV_EXACT_BAND: experiments with the width of the locating pass's decision band, tools/research/exact_band.py)
+        static const float band = [] {
+            const char* env = getenv("TPIV_EXACT_BAND");
+            return env ? (float)atof(env) : EXACT_BAND;
+        }();
+        p.exact_band = band;
         e = hipMemsetAsync(p.fb_count, 0, 256 + WORK_CTR_BYTES, stream);
         if (e != hipSuccess) return e;
-        e = launch_xcorr_cand_ws64(p, n_cu, stream);
+        auto mark = [&](int i) {
+            if (p.sub_events) (void)hipEventRecord(p.sub_events[i], stream);
+        };
+        e = p.ws == 32 ? launch_xcorr_cand_ws32(p, n_cu, stream)
+                       : (p.ws == 64 ? launch_xcorr_cand_ws64(p, n_cu, stream) : launch_xcorr_cand_ws128(p, n_cu, stream));
         if (e != hipSuccess) return e;
+        mark(0);
         e = launch_exact_refine(p, stream);
         if (e != hipSuccess) return e;
+        mark(1);
         e = launch_xcorr_f64_list(p, n_cu, stream);
+        mark(2);
     } else if (f64) {
         // (TPIV_F64_GENERIC128=1: the generic-size DFT kernel for 128x128, as before the split kernel existed -- A/B runs)
         static const bool gen128 = [] {

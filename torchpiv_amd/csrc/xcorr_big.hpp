@@ -39,6 +39,11 @@ struct BigShared {
     float redf[8];                  // (min, raw max) of the map
     int redi[8];                    // row of the maximum / second peak
     unsigned long long redu[4];     // window sums
+    // candidate-cell variant (precision "exact", xcorr_exact.hip): cells inside the band of the maximum (count only),
+    // of the second peak and of the minimum
+    int redc[4];
+    int n_second, n_min;
+    int cand_second[EXACT_MAX_SECOND], cand_min[EXACT_MAX_MIN];
 };
 
 // Workgroup barrier for LDS exchanges only: __syncthreads() also waits for vmcnt(0), which would
@@ -60,7 +65,9 @@ __device__ __forceinline__ T block_reduce(T v, OP op, T* slots, int wave, int la
 // in: thread (line = t & 127, par = t >> 7) holds c[j] = corr(row line, column 2j + par) in UN-shifted
 // coordinates; the map is parked in sm.plane in fftshift coordinates.  `prefetch` runs once after the
 // thread-local minimum (the kernel issues the next window's row loads there).
-template <typename PREFETCH>
+// CAND: instead of the record, the flat indices of the cells the exact refinement evaluates (see peak_candidates in
+// xcorr_tile.hpp for the rules; here the whole map sits in LDS and every thread looks through its own 64 cells)
+template <bool CAND = false, typename PREFETCH>
 __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[BH], BigShared& sm, int t, size_t fidx,
                                                bool dead, PREFETCH&& prefetch) {
     float* const plane = sm.plane;
@@ -78,7 +85,14 @@ __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[B
             cmin = fminf(cmin, c[j]);
             rraw = fmaxf(rraw, c[j]);
         }
+        const float cmin_mine = cmin;
         prefetch();
+        if constexpr (CAND) {
+            if (t == 0) {
+                sm.n_second = 0;
+                sm.n_min = 0;
+            }
+        }
         auto fmin_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fminf(a, b); };
         auto fmax_ = [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); };
         auto imin_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
@@ -153,7 +167,70 @@ __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[B
                 smax = cand > smax ? cand : smax;
             });
         }
+        const int smax_mine = smax;
         smax = block_reduce(smax, imax_, sm.redi + 4, wave, lane);
+        if constexpr (CAND) {
+            // (all values are the shifted cells v = (c - min) + 1e-7 > 0: differences are those of the raw map)
+            const float band = p.exact_band * __fsub_rn(graw, cmin);
+            bool open = !(band > 0.0f);
+            // arg-max: exactly one cell inside the band of the maximum (then it is the cell found above)
+            int cnt = 0;
+            if (rmax >= gmax - band) {
+#pragma unroll
+                for (int j = 0; j < BH; ++j) cnt += c[j] >= gmax - band ? 1 : 0;
+            }
+            // second peak: the cells outside the exclusion zone inside the band of their maximum
+            if (smax > 0 && smax_mine > 0 && __int_as_float(smax_mine) >= __int_as_float(smax) - band) {
+                const float thr = __int_as_float(smax) - band;
+                const int dj = ys - ywin;
+                static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int xe = (2 * j + 64) & 127;
+                    if (c[j] >= thr) {
+                        const int q = ys * BW + xe + par;
+                        // B:346-358 for one cell: q = clamp(m + i + BW jj), |i|, |jj| <= wv
+                        bool ex = false;
+                        for (int jj = dj - 1; jj <= dj + 1; ++jj) {
+                            const int i = q - m - BW * jj;
+                            ex = ex || (jj >= -wv && jj <= wv && i >= -wv && i <= wv);
+                        }
+                        ex = ex || (q == 0 && m - wv - wv * BW <= 0) || (q == KD - 1 && m + wv + wv * BW >= KD - 1);
+                        if (!ex) {
+                            const int k = atomicAdd(&sm.n_second, 1);
+                            if (k < EXACT_MAX_SECOND) sm.cand_second[k] = q;
+                        }
+                    }
+                });
+            }
+            // minimum: the cells inside the band of it
+            if (__fadd_rn(__fsub_rn(cmin_mine, cmin), 1e-7f) <= 1e-7f + band) {
+                const float thr = 1e-7f + band;
+                static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int xe = (2 * j + 64) & 127;
+                    if (c[j] <= thr) {
+                        const int k = atomicAdd(&sm.n_min, 1);
+                        if (k < EXACT_MAX_MIN) sm.cand_min[k] = ys * BW + xe + par;
+                    }
+                });
+            }
+            auto iadd_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a + b; };
+            cnt = block_reduce(cnt, iadd_, sm.redc, wave, lane);          // (also: the lists are complete)
+            if (t == 0) {
+                const int ns = sm.n_second, nn = sm.n_min;
+                open = open || cnt != 1 || ns > EXACT_MAX_SECOND || nn > EXACT_MAX_MIN;
+                auto get = [](const int* l, int n, int k) TPIV_LAMBDA_INLINE { return k < n ? l[k] : -1; };
+                auto pack = [](int lo_, int hi_) TPIV_LAMBDA_INLINE { return ((unsigned)lo_ & 0xffffu) | ((unsigned)hi_ << 16); };
+                const int m_out = dead ? -2 : (open ? -1 : m);
+                uint4 rec;
+                rec.x = pack(m_out, get(sm.cand_second, ns, 0));
+                rec.y = pack(get(sm.cand_second, ns, 1), get(sm.cand_second, ns, 2));
+                rec.z = pack(get(sm.cand_min, nn, 0), get(sm.cand_min, nn, 1));
+                rec.w = pack(get(sm.cand_min, nn, 2), get(sm.cand_min, nn, 3));
+                p.cand[fidx] = rec;
+            }
+            return;
+        }
         const float second_v = smax > 0 ? __int_as_float(smax) : gmax;
         if (t < 8) {
             int left = m + 1, right = m - 1, top = m + BW, bot = m - BW;     // B:385-392 (flat index)
@@ -175,7 +252,8 @@ __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[B
     }
 }
 
-__global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
+template <bool CAND>
+__device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
     __shared__ BigShared sm;
     float* const plane = sm.plane;
     const int t = threadIdx.x;
@@ -478,12 +556,16 @@ __global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) {
                 c[j] = (j & 1) ? zc[FFT_POS<j / 2, BH / 2>].y : zc[FFT_POS<j / 2, BH / 2>].x;
             });
             // prefetch: the last iteration re-loads its own window (no branch around the loads)
-            big_peak_stage(p, c, sm, t, fidx, dead, [&]() TPIV_LAMBDA_INLINE {
+            big_peak_stage<CAND>(p, c, sm, t, fidx, dead, [&]() TPIV_LAMBDA_INLINE {
                 issue_loads(item + per_xcd < hi ? item + per_xcd : item);
             });
         }
     }
 }
+
+__global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) { xcorr_big128_body<false>(p); }
+// float32 first pass of the exact scheme (xcorr_exact.hip): same transforms, candidate cells out
+__global__ __launch_bounds__(256, 2) void xcorr_big128_cand_kernel(PassParams p) { xcorr_big128_body<true>(p); }
 
 // test hook: hand-made maps [n_maps, 128, 128] float32 in fftshift layout through stage 7
 __global__ __launch_bounds__(256, 2) void peak_debug_big_kernel(PassParams p, const float* maps, int n_maps) {
@@ -504,12 +586,13 @@ inline hipError_t launch_peak_debug_big(const PassParams& p, const float* maps, 
     return hipGetLastError();
 }
 
-inline hipError_t launch_xcorr_big128(const PassParams& p, int n_cu, hipStream_t stream) {
+inline hipError_t launch_xcorr_big128(const PassParams& p, int n_cu, hipStream_t stream, bool cand = false) {
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
-    if (items <= 0) return hipErrorInvalidValue;
+    if (items <= 0 || (cand && p.cand == nullptr)) return hipErrorInvalidValue;
     long long blocks = items < (long long)n_cu * 16 ? items : (long long)n_cu * 16;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL(xcorr_big128_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    if (cand) hipLaunchKernelGGL(xcorr_big128_cand_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(xcorr_big128_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

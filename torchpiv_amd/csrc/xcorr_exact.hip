@@ -1,19 +1,20 @@
-// Exact first pass for 64x64 windows (precision "exact"): the values behind the sub-pixel fit and the validity ratio
+// Exact first pass for 32x32, 64x64 and 128x128 windows (precision "exact"): the values behind the sub-pixel fit and the validity ratio
 // as EXACT integer correlation sums of the uint8 windows.
 //
 // The reference (PIVbackend.py:513-518) divides both windows by their means in float64, correlates them through a
 // float64 FFT, subtracts the map minimum and adds 1e-7; every cell of that map is
-//     (S(d) - S_min) n^4 / (sum a  sum b) + 1e-7,      S(d) = sum_p a[p] b[(p + d) mod 64]   (integers < 2^28)
+//     (S(d) - S_min) n^4 / (sum a  sum b) + 1e-7,      S(d) = sum_p a[p] b[(p + d) mod W]   (integers < 2^30)
 // up to the rounding of the transform.  Only a handful of cells per window ever reach the result (B:383-411): the
 // arg-max, its four flat-index neighbours, the second peak, and the minimum.  So:
-//   1. xcorr_tile_cand_kernel<64> (xcorr_tile.hpp): the float32 FFT pass LOCATES those cells, with an error band around
-//      every decision (peak_candidates);
-//   2. exact_refine_kernel (here): one wavefront per window evaluates S at the located cells -- lane = window row,
+//   1. xcorr_tile_cand_kernel<32 | 64> (xcorr_tile.hpp, peak_candidates) / xcorr_big128_cand_kernel (xcorr_big.hpp): the
+//      float32 FFT pass LOCATES those cells, with an error band around every decision;
+//   2. xcorr_exact_refine_kernel<W> (here): the lanes of a window (32: half a wavefront, 64: one, 128: two) evaluate S
+//      at the located cells -- lane = window row,
 //      frame-a row in registers, frame b's rows parked twice over in LDS so that a row rotated by dx is one contiguous
-//      span; 16 v_dot4_u32_u8 per lane and cell --, re-checks the decisions on the exact values (no neighbour or second
+//      span; W / 4 v_dot4_u32_u8 per lane and cell --, re-checks the decisions on the exact values (no neighbour or second
 //      candidate above the arg-max, no evaluated cell below the minimum) and writes the 8-double record of
 //      finalize_kernel<true>.  Undecided windows are appended to a list;
-//   3. xcorr_f64_split_kernel<64, true> (xcorr_f64.hip) runs the float64 transform for the listed windows only.
+//   3. xcorr_f64_list_kernel<W> (xcorr_f64.hip) runs the float64 transform for the listed windows only.
 // tests/test_exact_scheme.py is the numpy statement of the scheme (checked against the oracle: 7e-15 px);
 // tests/test_gpu_exact.py compares this file with it and with the float64 kernel.
 #include <hip/hip_runtime.h>
@@ -26,138 +27,200 @@ namespace tpiv {
 
 namespace {
 
-constexpr int XW = 64;                  // window edge
-constexpr int XP = 33;                  // dwords per parked row: 2 x 16 (the row twice over) + 1 (odd pitch: lane = row reads hit 64 banks)
-constexpr int XWAVES = 4;               // windows per workgroup
+template <int W>
+struct XGeo {
+    static constexpr int NDW = W / 4;                        // dwords per window row
+    static constexpr int XP = 2 * NDW + 1;                   // dwords per parked row: the row twice over + 1 (odd pitch: the lane = row reads hit all banks)
+    static constexpr int GROUP = W < 64 ? W : 64;            // lanes of one window inside a wavefront
+    static constexpr int WPW = 64 / GROUP;                   // windows per wavefront (32x32: two)
+    static constexpr int PARTS = W / GROUP;                  // wavefronts per window (128x128: two)
+    static constexpr int WAVES = W == 128 ? 2 : 4;           // wavefronts per workgroup
+    static constexpr int WINS = WAVES * WPW / PARTS;         // windows per workgroup: 8 / 4 / 1
+    static constexpr int KD = W * W;
+};
 constexpr int XCELLS = 5 + EXACT_MAX_SECOND + EXACT_MAX_MIN;      // cells a window can ask for
 
-__global__ __launch_bounds__(64 * XWAVES) void exact_refine_kernel(PassParams p) {
-    __shared__ uint32_t parked[XWAVES][XW * XP];
+// Everything below is per-lane data with predicated control flow: for 32x32 the two windows of a wavefront take their
+// decisions independently.  (64x64: one window per wavefront; 128x128: one window per workgroup of two wavefronts, partial
+// sums joined through LDS behind ONE barrier that both wavefronts reach or neither does.)
+template <int W>
+__global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel(PassParams p) {
+    using G = XGeo<W>;
+    constexpr int NDW = G::NDW, XP = G::XP, KD = G::KD;
+    __shared__ uint32_t parked[G::WINS][W * XP];
+    __shared__ unsigned joined[2][16];                       // 128x128: per wavefront the partial S of 12 cells + 4 window sums
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
-    uint32_t* const rows_b = parked[wave];
+    const int g = lane / G::GROUP, r0 = lane % G::GROUP;     // window inside the wavefront, lane inside the window
+    const int part = G::PARTS == 2 ? wave : 0;
+    const int row = r0 + 64 * part;                          // window row of this lane
+    const int wslot = G::PARTS == 2 ? 0 : wave * G::WPW + g;
+    uint32_t* const rows_b = parked[wslot];
     const int N = p.n_rows * p.n_cols;
     const long long total = (long long)p.batch * N;
     // XCD-aware static order: workgroups b, b+8, ... share an XCD (and its L2) and cover one contiguous run of windows
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const long long chunk = (total + 7) / 8;
-    const long long in_chunk = (long long)slot * XWAVES + wave;
-    const long long it = (long long)xcd * chunk + in_chunk;
-    if (in_chunk >= chunk || it >= total) return;
+    const long long in_chunk = (long long)slot * G::WINS + wslot;
+    const long long it_raw = (long long)xcd * chunk + in_chunk;
+    const bool valid = in_chunk < chunk && it_raw < total;
+    const long long it = valid ? it_raw : 0;
 
     const uint4 rec = p.cand[it];
     auto lo16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v & 0xffffu); };
     auto hi16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v >> 16); };
-    const int m = lo16(rec.x);
+    const int m = valid ? lo16(rec.x) : -3;
     double* const out = reinterpret_cast<double*>(p.peak_raw) + (size_t)it * 8;
+    const bool writer = part == 0;                           // the wavefront of a window that stores its results
     auto to_f64_kernel = [&]() TPIV_LAMBDA_INLINE {
-        if (lane == 0) p.fb_list[atomicAdd(p.fb_count, 1u)] = (int)it;
+        if (r0 == 0 && writer) p.fb_list[atomicAdd(p.fb_count, 1u)] = (int)it;
     };
-    if (m == -1) {
-        to_f64_kernel();
-        return;
-    }
-    if (m == -2) {               // zero-mean window (B:513: NaN map): finalize_kernel looks at the flag only
-        if (lane < 8) out[lane] = lane == 7 ? 1.0 : (lane == 6 ? 0.0 : 1.0);
-        return;
-    }
-    constexpr int KD = XW * XW;
-    // ---- the cells: lane j holds flat index q_j (fftshift layout) or -1
-    int q;
-    {
-        int left = m + 1, right = m - 1, top = m + XW, bot = m - XW;      // B:385-392
+    if (m == -1) to_f64_kernel();
+    if (m == -2 && r0 < 8 && writer) out[r0] = r0 == 6 ? 0.0 : 1.0;      // zero-mean window (B:513: NaN map): finalize_kernel looks at the flag [7] only
+    const bool go = m >= 0;
+    if (__ballot(go) == 0ull) return;                        // (128x128: the same decision in both wavefronts of the window)
+
+    // ---- the cells: lane j of the window holds flat index q_j (fftshift layout) or -1
+    int q = -1;
+    if (go) {
+        int left = m + 1, right = m - 1, top = m + W, bot = m - W;      // B:385-392
         if (left >= KD - 1) left = m;
         if (right <= 0) right = m;
         if (top >= KD - 1) top = m;
         if (bot <= 0) bot = m;
-        q = -1;
-        q = lane == 0 ? m : q;
-        q = lane == 1 ? left : q;
-        q = lane == 2 ? right : q;
-        q = lane == 3 ? top : q;
-        q = lane == 4 ? bot : q;
-        q = lane == 5 ? hi16(rec.x) : q;
-        q = lane == 6 ? lo16(rec.y) : q;
-        q = lane == 7 ? hi16(rec.y) : q;
-        q = lane == 8 ? lo16(rec.z) : q;
-        q = lane == 9 ? hi16(rec.z) : q;
-        q = lane == 10 ? lo16(rec.w) : q;
-        q = lane == 11 ? hi16(rec.w) : q;
+        q = r0 == 0 ? m : q;
+        q = r0 == 1 ? left : q;
+        q = r0 == 2 ? right : q;
+        q = r0 == 3 ? top : q;
+        q = r0 == 4 ? bot : q;
+        q = r0 == 5 ? hi16(rec.x) : q;
+        q = r0 == 6 ? lo16(rec.y) : q;
+        q = r0 == 7 ? hi16(rec.y) : q;
+        q = r0 == 8 ? lo16(rec.z) : q;
+        q = r0 == 9 ? hi16(rec.z) : q;
+        q = r0 == 10 ? lo16(rec.w) : q;
+        q = r0 == 11 ? hi16(rec.w) : q;
     }
 
-    // ---- window rows: lane = row
+    // ---- window rows: lane = row (windows that do not go load their rows too: in-bounds, unused)
     const int pair = (int)(it / N), win = (int)(it % N);
     const int st = p.ws - p.ov;
-    const size_t off = (size_t)pair * p.H * p.W + (size_t)((win / p.n_cols) * st + lane) * p.W + (size_t)(win % p.n_cols) * st;
-    uint32_t a[XW / 4], b[XW / 4];
-    load_dwords<XW / 4>(p.A + off, a);
-    load_dwords<XW / 4>(p.B + off, b);
-    unsigned sa = 0, sb = 0;
+    const size_t off = (size_t)pair * p.H * p.W + (size_t)((win / p.n_cols) * st + row) * p.W + (size_t)(win % p.n_cols) * st;
+    uint32_t a[NDW], b[NDW];
+    load_dwords<NDW>(p.A + off, a);
+    load_dwords<NDW>(p.B + off, b);
+    unsigned sa = 0, sb = 0, saa = 0, sbb = 0;          // sums and sums of squares: < 2^22 and < 2^30 per window
 #pragma unroll
-    for (int i = 0; i < XW / 4; ++i) {
+    for (int i = 0; i < NDW; ++i) {
         sa = __builtin_amdgcn_sad_u8(a[i], 0u, sa);
         sb = __builtin_amdgcn_sad_u8(b[i], 0u, sb);
-        rows_b[lane * XP + i] = b[i];
-        rows_b[lane * XP + XW / 4 + i] = b[i];
+        saa = __builtin_amdgcn_udot4(a[i], a[i], saa, false);
+        sbb = __builtin_amdgcn_udot4(b[i], b[i], sbb, false);
+        rows_b[row * XP + i] = b[i];
+        rows_b[row * XP + NDW + i] = b[i];
     }
     auto uadd = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x + y; };
-    sa = grp_reduce<64>(sa, uadd);
-    sb = grp_reduce<64>(sb, uadd);
-    wave_sync();
+    sa = grp_reduce<G::GROUP>(sa, uadd);
+    sb = grp_reduce<G::GROUP>(sb, uadd);
+    saa = grp_reduce<G::GROUP>(saa, uadd);
+    sbb = grp_reduce<G::GROUP>(sbb, uadd);
+    if constexpr (G::PARTS == 2) __syncthreads();       // the other wavefront's rows are parked
+    else wave_sync();
 
-    // ---- S at every requested cell; lane j keeps S(q_j)
+    // ---- S at every requested cell; lane j of the window keeps S(q_j)
     unsigned S = 0;
     for (int c = 0; c < XCELLS; ++c) {
-        const int qc = __builtin_amdgcn_readlane(q, c);
-        if (qc < 0) continue;
-        const int dy = (qc >> 6) - XW / 2, dx = (qc & 63) - XW / 2;
-        const int brow = (lane + dy) & 63, bx = dx & 63;
+        int qc = __builtin_amdgcn_readlane(q, c);
+        if constexpr (G::WPW == 2) {
+            const int q1 = __builtin_amdgcn_readlane(q, 32 + c);
+            if (qc < 0 && q1 < 0) continue;
+            qc = g ? q1 : qc;
+        } else {
+            if (qc < 0) continue;
+        }
+        const bool on = qc >= 0;
+        const int qq = on ? qc : 0;
+        const int dy = qq / W - W / 2, dx = qq % W - W / 2;
+        const int brow = (row + dy) & (W - 1), bx = dx & (W - 1);
         const uint32_t* src = rows_b + brow * XP + (bx >> 2);
         const unsigned sh = (unsigned)(bx & 3);
-        uint32_t w[XW / 4 + 1];
+        uint32_t w[NDW + 1];
 #pragma unroll
-        for (int i = 0; i <= XW / 4; ++i) w[i] = src[i];
+        for (int i = 0; i <= NDW; ++i) w[i] = src[i];
         unsigned acc = 0;
 #pragma unroll
-        for (int i = 0; i < XW / 4; ++i) acc = __builtin_amdgcn_udot4(a[i], __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh), acc, false);
-        acc = grp_reduce<64>(acc, uadd);
-        S = lane == c ? acc : S;
+        for (int i = 0; i < NDW; ++i) acc = __builtin_amdgcn_udot4(a[i], __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh), acc, false);
+        acc = grp_reduce<G::GROUP>(acc, uadd);
+        S = (r0 == c && on) ? acc : S;
+    }
+    if constexpr (G::PARTS == 2) {
+        // join the two halves of the window: lanes 0..11 carry the partial S, lanes 12..15 the partial window sums
+        unsigned mine = S;
+        mine = lane == 12 ? sa : mine;
+        mine = lane == 13 ? sb : mine;
+        mine = lane == 14 ? saa : mine;
+        mine = lane == 15 ? sbb : mine;
+        if (lane < 16) joined[wave][lane] = mine;
+        __syncthreads();
+        S = lane < 16 ? joined[0][lane] + joined[1][lane] : 0u;
+        sa = joined[0][12] + joined[1][12];
+        sb = joined[0][13] + joined[1][13];
+        saa = joined[0][14] + joined[1][14];
+        sbb = joined[0][15] + joined[1][15];
+        S = lane < XCELLS ? S : 0u;
     }
 
     // ---- the decisions, re-checked on the exact values
     const bool have = q >= 0;
     auto umin = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x < y ? x : y; };
     auto umax = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x > y ? x : y; };
-    const unsigned s_min = grp_reduce<64>((have && lane >= 5 + EXACT_MAX_SECOND && lane < XCELLS) ? S : 0xffffffffu, umin);
-    const unsigned s_low = grp_reduce<64>((have && lane < XCELLS) ? S : 0xffffffffu, umin);
-    const unsigned s_top = grp_reduce<64>((have && lane < 5 + EXACT_MAX_SECOND) ? S : 0u, umax);
-    const unsigned s_m = (unsigned)__builtin_amdgcn_readlane((int)S, 0);
-    const unsigned long long seconds = __ballot(have && lane >= 5 && lane < 5 + EXACT_MAX_SECOND);
-    const unsigned s_second = grp_reduce<64>((have && lane >= 5 && lane < 5 + EXACT_MAX_SECOND) ? S : 0u, umax);
-    if (s_top > s_m || s_low < s_min || s_min == 0xffffffffu || sa == 0u || sb == 0u) {
-        to_f64_kernel();          // (cannot happen while the float32 map stays inside the band; sa, sb: the float32 kernel marks those)
-        return;
-    }
-    // (S - S_min) n^4 / (sum a sum b) + 1e-7: the integer difference is exact, sum a * sum b < 2^40 is exact
+    constexpr int S0 = 5, N0 = 5 + EXACT_MAX_SECOND;         // first second-peak / minimum slot
+    const unsigned s_min = grp_reduce<G::GROUP>((have && r0 >= N0 && r0 < XCELLS) ? S : 0xffffffffu, umin);
+    const unsigned s_low = grp_reduce<G::GROUP>((have && r0 < XCELLS) ? S : 0xffffffffu, umin);
+    const unsigned s_top = grp_reduce<G::GROUP>((have && r0 < N0) ? S : 0u, umax);
+    const unsigned s_m = grp_reduce<G::GROUP>(r0 == 0 ? S : 0u, umax);
+    const unsigned s_second = grp_reduce<G::GROUP>((have && r0 >= S0 && r0 < N0) ? S : 0u, umax);
+    const unsigned n_second = grp_reduce<G::GROUP>((have && r0 >= S0 && r0 < N0) ? 1u : 0u, uadd);
+    // contrast of the map against the scale the float32 transform's error follows (piv_kernels.h, "The band"):
+    // R = S(m) - S_min, E^2 = (sum a^2 - (sum a)^2 / n) (sum b^2 - (sum b)^2 / n), all from exact integers
+    const double ea2 = (double)saa - (double)sa * (double)sa * (1.0 / KD), eb2 = (double)sbb - (double)sb * (double)sb * (1.0 / KD);
+    const double range = (double)(s_m - s_min);
+    const bool low_contrast = !(range * range >= (EXACT_MIN_CONTRAST * EXACT_MIN_CONTRAST) * ea2 * eb2);
+    // (the first two cannot happen while the float32 map stays inside the band; sa, sb: the locating pass marks those)
+    const bool redo = s_top > s_m || s_low < s_min || s_min == 0xffffffffu || sa == 0u || sb == 0u || low_contrast;
+    if (go && redo) to_f64_kernel();
+    // (S - S_min) n^4 / (sum a sum b) + 1e-7: the integer difference is exact, sum a * sum b < 2^44 is exact
     const double scale = ((double)KD * (double)KD) / ((double)sa * (double)sb);
-    const unsigned mine = lane == 5 ? (seconds ? s_second : s_m) : S;      // B:411: no cell left -> the first peak itself
+    const unsigned mine = r0 == 5 ? (n_second ? s_second : s_m) : S;      // B:411: no cell left -> the first peak itself
     double v = __fma_rn((double)(mine - s_min), scale, 1e-7);
-    v = lane == 6 ? (double)m : v;
-    v = lane == 7 ? 0.0 : v;
-    if (lane < 8) out[lane] = v;
+    v = r0 == 6 ? (double)m : v;
+    v = r0 == 7 ? 0.0 : v;
+    if (go && !redo && r0 < 8 && writer) out[r0] = v;
 }
 
 }  // namespace
 
 // cand / fb_list / fb_count are set by the caller (launch_xcorr); the records go where the float64 kernel puts them
+template <int W>
+static hipError_t launch_refine(const PassParams& p, hipStream_t stream) {
+    using G = XGeo<W>;
+    const long long total = (long long)p.batch * p.n_rows * p.n_cols;
+    const long long chunk = (total + 7) / 8;
+    const long long slots = (chunk + G::WINS - 1) / G::WINS;
+    hipLaunchKernelGGL((xcorr_exact_refine_kernel<W>), dim3((unsigned)(slots * 8)), dim3(64 * G::WAVES), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_exact_refine(const PassParams& p, hipStream_t stream) {
     const long long total = (long long)p.batch * p.n_rows * p.n_cols;
-    if (p.ws != XW || total <= 0 || total >= (1ll << 31) || p.cand == nullptr || p.fb_list == nullptr || p.fb_count == nullptr)
+    if (total <= 0 || total >= (1ll << 31) || p.cand == nullptr || p.fb_list == nullptr || p.fb_count == nullptr)
         return hipErrorInvalidValue;
-    const long long chunk = (total + 7) / 8;
-    const long long slots = (chunk + XWAVES - 1) / XWAVES;
-    hipLaunchKernelGGL(exact_refine_kernel, dim3((unsigned)(slots * 8)), dim3(64 * XWAVES), 0, stream, p);
-    return hipGetLastError();
+    switch (p.ws) {
+        case 32: return launch_refine<32>(p, stream);
+        case 64: return launch_refine<64>(p, stream);
+        case 128: return launch_refine<128>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace tpiv

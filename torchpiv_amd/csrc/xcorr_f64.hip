@@ -418,15 +418,17 @@ __device__ __forceinline__ void lds_read_seq(unsigned base, F&& sink) {
     });
 }
 
-template <int WS>
-__global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
+// LIST: the windows are those of PassParams::fb_list, WPW consecutive entries per item (precision "exact")
+template <int WS, bool LIST>
+__device__ __forceinline__ void xcorr_f64_tile_body(const PassParams& p) {
     using G = F64TileGeo<WS>;
     constexpr int P = G::P, M = G::M, NDW = G::NDW, WPW = G::WPW;
     __shared__ double tile[WPW * G::PLANE];
 
     const int N = p.n_rows * p.n_cols;
+    const long long listed = LIST ? (long long)*p.fb_count : 0;
     const int groups = (N + WPW - 1) / WPW;
-    const long long items = (long long)p.batch * groups;
+    const long long items = LIST ? (listed + WPW - 1) / WPW : (long long)p.batch * groups;
     const int st = p.ws - p.ov;
     const int HW = p.H * p.W;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
@@ -438,10 +440,18 @@ __global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
     // (their stores are suppressed)
     auto geom = [&](long long it, int& pair_, int& win_, bool& active) TPIV_LAMBDA_INLINE {
         const int w_ = (int)(threadIdx.x / WS);
-        pair_ = (int)(it / groups);
-        const int raw = (int)(it % groups) * WPW + w_;
-        active = raw < N;
-        win_ = active ? raw : N - 1;
+        if constexpr (LIST) {
+            const long long li = it * WPW + w_;
+            active = li < listed;
+            const int e_ = p.fb_list[active ? li : listed - 1];
+            pair_ = e_ / N;
+            win_ = e_ % N;
+        } else {
+            pair_ = (int)(it / groups);
+            const int raw = (int)(it % groups) * WPW + w_;
+            active = raw < N;
+            win_ = active ? raw : N - 1;
+        }
     };
     uint32_t da[NDW], db[NDW];
     auto fetch = [&](long long it) TPIV_LAMBDA_INLINE {
@@ -677,6 +687,15 @@ __global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
 }
 
 template <int WS>
+__global__ __launch_bounds__(64, 2) void xcorr_f64_tile_kernel(PassParams p) {
+    xcorr_f64_tile_body<WS, false>(p);
+}
+template <int WS>
+__global__ __launch_bounds__(64, 2) void xcorr_f64_tile_list_kernel(PassParams p) {
+    xcorr_f64_tile_body<WS, true>(p);
+}
+
+template <int WS>
 static hipError_t launch_f64_tile(const PassParams& p, int n_cu, hipStream_t stream) {
     using G = F64TileGeo<WS>;
     const long long groups = ((long long)p.n_rows * p.n_cols + G::WPW - 1) / G::WPW;
@@ -690,14 +709,20 @@ static hipError_t launch_f64_tile(const PassParams& p, int n_cu, hipStream_t str
 
 }  // namespace
 
-// the 64x64 float64 transform for the windows of PassParams::fb_list (their number is known on the device only: the grid
-// is the resident set, workgroups without a window leave at once)
+// the float64 transform for the windows of PassParams::fb_list (their number is known on the device only: the grid is the
+// resident set, workgroups without a window leave at once)
 hipError_t launch_xcorr_f64_list(const PassParams& p, int n_cu, hipStream_t stream) {
-    if (p.ws != 64 || p.fb_list == nullptr || p.fb_count == nullptr) return hipErrorInvalidValue;
+    if (p.fb_list == nullptr || p.fb_count == nullptr) return hipErrorInvalidValue;
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
-    long long blocks = items < (long long)n_cu * 4 ? items : (long long)n_cu * 4;
+    const int per_cu = p.ws == 32 ? 8 : (p.ws == 64 ? 4 : 1);
+    long long blocks = items < (long long)n_cu * per_cu ? items : (long long)n_cu * per_cu;
     blocks = (blocks + 7) / 8 * 8;
-    hipLaunchKernelGGL((xcorr_f64_list_kernel<64>), dim3((unsigned)blocks), dim3(128), 0, stream, p);
+    switch (p.ws) {
+        case 32: hipLaunchKernelGGL((xcorr_f64_tile_list_kernel<32>), dim3((unsigned)blocks), dim3(64), 0, stream, p); break;
+        case 64: hipLaunchKernelGGL((xcorr_f64_list_kernel<64>), dim3((unsigned)blocks), dim3(128), 0, stream, p); break;
+        case 128: hipLaunchKernelGGL((xcorr_f64_list_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -1189,20 +1189,18 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
 //   * the arg-max, if exactly one cell lies within EXACT_BAND x (max - min) of the maximum,
 //   * up to EXACT_MAX_SECOND cells outside the exclusion zone of B:346-358 within the band of their maximum,
 //   * up to EXACT_MAX_MIN cells within the band of the minimum;
-// exact_refine_kernel then evaluates those cells (and the arg-max's flat-index neighbours) as exact integer sums of the
-// uint8 windows.  The float32 transform's error on a 64x64 map is ~3e-7 of the map's range (tests/test_exact_scheme.py
-// measures it; the band leaves two orders of magnitude), and the refinement re-checks every decision on the exact values.
+// xcorr_exact_refine_kernel then evaluates those cells (and the arg-max's flat-index neighbours) as exact integer sums of the
+// uint8 windows, and re-checks every decision on the exact values.
 // A window with more cells inside a band than the record holds, or a flat / NaN map, is marked undecided (-1): it goes
 // through the float64 transform (xcorr_f64_split_kernel<64, true>).  Dead windows (B:513: zero mean) are marked -2.
 // One window per wavefront (WS = 64): every ballot below spans exactly the window.
-constexpr float EXACT_BAND = 3.0e-5f;
-constexpr int EXACT_MAX_SECOND = 3, EXACT_MAX_MIN = 4;
+// (EXACT_BAND, EXACT_MIN_CONTRAST, EXACT_MAX_SECOND / _MIN: piv_kernels.h)
 
 // columns of map row ys (fftshift layout) that B:346-358 zeroes around the first peak m: q = clamp(m + i + WS j),
 // |i|, |j| <= wv -- in row y' the columns mx+i (j = y'-my), mx+i+WS (j = y'-my+1), mx+i-WS (j = y'-my-1), plus the clamps
 template <int WS>
 __device__ __forceinline__ unsigned long long exclusion_row_mask(int m, int ys, int wv) {
-    static_assert(WS == 64, "one 64-bit mask per row");
+    static_assert(WS <= 64, "one 64-bit mask per row");
     const int my_ = m / WS, mx_ = m % WS, KD = WS * WS;
     const int dj = ys - my_;
     unsigned long long ex = 0ull;
@@ -1222,9 +1220,17 @@ __device__ __forceinline__ unsigned long long exclusion_row_mask(int m, int ys, 
 }
 
 template <int WS>
-__device__ __forceinline__ void peak_candidates(const PassParams& p, const float (&row)[WS], float* tile, int r, bool dead,
-                                                size_t fidx) {
-    static_assert(WS == 64, "one window per wavefront");
+__device__ __forceinline__ void peak_candidates(const PassParams& p, const float (&row)[WS], float* tile, int w, int r,
+                                                bool active, bool dead, size_t fidx) {
+    static_assert(WS == 32 || WS == 64, "one or two windows per wavefront");
+    // ballot over the lanes of this lane's window (WS = 32: the two windows of the wavefront decide independently --
+    // everything below is per-lane data and predicated control flow, uniform only within a window)
+    auto wballot = [&](bool pred) TPIV_LAMBDA_INLINE {
+        const unsigned long long b_ = __ballot(pred);
+        if constexpr (WS == 64) return b_;
+        else return (b_ >> (w * 32)) & 0xffffffffull;
+    };
+    float* const my_row = tile + w * WS;              // one parked map row per window
     const int ys = (r + WS / 2) % WS;
     float rmin = 3.4e38f, rmax = -3.4e38f;
 #pragma unroll
@@ -1234,26 +1240,26 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
     }
     const float cmin = grp_min<WS>(rmin);
     const float gmax = grp_reduce<WS>(rmax, [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); });
-    const float band = EXACT_BAND * (gmax - cmin);
+    const float band = p.exact_band * (gmax - cmin);
     bool open = !(band > 0.0f);                       // flat or NaN map
-    // map row of lane rl (fftshift column order) through LDS: lane r receives column r
+    // map row of lane rl of the window (fftshift column order) through LDS: lane r receives column r
     auto park = [&](int rl) TPIV_LAMBDA_INLINE {
         wave_sync();
         if (r == rl) {
 #pragma unroll
-            for (int k = 0; k < WS; ++k) tile[(k + WS / 2) % WS] = row[k];
+            for (int k = 0; k < WS; ++k) my_row[(k + WS / 2) % WS] = row[k];
         }
         wave_sync();
-        return tile[r];
+        return my_row[r];
     };
     auto row_of_lane = [](int rl) TPIV_LAMBDA_INLINE { return (rl + WS / 2) % WS; };
     // ---- arg-max: one row, one column inside the band, or undecided
     int m = 0;
     {
-        const unsigned long long rows = __ballot(rmax >= gmax - band);
+        const unsigned long long rows = wballot(rmax >= gmax - band);
         open = open || __popcll(rows) != 1;
         const int rl = rows ? (int)__builtin_ctzll(rows) : 0;
-        const unsigned long long cols = __ballot(park(rl) >= gmax - band);
+        const unsigned long long cols = wballot(park(rl) >= gmax - band);
         open = open || __popcll(cols) != 1;
         m = row_of_lane(rl) * WS + (cols ? (int)__builtin_ctzll(cols) : 0);
     }
@@ -1273,54 +1279,62 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
             smax = cnd > smax ? cnd : smax;
         });
         const int sall = grp_reduce<WS>(smax, [](int a, int b) TPIV_LAMBDA_INLINE { return a > b ? a : b; });
-        if (sall >= 0) {                               // (wave-uniform)
-            const float thr = __int_as_float(sall) - band;
-            unsigned long long rows = __ballot(smax >= 0 && __int_as_float(smax) >= thr);
-            open = open || __popcll(rows) > EXACT_MAX_SECOND;
-            int ns = 0;
-            for (int it = 0; it < EXACT_MAX_SECOND && rows; ++it) {
-                const int rl = (int)__builtin_ctzll(rows);
-                rows &= rows - 1;
-                const int yr = row_of_lane(rl);
-                const unsigned long long exr = exclusion_row_mask<WS>(m, yr, wv);
-                unsigned long long cols = __ballot(__fsub_rn(park(rl), cmin) >= thr) & ~exr;
-                while (cols) {
-                    const int q = yr * WS + (int)__builtin_ctzll(cols);
-                    cols &= cols - 1;
-                    s[0] = ns == 0 ? q : s[0];
-                    s[1] = ns == 1 ? q : s[1];
-                    s[2] = ns == 2 ? q : s[2];
-                    ++ns;
-                }
+        const float thr = __int_as_float(sall) - band;
+        unsigned long long rows = sall >= 0 ? wballot(smax >= 0 && __int_as_float(smax) >= thr) : 0ull;
+        open = open || __popcll(rows) > EXACT_MAX_SECOND;
+        int ns = 0;
+        for (int it = 0; it < EXACT_MAX_SECOND; ++it) {
+            if (__ballot(rows != 0ull) == 0ull) break;          // (no window of the wavefront has a row left)
+            const bool on = rows != 0ull;
+            const int rl = on ? (int)__builtin_ctzll(rows) : 0;
+            rows &= rows - 1;
+            const int yr = row_of_lane(rl);
+            const unsigned long long exr = exclusion_row_mask<WS>(m, yr, wv);
+            unsigned long long cols = wballot(__fsub_rn(park(rl), cmin) >= thr) & ~exr;
+            cols = on ? cols : 0ull;
+            for (int k = 0; k < WS; ++k) {                      // (at most a handful of bits are set)
+                if (__ballot(cols != 0ull) == 0ull) break;
+                const bool has = cols != 0ull;
+                const int q = yr * WS + (has ? (int)__builtin_ctzll(cols) : 0);
+                cols &= cols - 1;
+                s[0] = (has && ns == 0) ? q : s[0];
+                s[1] = (has && ns == 1) ? q : s[1];
+                s[2] = (has && ns == 2) ? q : s[2];
+                ns += has ? 1 : 0;
             }
-            open = open || ns > EXACT_MAX_SECOND;
         }
+        open = open || ns > EXACT_MAX_SECOND;
     }
     // ---- minimum: the cells within the band of it (only the VALUE of the exact minimum is needed)
     int n[EXACT_MAX_MIN] = {-1, -1, -1, -1};
     {
         const float thr = cmin + band;
-        unsigned long long rows = __ballot(rmin <= thr);
+        unsigned long long rows = wballot(rmin <= thr);
         open = open || __popcll(rows) > EXACT_MAX_MIN;
         int nn = 0;
-        for (int it = 0; it < EXACT_MAX_MIN && rows; ++it) {
-            const int rl = (int)__builtin_ctzll(rows);
+        for (int it = 0; it < EXACT_MAX_MIN; ++it) {
+            if (__ballot(rows != 0ull) == 0ull) break;
+            const bool on = rows != 0ull;
+            const int rl = on ? (int)__builtin_ctzll(rows) : 0;
             rows &= rows - 1;
             const int yr = row_of_lane(rl);
-            unsigned long long cols = __ballot(park(rl) <= thr);
-            while (cols) {
-                const int q = yr * WS + (int)__builtin_ctzll(cols);
+            unsigned long long cols = wballot(park(rl) <= thr);
+            cols = on ? cols : 0ull;
+            for (int k = 0; k < WS; ++k) {
+                if (__ballot(cols != 0ull) == 0ull) break;
+                const bool has = cols != 0ull;
+                const int q = yr * WS + (has ? (int)__builtin_ctzll(cols) : 0);
                 cols &= cols - 1;
-                n[0] = nn == 0 ? q : n[0];
-                n[1] = nn == 1 ? q : n[1];
-                n[2] = nn == 2 ? q : n[2];
-                n[3] = nn == 3 ? q : n[3];
-                ++nn;
+                n[0] = (has && nn == 0) ? q : n[0];
+                n[1] = (has && nn == 1) ? q : n[1];
+                n[2] = (has && nn == 2) ? q : n[2];
+                n[3] = (has && nn == 3) ? q : n[3];
+                nn += has ? 1 : 0;
             }
         }
         open = open || nn > EXACT_MAX_MIN;
     }
-    if (r == 0) {
+    if (r == 0 && active) {
         const int m_out = dead ? -2 : (open ? -1 : m);
         auto pack = [](int lo_, int hi_) TPIV_LAMBDA_INLINE { return ((unsigned)lo_ & 0xffffu) | ((unsigned)hi_ << 16); };
         uint4 rec;
@@ -1651,7 +1665,7 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
             const bool active_e = win_raw_e < N;
             const int win_e = active_e ? win_raw_e : N - 1;
             const size_t fidx_e = (size_t)pair_e * N + win_e;
-            if constexpr (CAND) peak_candidates<WS>(p, crow, tile, r_e, dead, fidx_e);
+            if constexpr (CAND) peak_candidates<WS>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e);
             else peak_analysis<WS, PLANAR, FASTN>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e, end_scale);
         } else {
             peak_analysis<WS, PLANAR, FASTN>(p, crow, tile, w, r, active, dead, fidx, end_scale);
@@ -1780,11 +1794,12 @@ static hipError_t launch_tile(const PassParams& p_in, int n_cu, hipStream_t stre
 template <int WS>
 hipError_t launch_xcorr_tile_cand_ws(const PassParams& p_in, int n_cu, hipStream_t stream) {
     using G = TileGeo<WS>;
-    static_assert(G::WPW == 1, "one window per wavefront");
     PassParams p = p_in;
-    const long long items = (long long)p.batch * p.n_rows * p.n_cols;
+    const int N = p.n_rows * p.n_cols;
+    const long long groups = (N + G::WPW - 1) / G::WPW;
+    const long long items = (long long)p.batch * groups;
     if (items <= 0 || items >= (1ll << 31) - 64 || p.cand == nullptr) return hipErrorInvalidValue;
-    fast_div_setup((unsigned)(p.n_rows * p.n_cols), p.groups_magic, p.groups_shift);
+    fast_div_setup((unsigned)groups, p.groups_magic, p.groups_shift);
     fast_div_setup((unsigned)p.n_cols, p.ncols_magic, p.ncols_shift);
     long long blocks = items < (long long)n_cu * 64 ? items : (long long)n_cu * 64;
     blocks = (blocks + 7) / 8 * 8;

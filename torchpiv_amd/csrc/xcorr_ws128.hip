@@ -6,6 +6,9 @@ namespace tpiv {
 hipError_t launch_xcorr_big128_pass1(const PassParams& p, int n_cu, hipStream_t stream) {
     return launch_xcorr_big128(p, n_cu, stream);
 }
+hipError_t launch_xcorr_cand_ws128(const PassParams& p, int n_cu, hipStream_t stream) {
+    return launch_xcorr_big128(p, n_cu, stream, true);
+}
 hipError_t launch_peak_debug_ws128(const PassParams& p, const float* maps, int n_maps, hipStream_t stream) {
     return launch_peak_debug_big(p, maps, n_maps, stream);
 }

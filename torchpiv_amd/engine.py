@@ -82,10 +82,11 @@ def spline_matrix(xc: np.ndarray, xf: np.ndarray) -> np.ndarray:
     return A
 
 
-def pass1(a, b, ws, ov, val_ratio=1.2, val_win=3, precision="f64"):
+def pass1(a, b, ws, ov, val_ratio=1.2, val_win=3, precision="exact"):
     """Device part of extended_search_area_piv(validate=True). Returns u, v (float64) and
     invalid (uint8), each [batch, n_rows, n_cols], on the frames' device.
-    precision: "f64" (default, like OfflinePIV: float64 transforms as in PIVbackend.py:513-514), "reference"
+    precision: "exact" (default, like OfflinePIV: exact integer correlation sums at the cells that reach the result, 64x64
+    windows -- csrc/xcorr_exact.hip; other sizes run as "f64"), "f64" (float64 transforms as in PIVbackend.py:513-514), "reference"
     (the same kernel here) or "fast" (float32 transforms, about 1e-6 px from the reference; opt-in)."""
     a, b = _frames(a, b)
     B, H, W = a.shape
@@ -117,10 +118,10 @@ def predict(mode, Ay, Ax, u_c, v_c, inv_c):
     return outs
 
 
-def iterate(mode, a, b, ws, ov, u0, v0, u2, v2, val_ratio=1.2, val_win=3, want_raw=False, precision="f64"):
+def iterate(mode, a, b, ws, ov, u0, v0, u2, v2, val_ratio=1.2, val_win=3, want_raw=False, precision="exact"):
     """Device part of piv_iteration_{DWS,CWS}.__call__ after the predictor.  Shifted passes run in float32 like the
     reference's (B:249-257) at every precision; precision="reference" additionally keeps the reference's operation
-    order in the CWS bilinear sampling (bit-identical staged windows), "f64" (default) and "fast" use the lerp form."""
+    order in the CWS bilinear sampling (bit-identical staged windows), "exact" (default), "f64" and "fast" use the lerp form."""
     prec = _precision(precision)
     a, b = _frames(a, b)
     if mode == "CWS_Fast" and u2 is None:        # B:599-675: the shift is u0 / 2 inside the window; no u2 field
@@ -280,7 +281,7 @@ class Plan:
     pairs resident on one GPU.  Owns the device workspace; `run` only enqueues kernels."""
 
     def __init__(self, H, W, ws, ov, n_pass=1, mode="CWS", pass_scale=2.0, val_ratio=1.2,
-                 val_win=3, max_batch=1, device=None, precision="f64"):
+                 val_win=3, max_batch=1, device=None, precision="exact"):
         if not torch.cuda.is_available():
             raise RuntimeError("torchpiv_amd.Plan needs a ROCm device (there is no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None \
@@ -358,6 +359,13 @@ class Plan:
         n = C.c_longlong()
         check(lib.tpiv_plan_exact_fallbacks(self._h, C.byref(n)))
         return n.value
+
+    def exact_timing(self):
+        """precision="exact": pass1_xcorr of the last get_timing() taken apart (mean ms): the float32 locating pass, the exact
+        refinement, the float64 pass of the undecided windows, finalize."""
+        arr = (C.c_double * 4)()
+        check(lib.tpiv_plan_exact_timing(self._h, arr))
+        return dict(zip(("locate_f32", "refine_exact", "undecided_f64", "finalize"), list(arr)))
 
     def debug_predict(self, p, u_c, v_c, inv_c):
         """Test hook: the plan's banded predictor of pass p on given coarse fields."""

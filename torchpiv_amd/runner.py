@@ -236,7 +236,7 @@ def run_folder(folder: str, device: str, file_fmt: str, wind_size: int, overlap:
                multipass_mode: str = "CWS", dt: int = 1, scale: float = 1.0, multipass_scale: float = 2.0,
                folder_mode: str = "pairs", save_opt: str = "Dont save", save_dir: str = "Out",
                batch_size: int = 32, on_pair=None, distributed: bool = False, stats_on_device: bool = True,
-               precision: str = "f64", streaming_stats: bool = False):
+               precision: str = "exact", streaming_stats: bool = False):
     """Process a folder like PIVWorker.run.  save_opt: "Dont save" | "Save all binary" |
     "Save all text" | "Save statistics" (anything but "Dont save" also writes the statistics table).
     streaming_stats: running accumulators instead of the stacked fields (EnsembleStats(streaming=True): O(1) memory in
