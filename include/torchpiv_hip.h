@@ -63,14 +63,15 @@ enum tpiv_precision {
                                 TPIV_PREC_REFERENCE), shifted passes in float32 with the float64 epilogue -- with
                                 the cheaper operation order of TPIV_PREC_FAST in the shifted passes (row lerps +
                                 column lerp of the CWS sample: float32 rounding differences, <= 1e-4 grey levels,
-                                against B:187-193).  The default of the Python drop-in (OfflinePIV). */
+                                against B:187-193). */
     TPIV_PREC_EXACT = 3      /* as TPIV_PREC_F64, with the map cells that reach the result of pass 1 (arg-max, its
                                 neighbours, second peak, minimum: B:383-411, B:518) evaluated as EXACT integer
                                 correlation sums of the uint8 windows instead of through a float64 FFT: a float32
                                 FFT pass locates the cells inside an error band, windows it cannot decide run the
-                                float64 transform (xcorr_exact.hip).  64x64 windows; other sizes run as
-                                TPIV_PREC_F64.  Within ~1e-14 px of the reference's float64 pass 1 (whose own
-                                transform rounding is the difference). */
+                                float64 transform (xcorr_exact.hip).  32x32, 64x64 and 128x128 first-pass windows;
+                                other sizes run as TPIV_PREC_F64.  Within ~1e-14 px of the reference's float64
+                                pass 1 (whose own transform rounding is the difference).  The default of the Python
+                                drop-in (OfflinePIV). */
 };
 
 typedef struct tpiv_plan tpiv_plan;
@@ -253,11 +254,11 @@ int tpiv_plan_set_timing(tpiv_plan* plan, int enable);
  * the runs recorded since the last call into avg_ms[0..n_slots) and the number of runs into
  * n_runs, then clears the record.  n_slots must be 2*n_pass - 1. */
 int tpiv_plan_get_timing(tpiv_plan* plan, double* avg_ms, int n_slots, int* n_runs);
-/* TPIV_PREC_EXACT plans with 64x64 first-pass windows: the number of windows of the LAST tpiv_plan_run whose first pass
+/* TPIV_PREC_EXACT plans with 32x32 / 64x64 / 128x128 first-pass windows: the number of windows of the LAST tpiv_plan_run whose first pass
  * went through the float64 transform (undecided by the float32 locating pass).  Waits for the device.  TPIV_EINVAL for
  * other plans or before the first run.  (Diagnostics: bench.py reports the share.) */
 int tpiv_plan_exact_fallbacks(tpiv_plan* plan, long long* n_windows);
-/* TPIV_PREC_EXACT plans with 64x64 first-pass windows: slot 0 of tpiv_plan_get_timing taken apart, as of the last call of
+/* The same plans: slot 0 of tpiv_plan_get_timing taken apart, as of the last call of
  * that function: ms4 = mean milliseconds of {float32 locating pass, exact refinement, float64 pass of the undecided
  * windows, finalize}. */
 int tpiv_plan_exact_timing(const tpiv_plan* plan, double* ms4);

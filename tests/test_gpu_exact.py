@@ -129,3 +129,28 @@ def test_exact_other_sizes_fallback_share(eng, ws, size, batch):
     print(f"ws {ws}: {n_fb} of {n_win} windows through the float64 transform")
     assert n_fb <= n_win // 20
     assert float((ue - uf).abs().max()) < TOL_F64 and float((ve - vf).abs().max()) < TOL_F64 and torch.equal(ie, i_f)
+
+
+
+def test_exact_on_windows_built_to_break_the_locating_pass(eng):
+    """tools/research/exact_band.py's families -- nearly orthogonal patterns (map range 1e-5 of the transform's scale), one
+    bright pixel on a pedestal, two grey levels, saturated frames with a few dark pixels, sinusoids, ramps: whatever the
+    float32 locating pass makes of them, the result must be the float64 kernel's (the contrast guard and the re-checks of
+    the refinement send the hopeless ones to the float64 transform)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "research"))
+    import exact_band
+    for name, (a, b) in exact_band.families(n=64, seed=1).items():
+        A, B = dev(a), dev(b)
+        plan = eng.Plan(64, 64, 64, 0, n_pass=1, max_batch=a.shape[0], precision="exact")
+        ue, ve, ie = plan.run(A, B)
+        n_fb = plan.exact_fallbacks()
+        uf, vf, i_f = eng.pass1(A, B, 64, 0, precision="f64")
+        d = max(float((ue - uf).abs().max()), float((ve - vf).abs().max()))
+        print(f"  {name}: {n_fb} of {a.shape[0]} through the float64 transform, max |exact - f64| {d:.1e} px")
+        assert d < TOL_F64 and torch.equal(ie, i_f), name
+        if name.startswith("particles"):
+            assert n_fb <= 2, (name, n_fb)
+        if name == "checkerboard vs stripes":
+            assert n_fb == a.shape[0], (name, n_fb)          # map range 8e-6 of the scale: below the contrast guard, all of them

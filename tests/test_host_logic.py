@@ -548,3 +548,4 @@ _ZkernelB:
 """
     assert len(C.check(bad)[0]) == 1 and C.check(good) == ([], 2)
     assert C.main("xcorr_f64") == 0
+    assert C.main("xcorr_exact") == 0          # the refinement kernel's single ds_read_b32 spans

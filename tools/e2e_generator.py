@@ -64,7 +64,7 @@ def rate3(make_gen, n, trials=3):
     return sorted(rs)[len(rs) // 2], k, [round(r_) for r_ in rs], cpu
 
 
-def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True, budget_s=None, precision="f64", reps=8):
+def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True, budget_s=None, precision="exact", reps=8):
     """Rates in pairs/s per case; `files` adds the BMP cases (skipped once `budget_s` seconds are spent).  Every case
     streams n * reps pairs (the n distinct pairs `reps` times over: 128 pairs alone last some 20 ms, which measures the
     pipeline's fill and drain, not its rate); the file cases hard-link the n pairs' files under n * reps names."""
@@ -125,4 +125,4 @@ def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True,
 if __name__ == "__main__":
     main(int(sys.argv[1]) if len(sys.argv) > 1 else 128, workers=int(sys.argv[2]) if len(sys.argv) > 2 else 0,
          read_threads=int(sys.argv[3]) if len(sys.argv) > 3 else 0,
-         precision=sys.argv[4] if len(sys.argv) > 4 else "f64")
+         precision=sys.argv[4] if len(sys.argv) > 4 else "exact")

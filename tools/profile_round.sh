@@ -1,13 +1,14 @@
 #!/bin/bash
 # Round profile on the GPU box.  Everything the bench line quotes can be re-derived from these outputs:
-#   bench_n1.json               the driver's command (configs[1], float64 pass 1 = the headline, with the all-float32
-#                               run, the end_to_end block, live PMC counters and the CPU baseline)
+#   bench_n1.json               the driver's command (configs[1] at the default precision "exact" = the headline, with the
+#                               float64-FFT and all-float32 runs beside it, the end_to_end block, live PMC counters and the
+#                               CPU baseline)
 #   bench_n1_reference.json     the same at precision "reference" (reference-order CWS staging)
 #   bench_n1_config2.json       configs[2] stream
 #   bench_gloo{2,4}_*.json      2- / 4-rank gloo launch rehearsals of --gpus N (the ranks time-slice ONE GPU: not a measurement)
 #   bench_soak2000.json         2000 timed steps of the headline workload
 #   rocprofv3_kernel_stats.csv  rocprofv3 --kernel-trace --stats of the headline command
-#   other_configs/              configs[3] / configs[4] at both precisions: quick_bench lines, kernel stats, SQ counters
+#   other_configs/              configs[3] / configs[4] at the three precisions: quick_bench lines, kernel stats, SQ counters
 #   stamps_f64.txt              per-phase cycle shares of the float64 pass-1 kernel (stamped diagnostic build)
 #   files_profile.txt           where the file path spends its time
 #   bench_e2e_gloo2.json        the GENERATOR path sharded over 2 gloo ranks on the one GPU (bench.py --gpus 2 --e2e): launch,
@@ -46,8 +47,10 @@ cfg() {   # name, quick_bench args
 }
 cfg cfg3_4096_32_16_8_fast --size 4096 --ws 32 --passes 3 --mode CWS --batch 16
 cfg cfg3_4096_32_16_8_f64 --size 4096 --ws 32 --passes 3 --mode CWS --batch 16 --precision f64
+cfg cfg3_4096_32_16_8_exact --size 4096 --ws 32 --passes 3 --mode CWS --batch 16 --precision exact
 cfg cfg4_128_64_fast --size 2048 --ws 128 --passes 2 --mode CWS --batch 64
 cfg cfg4_128_64_f64 --size 2048 --ws 128 --passes 2 --mode CWS --batch 64 --precision f64
+cfg cfg4_128_64_exact --size 2048 --ws 128 --passes 2 --mode CWS --batch 64 --precision exact
 TPIV_LIB=tools/diag/libtorchpiv_hip_stamps.so python3 tools/stamp_f64.py > $OUT/stamps_f64.txt 2> $OUT/stamps.err || tail -3 $OUT/stamps.err
 python3 tools/dev/files_profile.py 8 8 8 spots 2 32 2> /dev/null | grep -v amdgpu.ids > $OUT/files_profile.txt
 TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --e2e --e2e-pairs 64 > $OUT/bench_e2e_gloo2.json 2> $OUT/e2e_g2.err || tail -3 $OUT/e2e_g2.err

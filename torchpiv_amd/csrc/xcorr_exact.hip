@@ -40,6 +40,33 @@ struct XGeo {
 };
 constexpr int XCELLS = 5 + EXACT_MAX_SECOND + EXACT_MAX_MIN;      // cells a window can ask for
 
+// N consecutive dwords of a parked row as N single ds_read_b32: left to itself the backend pairs them into ds_read2_b32,
+// which deliver a fifth of the bytes per clock (tools/micro/lds_pair.hip, DESIGN.md 9 "Paired LDS accesses") -- and this
+// kernel is nothing but LDS reads and dot products.  Hand-issued reads become usable behind the wait only; the asm
+// statements are volatile and tie every destination to the wait (tools/check_lds_inflight.py walks this unit too).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int OFF>
+__device__ __forceinline__ uint32_t lds_rd32(unsigned addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_landed() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_tie(uint32_t& v) { asm volatile("" : "+v"(v)); }
+#else       // host pass of the translation unit: the kernels' bodies are parsed, never run
+template <int OFF>
+__host__ __device__ inline uint32_t lds_rd32(unsigned) { return 0u; }
+__host__ __device__ inline void lds_landed() {}
+__host__ __device__ inline void lds_tie(uint32_t&) {}
+#endif
+template <int N>
+__device__ __forceinline__ void read_span(const uint32_t* src, uint32_t (&w)[N]) {
+    const unsigned addr = (unsigned)(uintptr_t)src;
+    static_for<0, N>([&](auto ic) TPIV_LAMBDA_INLINE { w[decltype(ic)::value] = lds_rd32<4 * decltype(ic)::value>(addr); });
+    lds_landed();
+    static_for<0, N>([&](auto ic) TPIV_LAMBDA_INLINE { lds_tie(w[decltype(ic)::value]); });
+}
+
 // Everything below is per-lane data with predicated control flow: for 32x32 the two windows of a wavefront take their
 // decisions independently.  (64x64: one window per wavefront; 128x128: one window per workgroup of two wavefronts, partial
 // sums joined through LDS behind ONE barrier that both wavefronts reach or neither does.)
@@ -66,6 +93,16 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     const bool valid = in_chunk < chunk && it_raw < total;
     const long long it = valid ? it_raw : 0;
 
+    // ---- window rows: lane = row.  Issued together with the candidate record, IN FRONT of the decisions that depend on
+    //      it: the kernel is a chain of memory latencies (one window per wavefront lifetime), and the rows' addresses do not
+    //      depend on the record.  (The 0.1 % of windows that do not go load their rows for nothing: in-bounds, unused.)
+    const unsigned itu = (unsigned)it;                       // (total < 2^31: 32-bit divisions)
+    const int pair = (int)(itu / (unsigned)N), win = (int)(itu - (unsigned)pair * (unsigned)N);
+    const int st = p.ws - p.ov;
+    const size_t off = (size_t)pair * p.H * p.W + (size_t)((win / p.n_cols) * st + row) * p.W + (size_t)(win % p.n_cols) * st;
+    uint32_t a[NDW], b[NDW];
+    load_dwords<NDW>(p.A + off, a);
+    load_dwords<NDW>(p.B + off, b);
     const uint4 rec = p.cand[it];
     auto lo16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v & 0xffffu); };
     auto hi16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v >> 16); };
@@ -102,85 +139,113 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
         q = r0 == 11 ? hi16(rec.w) : q;
     }
 
-    // ---- window rows: lane = row (windows that do not go load their rows too: in-bounds, unused)
-    const int pair = (int)(it / N), win = (int)(it % N);
-    const int st = p.ws - p.ov;
-    const size_t off = (size_t)pair * p.H * p.W + (size_t)((win / p.n_cols) * st + row) * p.W + (size_t)(win % p.n_cols) * st;
-    uint32_t a[NDW], b[NDW];
-    load_dwords<NDW>(p.A + off, a);
-    load_dwords<NDW>(p.B + off, b);
-    unsigned sa = 0, sb = 0, saa = 0, sbb = 0;          // sums and sums of squares: < 2^22 and < 2^30 per window
+    // per-lane partial sums P[0..11]: S at the requested cells, P[12..15]: window sums and sums of squares (< 2^22 / 2^30 per window)
+    unsigned P[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) P[k] = 0u;
 #pragma unroll
     for (int i = 0; i < NDW; ++i) {
-        sa = __builtin_amdgcn_sad_u8(a[i], 0u, sa);
-        sb = __builtin_amdgcn_sad_u8(b[i], 0u, sb);
-        saa = __builtin_amdgcn_udot4(a[i], a[i], saa, false);
-        sbb = __builtin_amdgcn_udot4(b[i], b[i], sbb, false);
+        P[12] = __builtin_amdgcn_sad_u8(a[i], 0u, P[12]);
+        P[13] = __builtin_amdgcn_sad_u8(b[i], 0u, P[13]);
+        P[14] = __builtin_amdgcn_udot4(a[i], a[i], P[14], false);
+        P[15] = __builtin_amdgcn_udot4(b[i], b[i], P[15], false);
         rows_b[row * XP + i] = b[i];
         rows_b[row * XP + NDW + i] = b[i];
     }
-    auto uadd = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x + y; };
-    sa = grp_reduce<G::GROUP>(sa, uadd);
-    sb = grp_reduce<G::GROUP>(sb, uadd);
-    saa = grp_reduce<G::GROUP>(saa, uadd);
-    sbb = grp_reduce<G::GROUP>(sbb, uadd);
     if constexpr (G::PARTS == 2) __syncthreads();       // the other wavefront's rows are parked
     else wave_sync();
 
-    // ---- S at every requested cell; lane j of the window keeps S(q_j)
-    unsigned S = 0;
-    for (int c = 0; c < XCELLS; ++c) {
+    // ---- S at every requested cell
+    static_for<0, XCELLS>([&](auto cc) TPIV_LAMBDA_INLINE {
+        constexpr int c = decltype(cc)::value;
         int qc = __builtin_amdgcn_readlane(q, c);
+        bool any = qc >= 0;
         if constexpr (G::WPW == 2) {
             const int q1 = __builtin_amdgcn_readlane(q, 32 + c);
-            if (qc < 0 && q1 < 0) continue;
+            any = any || q1 >= 0;
             qc = g ? q1 : qc;
-        } else {
-            if (qc < 0) continue;
         }
-        const bool on = qc >= 0;
-        const int qq = on ? qc : 0;
-        const int dy = qq / W - W / 2, dx = qq % W - W / 2;
-        const int brow = (row + dy) & (W - 1), bx = dx & (W - 1);
-        const uint32_t* src = rows_b + brow * XP + (bx >> 2);
-        const unsigned sh = (unsigned)(bx & 3);
-        uint32_t w[NDW + 1];
+        if (any) {                                      // (wave-uniform)
+            const bool on = qc >= 0;
+            const int qq = on ? qc : 0;
+            const int dy = qq / W - W / 2, dx = qq % W - W / 2;
+            const int brow = (row + dy) & (W - 1), bx = dx & (W - 1);
+            const uint32_t* src = rows_b + brow * XP + (bx >> 2);
+            const unsigned sh = (unsigned)(bx & 3);
+            uint32_t w[NDW + 1];
+            read_span<NDW + 1>(src, w);
+            unsigned acc = 0;
 #pragma unroll
-        for (int i = 0; i <= NDW; ++i) w[i] = src[i];
-        unsigned acc = 0;
+            for (int i = 0; i < NDW; ++i) acc = __builtin_amdgcn_udot4(a[i], __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh), acc, false);
+            P[c] = on ? acc : 0u;
+        }
+    });
+    // ---- ONE transposing reduction of the 16 partials over the window's lanes (instead of 16 butterflies): two halving
+    //      steps inside the quads -- lane l keeps the values 4j + (l & 3) --, then plain sums over the quads of a row
+    //      (row rotations by 8 and 4 keep l & 3), over the rows (permlane swaps)
+    unsigned T[4];
+    {
+        const bool odd = lane & 1, hi = lane & 2;
+        unsigned Q[8];
 #pragma unroll
-        for (int i = 0; i < NDW; ++i) acc = __builtin_amdgcn_udot4(a[i], __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh), acc, false);
-        acc = grp_reduce<G::GROUP>(acc, uadd);
-        S = (r0 == c && on) ? acc : S;
+        for (int j = 0; j < 8; ++j) {
+            const unsigned keep = odd ? P[2 * j + 1] : P[2 * j], send = odd ? P[2 * j] : P[2 * j + 1];
+            Q[j] = keep + (unsigned)dpp_i<DPP_XOR1>((int)send);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned keep = hi ? Q[2 * j + 1] : Q[2 * j], send = hi ? Q[2 * j] : Q[2 * j + 1];
+            unsigned t = keep + (unsigned)dpp_i<DPP_XOR2>((int)send);
+            t += (unsigned)dpp_i<0x128>((int)t);        // row_ror:8
+            t += (unsigned)dpp_i<0x124>((int)t);        // row_ror:4
+            if constexpr (G::GROUP >= 32) {
+                auto r = __builtin_amdgcn_permlane16_swap(t, t, false, false);
+                t = r[0] + r[1];
+            }
+            if constexpr (G::GROUP >= 64) {
+                auto r = __builtin_amdgcn_permlane32_swap(t, t, false, false);
+                t = r[0] + r[1];
+            }
+            T[j] = t;
+        }
     }
+    // lane j < 12 of the window: S(q_j) = value j = T[j >> 2]; lanes 12..15: the four window sums = T[3]
+    unsigned S = r0 < 4 ? T[0] : (r0 < 8 ? T[1] : (r0 < 12 ? T[2] : T[3]));
     if constexpr (G::PARTS == 2) {
         // join the two halves of the window: lanes 0..11 carry the partial S, lanes 12..15 the partial window sums
-        unsigned mine = S;
-        mine = lane == 12 ? sa : mine;
-        mine = lane == 13 ? sb : mine;
-        mine = lane == 14 ? saa : mine;
-        mine = lane == 15 ? sbb : mine;
-        if (lane < 16) joined[wave][lane] = mine;
+        if (lane < 16) joined[wave][lane] = S;
         __syncthreads();
         S = lane < 16 ? joined[0][lane] + joined[1][lane] : 0u;
-        sa = joined[0][12] + joined[1][12];
-        sb = joined[0][13] + joined[1][13];
-        saa = joined[0][14] + joined[1][14];
-        sbb = joined[0][15] + joined[1][15];
-        S = lane < XCELLS ? S : 0u;
+        T[3] = S;                                       // (lanes 12..15; the quad broadcasts below read exactly those)
     }
+    // the window sums to every lane of their quad (lanes 12..15 hold them; every lane r0 < 16 needs them: same row)
+    unsigned sa, sb, saa, sbb;
+    {
+        // row_bcast within the row of 16 lanes: lane 12 / 13 / 14 / 15 of the row through a row rotation + quad broadcast
+        const unsigned t3 = (r0 & 12) == 12 ? T[3] : 0u;                  // only the last quad of the first row carries sums
+        unsigned rowsum = t3;                                             // value at lane 12 + (l & 3), spread over the row:
+        rowsum += (unsigned)dpp_i<0x128>((int)rowsum);                    // row_ror:8
+        rowsum += (unsigned)dpp_i<0x124>((int)rowsum);                    // row_ror:4  -> every quad of the row holds the four sums
+        sa = (unsigned)dpp_i<0x00>((int)rowsum);                          // quad_perm [0,0,0,0]
+        sb = (unsigned)dpp_i<0x55>((int)rowsum);                          // quad_perm [1,1,1,1]
+        saa = (unsigned)dpp_i<0xAA>((int)rowsum);                         // quad_perm [2,2,2,2]
+        sbb = (unsigned)dpp_i<0xFF>((int)rowsum);                         // quad_perm [3,3,3,3]
+    }
+    S = r0 < XCELLS ? S : 0u;
 
     // ---- the decisions, re-checked on the exact values
     const bool have = q >= 0;
     auto umin = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x < y ? x : y; };
     auto umax = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x > y ? x : y; };
     constexpr int S0 = 5, N0 = 5 + EXACT_MAX_SECOND;         // first second-peak / minimum slot
-    const unsigned s_min = grp_reduce<G::GROUP>((have && r0 >= N0 && r0 < XCELLS) ? S : 0xffffffffu, umin);
-    const unsigned s_low = grp_reduce<G::GROUP>((have && r0 < XCELLS) ? S : 0xffffffffu, umin);
-    const unsigned s_top = grp_reduce<G::GROUP>((have && r0 < N0) ? S : 0u, umax);
-    const unsigned s_m = grp_reduce<G::GROUP>(r0 == 0 ? S : 0u, umax);
-    const unsigned s_second = grp_reduce<G::GROUP>((have && r0 >= S0 && r0 < N0) ? S : 0u, umax);
-    const unsigned n_second = grp_reduce<G::GROUP>((have && r0 >= S0 && r0 < N0) ? 1u : 0u, uadd);
+    // (the cells sit in lanes 0..11 of the window and the results are used by lanes 0..7: reductions over its first 16 lanes)
+    auto uadd = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x + y; };
+    const unsigned s_min = grp_reduce<16>((have && r0 >= N0 && r0 < XCELLS) ? S : 0xffffffffu, umin);
+    const unsigned s_low = grp_reduce<16>((have && r0 < XCELLS) ? S : 0xffffffffu, umin);
+    const unsigned s_top = grp_reduce<16>((have && r0 < N0) ? S : 0u, umax);
+    const unsigned s_m = grp_reduce<16>(r0 == 0 ? S : 0u, umax);
+    const unsigned s_second = grp_reduce<16>((have && r0 >= S0 && r0 < N0) ? S : 0u, umax);
+    const unsigned n_second = grp_reduce<16>((have && r0 >= S0 && r0 < N0) ? 1u : 0u, uadd);
     // contrast of the map against the scale the float32 transform's error follows (piv_kernels.h, "The band"):
     // R = S(m) - S_min, E^2 = (sum a^2 - (sum a)^2 / n) (sum b^2 - (sum b)^2 / n), all from exact integers
     const double ea2 = (double)saa - (double)sa * (double)sa * (1.0 / KD), eb2 = (double)sbb - (double)sb * (double)sb * (1.0 / KD);

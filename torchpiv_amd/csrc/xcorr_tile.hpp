@@ -1230,6 +1230,16 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
         if constexpr (WS == 64) return b_;
         else return (b_ >> (w * 32)) & 0xffffffffull;
     };
+    // "some window of the wavefront still has a bit set" / "this lane's window has": with one window per wavefront the
+    // masks are wave-uniform and both are the plain scalar test
+    auto any_left = [](unsigned long long mk) TPIV_LAMBDA_INLINE {
+        if constexpr (WS == 64) return mk != 0ull;
+        else return __ballot(mk != 0ull) != 0ull;
+    };
+    auto mine_left = [](unsigned long long mk) TPIV_LAMBDA_INLINE {
+        if constexpr (WS == 64) return true;
+        else return mk != 0ull;
+    };
     float* const my_row = tile + w * WS;              // one parked map row per window
     const int ys = (r + WS / 2) % WS;
     float rmin = 3.4e38f, rmax = -3.4e38f;
@@ -1284,8 +1294,8 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
         open = open || __popcll(rows) > EXACT_MAX_SECOND;
         int ns = 0;
         for (int it = 0; it < EXACT_MAX_SECOND; ++it) {
-            if (__ballot(rows != 0ull) == 0ull) break;          // (no window of the wavefront has a row left)
-            const bool on = rows != 0ull;
+            if (!any_left(rows)) break;                         // (no window of the wavefront has a row left)
+            const bool on = mine_left(rows);
             const int rl = on ? (int)__builtin_ctzll(rows) : 0;
             rows &= rows - 1;
             const int yr = row_of_lane(rl);
@@ -1293,8 +1303,8 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
             unsigned long long cols = wballot(__fsub_rn(park(rl), cmin) >= thr) & ~exr;
             cols = on ? cols : 0ull;
             for (int k = 0; k < WS; ++k) {                      // (at most a handful of bits are set)
-                if (__ballot(cols != 0ull) == 0ull) break;
-                const bool has = cols != 0ull;
+                if (!any_left(cols)) break;
+                const bool has = mine_left(cols);
                 const int q = yr * WS + (has ? (int)__builtin_ctzll(cols) : 0);
                 cols &= cols - 1;
                 s[0] = (has && ns == 0) ? q : s[0];
@@ -1313,16 +1323,16 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
         open = open || __popcll(rows) > EXACT_MAX_MIN;
         int nn = 0;
         for (int it = 0; it < EXACT_MAX_MIN; ++it) {
-            if (__ballot(rows != 0ull) == 0ull) break;
-            const bool on = rows != 0ull;
+            if (!any_left(rows)) break;
+            const bool on = mine_left(rows);
             const int rl = on ? (int)__builtin_ctzll(rows) : 0;
             rows &= rows - 1;
             const int yr = row_of_lane(rl);
             unsigned long long cols = wballot(park(rl) <= thr);
             cols = on ? cols : 0ull;
             for (int k = 0; k < WS; ++k) {
-                if (__ballot(cols != 0ull) == 0ull) break;
-                const bool has = cols != 0ull;
+                if (!any_left(cols)) break;
+                const bool has = mine_left(cols);
                 const int q = yr * WS + (has ? (int)__builtin_ctzll(cols) : 0);
                 cols &= cols - 1;
                 n[0] = (has && nn == 0) ? q : n[0];
