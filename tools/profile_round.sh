@@ -38,7 +38,7 @@ fi
 if [[ $PART == *b* ]]; then
 cfg() {   # name, quick_bench args
     local name=$1; shift
-    python3 tools/quick_bench.py "$@" 2>&1 | grep -E "pairs/s|us/pair:" > $OUT/other_configs/$name.txt
+    python3 tools/quick_bench.py "$@" 2>&1 | grep -E "pairs/s|us/pair:|^exact" > $OUT/other_configs/$name.txt
     rocprofv3 --kernel-trace --stats --output-format csv $R -d $OUT/other_configs/$name.prof -- python3 tools/quick_bench.py "$@" > /dev/null 2> $OUT/other_configs/$name.err
     cp $OUT/other_configs/$name.prof/*/*_kernel_stats.csv $OUT/other_configs/${name}_kernel_stats.csv; rm -rf $OUT/other_configs/$name.prof
     rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv --kernel-include-regex "xcorr|predict" -d $OUT/other_configs/$name.pmc -- python3 tools/quick_bench.py "$@" --iters 2 > /dev/null 2>> $OUT/other_configs/$name.err

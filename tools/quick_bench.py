@@ -45,7 +45,8 @@ tm, n = plan.get_timing()
 print("per-kernel ms per batch:", {k: round(v, 3) for k, v in tm.items()}, " us/pair:",
       {k: round(v / a.batch * 1000, 1) for k, v in tm.items()})
 u, v, inv = out
-if a.precision == "exact" and a.ws == 64:
+if a.precision == "exact" and a.ws in (32, 64, 128):
+    print("exact pass 1, ms per batch:", {k: round(v, 3) for k, v in plan.exact_timing().items()})
     n_fb = plan.exact_fallbacks()
     n_w = a.batch * plan.geometry[0][2] * plan.geometry[0][3]
     print(f"exact: {n_fb} of {n_w} first-pass windows took the float64 transform ({100.0 * n_fb / n_w:.3f} %)")

@@ -459,9 +459,13 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
 // Float32 only (every mode); even sizes whose factors fit; everything else stays with xcorr_generic_kernel above.
 // =====================================================================================================
 using cff = cplx<float>;
-constexpr int CT_T = 64;     // threads per workgroup of the second-generation kernel: ONE wavefront per window -- its LDS
-                             // exchanges need no workgroup barrier (s_barrier of a one-wave workgroup is free) and its
-                             // reductions are cross-lane moves instead of LDS trees with nine barriers each
+constexpr int CT_T = 256;    // most threads per workgroup = per window.  Round 4 first ran ONE wavefront per window (free barriers,
+                             // reductions as cross-lane moves): with ~29 KB of LDS per window that is five wavefronts per CU.
+                             // Measured since (64 -> 42 -> 28 chain): four wavefronts per window take the 42 x 42 pass from
+                             // 496 to 412 us per pair and the 28 x 28 pass from 431 to 596 (784 elements: three sweeps of
+                             // 256 threads, barriers dominate) -- so windows of 40 pixels and more get four wavefronts, smaller
+                             // ones one (ct_threads); the loops below take their stride from blockDim.x
+constexpr int CT_WAVES = CT_T / 64;
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -477,6 +481,45 @@ __device__ __forceinline__ AM<float> wave_argmax(AM<float> a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a = better_g(a, AM<float>{__shfl_xor(a.v, o, 64), __shfl_xor(a.idx, o, 64)});
     return a;
+}
+
+// workgroup-wide forms (red: CT_WAVES slots of the dynamic LDS; the trailing barrier frees them for the next call)
+__device__ __forceinline__ float ct_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int nw = (int)blockDim.x >> 6;
+    if (nw == 1) return v;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < nw; ++w) r += red[w];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float ct_min(float v, float* red) {
+    v = wave_min(v);
+    const int nw = (int)blockDim.x >> 6;
+    if (nw == 1) return v;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int w = 1; w < nw; ++w) r = rmin(r, red[w]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ AM<float> ct_argmax(AM<float> a, float* red) {
+    a = wave_argmax(a);
+    const int nw = (int)blockDim.x >> 6;
+    if (nw == 1) return a;
+    int* redi = reinterpret_cast<int*>(red + CT_WAVES);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = a.v;
+        redi[threadIdx.x >> 6] = a.idx;
+    }
+    __syncthreads();
+    AM<float> r{red[0], redi[0]};
+    for (int w = 1; w < nw; ++w) r = better_g(r, AM<float>{red[w], redi[w]});
+    __syncthreads();
+    return r;
 }
 
 __device__ __forceinline__ int div_small(int i, float rcp) { return (int)(((float)i + 0.5f) * rcp); }     // i / n for i < 2^22
@@ -498,7 +541,7 @@ __device__ __noinline__ void radix_pass(const cff* __restrict__ src, cff* __rest
     }
     const int count = nlines * per_line;
     const float rcp = 1.0f / (float)(line_fast ? nlines : per_line);
-    for (int item = threadIdx.x; item < count; item += CT_T) {
+    for (int item = threadIdx.x; item < count; item += (int)blockDim.x) {
         const int hi = div_small(item, rcp);
         const int lo = item - hi * (line_fast ? nlines : per_line);
         const int line = line_fast ? lo : hi, t = line_fast ? hi : lo;
@@ -569,6 +612,7 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
     cff* T0 = reinterpret_cast<cff*>(ct_smem);
     cff* T1 = T0 + n * P;
     cff* tw = T1 + n * P;                                   // exp(-2 pi i k / n), k < n
+    float* red = reinterpret_cast<float*>(tw + n);          // 2 x CT_WAVES reduction slots
     const int PD = n + 4;                                   // CWS: source patch of a shifted window incl. the interpolation margin
     uint8_t* patch_a = reinterpret_cast<uint8_t*>(T1);      // (the patches live in the second tile's memory: it is idle until the
     uint8_t* patch_b = patch_a + PD * PD;                   //  first transform -- more LDS would cost a resident wavefront per CU)
@@ -578,7 +622,7 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
     const int HW = p.H * p.W;
     const int st = p.ws - p.ov;
     const float rcp_n = 1.0f / (float)n;
-    for (int k = tid; k < n; k += CT_T) {
+    for (int k = tid; k < n; k += (int)blockDim.x) {
         double s, c;
         sincospi(2.0 * (double)k / (double)n, &s, &c);
         tw[k] = cff{(float)c, (float)(-s)};
@@ -614,7 +658,7 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
             byb = y0 + f2i_sat_g(floorf(vy)) - 1;
             const float rcp_pd = 1.0f / (float)PD;
 #pragma unroll 4
-            for (int i = tid; i < PD * PD; i += CT_T) {
+            for (int i = tid; i < PD * PD; i += (int)blockDim.x) {
                 const int py = div_small(i, rcp_pd), px = i - py * PD;
                 patch_a[i] = (uint8_t)fetch_clamped_g(fa, (long long)(bya + py) * p.W + (bxa + px), HW);
                 patch_b[i] = (uint8_t)fetch_clamped_g(fb, (long long)(byb + py) * p.W + (bxb + px), HW);
@@ -623,7 +667,7 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
         }
         float sa = 0, sb = 0;
 #pragma unroll 4
-        for (int i = tid; i < nn; i += CT_T) {
+        for (int i = tid; i < nn; i += (int)blockDim.x) {
             const int y = div_small(i, rcp_n), x = i - y * n;
             float a, b;
             if constexpr (MODE == MODE_PASS1) {
@@ -649,8 +693,8 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
                 p.dbg_win[fidx * 2 * nn + nn + i] = b;
             }
         }
-        sa = wave_sum(sa);
-        sb = wave_sum(sb);
+        sa = ct_sum(sa, red);
+        sb = ct_sum(sb, red);
         const float ma = sa / (float)nn, mb = sb / (float)nn;
         bool dead = false;
         float ka = 1, kb = 1;
@@ -662,7 +706,7 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
         __syncthreads();
         // mean removal (conditions the float32 transform; corr - min is unchanged by it) and the normalisation
 #pragma unroll 4
-        for (int i = tid; i < nn; i += CT_T) {
+        for (int i = tid; i < nn; i += (int)blockDim.x) {
             const int y = div_small(i, rcp_n), x = i - y * n;
             const cff z = T0[y * P + x];
             T0[y * P + x] = cff{(z.x - ma) * ka, (z.y - mb) * kb};
@@ -673,7 +717,7 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
         // ---- cross-spectrum: T1[k] = conj(A) * B / n^2 with A, B split out of Z = FFT2(a + i b)
         const float scale = 0.25f / (float)nn;
 #pragma unroll 4
-        for (int i = tid; i < nn; i += CT_T) {
+        for (int i = tid; i < nn; i += (int)blockDim.x) {
             const int ky = div_small(i, rcp_n), kx = i - ky * n;
             const cff zk = T0[ky * P + kx];
             const cff zm = T0[(ky ? n - ky : 0) * P + (kx ? n - kx : 0)];
@@ -690,7 +734,7 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
         float cmin = 3.4e38f;
         const int hshift = n / 2;
 #pragma unroll 4
-        for (int i = tid; i < nn; i += CT_T) {
+        for (int i = tid; i < nn; i += (int)blockDim.x) {
             const int y = div_small(i, rcp_n), x = i - y * n;
             const float re = T1[y * P + x].x;
             int ys = y + hshift, xs = x + hshift;
@@ -699,11 +743,11 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
             map[ys * n + xs] = re;
             cmin = rmin(cmin, re);
         }
-        cmin = wave_min(cmin);
+        cmin = ct_min(cmin, red);
         // ---- corr - min + eps (B:518, B:381), first peak
         AM<float> best{-1.f, 0};
 #pragma unroll 4
-        for (int i = tid; i < nn; i += CT_T) {
+        for (int i = tid; i < nn; i += (int)blockDim.x) {
             const float v = add_eps(map[i], cmin);
             map[i] = v;
             if (p.dbg_corr != nullptr) p.dbg_corr[fidx * nn + i] = v;
@@ -712,14 +756,14 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
                 best.idx = i;
             }
         }
-        best = wave_argmax(best);
+        best = ct_argmax(best, red);
         __syncthreads();
         const int m = best.idx;
         // ---- second peak outside the flat-index neighbourhood (B:346-358)
         const int wv = p.val_win;
         AM<float> second{-1.f, nn};
 #pragma unroll 4
-        for (int i = tid; i < nn; i += CT_T) {
+        for (int i = tid; i < nn; i += (int)blockDim.x) {
             // i = m + t + n j with |t|, |j| <= wv (2 wv < n: at most one such pair), or one of the two clamps
             const int d = i - m + wv;                         // = t' + n j with t' = t + wv in [0, 2 wv]
             const int j = (int)floorf(((float)d + 0.5f) * rcp_n);
@@ -733,7 +777,7 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
                 second.idx = i;
             }
         }
-        second = wave_argmax(second);
+        second = ct_argmax(second, red);
         __syncthreads();
         if (tid < 8) {
             int left = m + 1, right = m - 1, top = m + n, bot = m - n;    // B:385-392
@@ -757,6 +801,7 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
     }
 }
 
+static int ct_threads(int n) { return n >= 40 ? CT_T : 64; }
 constexpr int CT_MAX_RADIX = 8;
 // n = n1 n2 with 2 <= n1 <= n2 <= CT_MAX_RADIX, n1 as large as possible; false if there is no such split
 bool ct_factors(int n, int& n1, int& n2) {
@@ -767,7 +812,7 @@ bool ct_factors(int n, int& n1, int& n2) {
     n2 = n / n1;
     return n1 >= 2 && n2 <= CT_MAX_RADIX;
 }
-size_t ct_smem_bytes(int n) { return (size_t)(2 * n * (n | 1) + n) * sizeof(cff); }     // (2 (n + 4)^2 patch bytes fit the second tile, n >= 4)
+size_t ct_smem_bytes(int n) { return (size_t)(2 * n * (n | 1) + n) * sizeof(cff) + 2 * CT_WAVES * sizeof(float); }     // (2 (n + 4)^2 patch bytes fit the second tile, n >= 4)
 bool ct_usable(int n, int precision) {
     int a, b;
     return precision == 0 && (n & 1) == 0 && n >= 4 && n <= 96 && ct_factors(n, a, b) && ct_smem_bytes(n) <= 160 * 1024;
@@ -811,7 +856,7 @@ hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, void* s
         hipError_t e_ = hipSuccess;
 #define TPIV_CT_LAUNCH(M)                                                                                               \
     e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_generic_ct_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    if (e_ == hipSuccess) hipLaunchKernelGGL((xcorr_generic_ct_kernel<M>), dim3((unsigned)blocks), dim3(CT_T), smem, stream, p, n1, n2);
+    if (e_ == hipSuccess) hipLaunchKernelGGL((xcorr_generic_ct_kernel<M>), dim3((unsigned)blocks), dim3(ct_threads(p.ws)), smem, stream, p, n1, n2);
         switch (mode) {
             case MODE_PASS1: TPIV_CT_LAUNCH(MODE_PASS1) break;
             case MODE_DWS: TPIV_CT_LAUNCH(MODE_DWS) break;
