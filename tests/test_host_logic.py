@@ -150,6 +150,43 @@ def test_api_surface_and_errors_without_gpu(tmp_path):
             T.engine.pass1(torch.zeros(64, 64, dtype=torch.uint8), torch.zeros(64, 64, dtype=torch.uint8), 32, 16)
 
 
+def test_mixed_radix_codelets_on_host(tmp_path):
+    """fft_mixed.hpp (window sizes n1 * n2 with factors up to 8) compiled as host C++ against numpy.fft, both directions,
+    output slots by mixed_pos."""
+    sizes = [4, 6, 8, 9, 10, 12, 14, 15, 16, 18, 20, 21, 24, 25, 28, 30, 35, 36, 40, 42, 48, 49, 56, 64]
+    calls = " ".join(f"run<{n},1>(); run<{n},-1>();" for n in sizes)
+    src = tmp_path / "m.cpp"
+    src.write_text(r"""
+#include "fft_mixed.hpp"
+#include <cstdio>
+using namespace tpiv;
+template<int N, int DIR> void run() {
+  static_assert(fmx::mixed_usable(N), "size");
+  cf x[N];
+  for (int i = 0; i < N; ++i) { x[i].x = (float)((i*37+11)%101) - 50.f; x[i].y = (float)((i*53+7)%89) - 44.f; }
+  fmx::fft_mixed<N, DIR>(x);
+  printf("%d %d", N, DIR);
+  for (int k = 0; k < N; ++k) printf(" %.9g %.9g", x[fmx::mixed_pos(k,N)].x, x[fmx::mixed_pos(k,N)].y);
+  printf("\n");
+}
+int main(){ """ + calls + """ }
+""")
+    exe = tmp_path / "m"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "torchpiv_amd", "csrc"), str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == 2 * len(sizes)
+    for line in out:
+        f = line.split()
+        n, d = int(f[0]), int(f[1])
+        got = np.array(f[2:], dtype=np.float64).reshape(n, 2)
+        i = np.arange(n)
+        x = ((i * 37 + 11) % 101 - 50.0) + 1j * ((i * 53 + 7) % 89 - 44.0)
+        ref = np.fft.fft(x) if d > 0 else np.fft.ifft(x) * n
+        err = np.abs(got[:, 0] + 1j * got[:, 1] - ref).max() / np.abs(ref).max()
+        assert err < 2e-6, (n, d, err)
+
+
 def test_fft_codelets_on_host(tmp_path):
     """fft_inreg.hpp compiled as host C++ against numpy.fft (forward and inverse, N = 8..128)."""
     src = tmp_path / "t.cpp"

@@ -24,6 +24,7 @@ hipError_t launch_peak_debug_ws128(const PassParams& p, const float* maps, int n
 hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, void* scratch, hipStream_t stream);
 int generic_blocks(int ws, long long items, int n_cu, int elem_bytes);
 bool generic_ct_usable(int ws);
+int generic_ct_register_size(int ws, int mode);
 hipError_t launch_xcorr_f64(const PassParams& p, int n_cu, hipStream_t stream);      // xcorr_f64.hip: 8..64, pass 1
 // precision "exact" (64x64 pass 1): float32 candidate pass, exact integer refinement, float64 pass for the undecided windows
 hipError_t launch_xcorr_cand_ws32(const PassParams& p, int n_cu, hipStream_t stream);       // xcorr_tile.hpp
@@ -234,9 +235,10 @@ const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int le
     } else if (ws == 128 && mode == MODE_PASS1) {
         snprintf(buf, len, "xcorr_big128_kernel");
     } else {
-        snprintf(buf, len, generic_ct_usable(ws) ? "xcorr_generic_ct_kernel<%d>" : "xcorr_generic_kernel<%d, float>", mode);
+        if (generic_ct_usable(ws)) snprintf(buf, len, "xcorr_generic_ct_kernel<%d, %d>", mode, generic_ct_register_size(ws, mode));
+        else snprintf(buf, len, "xcorr_generic_kernel<%d, float>", mode);
     }
-    if (mode == MODE_CWSF) snprintf(buf, len, generic_ct_usable(ws) ? "xcorr_generic_ct_kernel<3>" : "xcorr_generic_kernel<3, float>");
+    if (mode == MODE_CWSF) snprintf(buf, len, generic_ct_usable(ws) ? "xcorr_generic_ct_kernel<3, 0>" : "xcorr_generic_kernel<3, float>");
     return buf;
 }
 

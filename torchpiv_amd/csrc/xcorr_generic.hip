@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "fft_inreg.hpp"
+#include "fft_mixed.hpp"
 #include "piv_kernels.h"
 
 namespace tpiv {
@@ -605,12 +606,15 @@ __device__ __forceinline__ void axis_transform(cff* a, cff* tmp, int n, int n1, 
     __syncthreads();
 }
 
-template <int MODE>
-__global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, int n1, int n2) {
+// NC > 0: the window size as a compile-time constant -- ONE wavefront per window, lane = line, the four transforms as
+// in-register mixed-radix codelets (fft_mixed.hpp) with LDS only for the two transpositions; staging and peak analysis are
+// the loops of the run-time form with n known to the compiler.  NC = 0: the run-time form (any even n whose factors fit).
+template <int MODE, int NC>
+__global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(PassParams p, int n1, int n2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
-    const int n = p.ws, nn = n * n, P = n | 1;             // tile pitch: odd (rows and columns both conflict-poor)
+    const int n = NC > 0 ? NC : p.ws, nn = n * n, P = n | 1;      // tile pitch: odd (rows and columns both conflict-poor)
     cff* T0 = reinterpret_cast<cff*>(ct_smem);
-    cff* T1 = T0 + n * P;
+    cff* T1 = T0 + n * P;                                   // (NC > 0: no second tile -- the patches sit behind the first)
     cff* tw = T1 + n * P;                                   // exp(-2 pi i k / n), k < n
     float* red = reinterpret_cast<float*>(tw + n);          // 2 x CT_WAVES reduction slots
     const int PD = n + 4;                                   // CWS: source patch of a shifted window incl. the interpolation margin
@@ -620,14 +624,16 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
     const int N = p.n_rows * p.n_cols;
     const long long items = (long long)p.batch * N;
     const int HW = p.H * p.W;
-    const int st = p.ws - p.ov;
+    const int st = n - p.ov;
     const float rcp_n = 1.0f / (float)n;
-    for (int k = tid; k < n; k += (int)blockDim.x) {
-        double s, c;
-        sincospi(2.0 * (double)k / (double)n, &s, &c);
-        tw[k] = cff{(float)c, (float)(-s)};
+    if constexpr (NC == 0) {
+        for (int k = tid; k < n; k += (int)blockDim.x) {
+            double s, c;
+            sincospi(2.0 * (double)k / (double)n, &s, &c);
+            tw[k] = cff{(float)c, (float)(-s)};
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     for (long long item = blockIdx.x; item < items; item += gridDim.x) {
         const int pair = (int)(item / N), win = (int)(item % N);
@@ -704,6 +710,92 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
             kb = dead ? 0.f : 1.f / mb;
         }
         __syncthreads();
+        float* map = reinterpret_cast<float*>(T0);
+        float cmin = 3.4e38f;
+        const int hshift = n / 2;
+        if constexpr (NC > 0) {
+            // ---- lane = line; every transform on registers, the tile only for the two transpositions
+            using fmx::fft_mixed;
+            const int r = tid < NC ? tid : 0;                 // (lanes >= NC idle along with lane 0's data; their stores are masked)
+            const bool on = tid < NC;
+            const int mirror = (NC - r) % NC;                 // the lane that holds column -kx
+            cf x[NC];
+            static_for<0, NC>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int k = decltype(kc)::value;
+                const cff z = T0[r * P + k];
+                // mean removal (conditions the float32 transform; corr - min is unchanged by it) and the normalisation
+                x[k] = cf{(z.x - ma) * ka, (z.y - mb) * kb};
+            });
+            fft_mixed<NC, 1>(x);                              // over x: bin kx at slot MIXED_POS<kx>
+            if (on) {                                         // (each lane rewrites its own row: no other lane reads it)
+                static_for<0, NC>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    T0[r * P + k] = cff{x[fmx::MIXED_POS<k, NC>].x, x[fmx::MIXED_POS<k, NC>].y};
+                });
+            }
+            __syncthreads();
+            static_for<0, NC>([&](auto yc) TPIV_LAMBDA_INLINE {       // lane = kx: column of the row transforms
+                constexpr int y = decltype(yc)::value;
+                const cff z = T0[y * P + r];
+                x[y] = cf{z.x, z.y};
+            });
+            fft_mixed<NC, 1>(x);                              // over y: Z(ky, kx = lane) at slot MIXED_POS<ky>
+            // cross-spectrum P = conj(A) B / n^2 of the packed transform; Z(-ky, -kx) sits in lane `mirror`, slot of -ky
+            {
+                const float scale = 0.25f / (float)(NC * NC);
+                auto cross = [&](cf zk, cf zm) TPIV_LAMBDA_INLINE {
+                    cf pr;
+                    pr.x = (zk.x * zm.y + zk.y * zm.x) * (2.0f * scale);
+                    pr.y = ((zm.x * zm.x - zk.x * zk.x) + (zm.y * zm.y - zk.y * zk.y)) * scale;
+                    return pr;
+                };
+                static_for<0, NC / 2 + 1>([&](auto kc) TPIV_LAMBDA_INLINE {
+                    constexpr int ky = decltype(kc)::value;
+                    constexpr int nky = (NC - ky) % NC;
+                    constexpr int p1 = fmx::MIXED_POS<ky, NC>, p2 = fmx::MIXED_POS<nky, NC>;
+                    const cf z1 = x[p1];
+                    if constexpr (ky == nky) {
+                        const cf m1{__shfl(z1.x, mirror, 64), __shfl(z1.y, mirror, 64)};
+                        x[p1] = cross(z1, m1);
+                    } else {
+                        const cf z2 = x[p2];
+                        const cf m1{__shfl(z2.x, mirror, 64), __shfl(z2.y, mirror, 64)};      // Z(-ky, -kx)
+                        const cf m2{__shfl(z1.x, mirror, 64), __shfl(z1.y, mirror, 64)};      // Z(+ky, -kx): the mirror of bin -ky
+                        x[p1] = cross(z1, m1);
+                        x[p2] = cross(z2, m2);
+                    }
+                });
+            }
+            cf t[NC];
+            static_for<0, NC>([&](auto kc) TPIV_LAMBDA_INLINE { t[decltype(kc)::value] = x[fmx::MIXED_POS<decltype(kc)::value, NC>]; });
+            fft_mixed<NC, -1>(t);                             // inverse over ky: row y at slot MIXED_POS<y>
+            __syncthreads();                                  // (every lane has read its column)
+            if (on) {
+                static_for<0, NC>([&](auto yc) TPIV_LAMBDA_INLINE {
+                    constexpr int y = decltype(yc)::value;
+                    T0[y * P + r] = cff{t[fmx::MIXED_POS<y, NC>].x, t[fmx::MIXED_POS<y, NC>].y};
+                });
+            }
+            __syncthreads();
+            static_for<0, NC>([&](auto kc) TPIV_LAMBDA_INLINE {       // lane = y: row of the spectrum over kx
+                constexpr int k = decltype(kc)::value;
+                const cff z = T0[r * P + k];
+                x[k] = cf{z.x, z.y};
+            });
+            fft_mixed<NC, -1>(x);                             // inverse over kx: corr(y = lane, x) = real part at slot MIXED_POS<x>
+            __syncthreads();                                  // (rows read: the tile becomes the map)
+            if (on) {
+                int ys = r + hshift;
+                ys -= ys >= n ? n : 0;
+                static_for<0, NC>([&](auto xc) TPIV_LAMBDA_INLINE {
+                    constexpr int xo = decltype(xc)::value;
+                    constexpr int xs = (xo + NC / 2) % NC;
+                    const float re = x[fmx::MIXED_POS<xo, NC>].x;
+                    map[ys * NC + xs] = re;
+                    cmin = rmin(cmin, re);
+                });
+            }
+        } else {
         // mean removal (conditions the float32 transform; corr - min is unchanged by it) and the normalisation
 #pragma unroll 4
         for (int i = tid; i < nn; i += (int)blockDim.x) {
@@ -730,9 +822,6 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
         axis_transform(T1, T0, n, n1, n2, 1, P, true, tw);           // inverse over ky: T1[y][kx]
         axis_transform(T1, T0, n, n1, n2, P, 1, true, tw);           // inverse over kx: T1[y][x] (the real part is the map)
         // ---- map in fftshift coordinates (into T0's memory), minimum
-        float* map = reinterpret_cast<float*>(T0);
-        float cmin = 3.4e38f;
-        const int hshift = n / 2;
 #pragma unroll 4
         for (int i = tid; i < nn; i += (int)blockDim.x) {
             const int y = div_small(i, rcp_n), x = i - y * n;
@@ -743,6 +832,8 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
             map[ys * n + xs] = re;
             cmin = rmin(cmin, re);
         }
+        }       // NC == 0
+        __syncthreads();
         cmin = ct_min(cmin, red);
         // ---- corr - min + eps (B:518, B:381), first peak
         AM<float> best{-1.f, 0};
@@ -802,6 +893,21 @@ __global__ __launch_bounds__(CT_T) void xcorr_generic_ct_kernel(PassParams p, in
 }
 
 static int ct_threads(int n) { return n >= 40 ? CT_T : 64; }
+// window sizes with a compile-time instance of the kernel (in-register transforms): the sizes multipass scales of 1.5 and
+// 1.33 make of 128 / 64 / 48 / 32 first passes, each in the three reachable modes; anything else takes the run-time form.
+// (TPIV_GENERIC_REG=0: run-time form for every size -- A/B runs)
+#ifndef TPIV_CT_REGISTER_SIZES
+#define TPIV_CT_REGISTER_SIZES(X) X(12) X(14) X(18) X(24) X(28) X(36) X(42) X(48) X(56)
+#endif
+static bool ct_register_size(int n) {
+    static const bool off = [] { const char* e_ = getenv("TPIV_GENERIC_REG"); return e_ && e_[0] == '0'; }();
+    if (off) return false;
+#define TPIV_CTR_IS(NCV) if (n == NCV) return true;
+    TPIV_CT_REGISTER_SIZES(TPIV_CTR_IS)
+#undef TPIV_CTR_IS
+    return false;
+}
+static size_t ct_register_smem(int n) { return ((size_t)n * (n | 1) * sizeof(cff) + 2 * (size_t)(n + 4) * (n + 4) + 15) / 16 * 16; }
 constexpr int CT_MAX_RADIX = 8;
 // n = n1 n2 with 2 <= n1 <= n2 <= CT_MAX_RADIX, n1 as large as possible; false if there is no such split
 bool ct_factors(int n, int& n1, int& n2) {
@@ -819,6 +925,9 @@ bool ct_usable(int n, int precision) {
 }
 
 }  // namespace
+
+// ... with a compile-time instance?  (the second template argument of the kernel's name: 0 = run-time form)
+int generic_ct_register_size(int ws, int mode) { return (mode != MODE_CWSF && ct_usable(ws, 0) && ct_register_size(ws)) ? ws : 0; }
 
 // does (ws, float32) run the second-generation kernel?  (bench / profile labels, piv_launch.hip)
 bool generic_ct_usable(int ws) {
@@ -854,9 +963,33 @@ hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, void* s
         long long blocks = (long long)n_cu * (per_cu < 1 ? 1 : per_cu);
         if (blocks > items) blocks = items;
         hipError_t e_ = hipSuccess;
+        // sizes with a compile-time instance (in-register transforms, one wavefront per window): every mode but CWS_Fast
+        if (mode != MODE_CWSF && ct_register_size(p.ws)) {
+            const size_t smem_r = ct_register_smem(p.ws);
+            int per_cu_r = (int)((160 * 1024) / smem_r);
+            per_cu_r = per_cu_r > 16 ? 16 : (per_cu_r < 1 ? 1 : per_cu_r);
+            long long blocks_r = (long long)n_cu * per_cu_r;
+            if (blocks_r > items) blocks_r = items;
+#define TPIV_CTR_LAUNCH(M, NCV)                                                                                         \
+    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_generic_ct_kernel<M, NCV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r); \
+    if (e_ == hipSuccess) hipLaunchKernelGGL((xcorr_generic_ct_kernel<M, NCV>), dim3((unsigned)blocks_r), dim3(64), smem_r, stream, p, n1, n2);
+#define TPIV_CTR_MODES(NCV)                                                                                             \
+    case NCV:                                                                                                           \
+        if (mode == MODE_PASS1) { TPIV_CTR_LAUNCH(MODE_PASS1, NCV) }                                                    \
+        else if (mode == MODE_DWS) { TPIV_CTR_LAUNCH(MODE_DWS, NCV) }                                                   \
+        else { TPIV_CTR_LAUNCH(MODE_CWS, NCV) }                                                                         \
+        break;
+            switch (p.ws) {
+                TPIV_CT_REGISTER_SIZES(TPIV_CTR_MODES)
+                default: return hipErrorInvalidValue;
+            }
+#undef TPIV_CTR_MODES
+#undef TPIV_CTR_LAUNCH
+            return e_ != hipSuccess ? e_ : hipGetLastError();
+        }
 #define TPIV_CT_LAUNCH(M)                                                                                               \
-    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_generic_ct_kernel<M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    if (e_ == hipSuccess) hipLaunchKernelGGL((xcorr_generic_ct_kernel<M>), dim3((unsigned)blocks), dim3(ct_threads(p.ws)), smem, stream, p, n1, n2);
+    e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_generic_ct_kernel<M, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    if (e_ == hipSuccess) hipLaunchKernelGGL((xcorr_generic_ct_kernel<M, 0>), dim3((unsigned)blocks), dim3(ct_threads(p.ws)), smem, stream, p, n1, n2);
         switch (mode) {
             case MODE_PASS1: TPIV_CT_LAUNCH(MODE_PASS1) break;
             case MODE_DWS: TPIV_CT_LAUNCH(MODE_DWS) break;
