@@ -103,12 +103,14 @@ def exact_window(a, b, wv=3, val_ratio=1.2):
     scale = float(W) ** 4 / (float(sa) * float(sb))
     val = lambda q: (S[q] - smin) * scale + 1e-7
     cm, cl, cr, ct, cb = val(m), val(left), val(right), val(top), val(bot)
-    c2 = max(val(q) for q in second) if second else cm
+    # (nothing outside the exclusion zone: the reference zeroes its float64 map in place and divides by the 0 it finds there)
+    c2 = max(val(q) for q in second) if second else 0.0
     with np.errstate(all="ignore"):
         lm, ll, lr, lt, lb = np.log(cm), np.log(cl), np.log(cr), np.log(ct), np.log(cb)
         u = m % W + (lr - ll) / (2 * (ll + lr) - 4 * lm) - W // 2
         v = m // W + (lb - lt) / (2 * (lb + lt) - 4 * lm) - W // 2
-    return float(np.nan_to_num(u)), float(np.nan_to_num(v)), bool(cm / c2 < val_ratio)
+        invalid = bool(np.float64(cm) / np.float64(c2) < val_ratio)
+    return float(np.nan_to_num(u)), float(np.nan_to_num(v)), invalid
 
 
 def synthetic_pair(H, W, seed, shift=(2.3, -1.6), n=None, noise=2.0):

@@ -405,7 +405,9 @@ def test_resident_generator_equals_host_post_validation(eng):
     A, B = torch.stack(A).cuda(), torch.stack(B).cuda()
     piv = T.ResidentPIV(A, B, 32, 16, multipass=2, multipass_mode="CWS", dt=2, scale=0.5)       # (default precision: "exact" = "f64" for 32x32 windows)
     res = {i: (x, y, u, v) for i, x, y, u, v in piv.batched(4)}
-    plan = eng.Plan(H, W, 32, 16, n_pass=2, mode="CWS", max_batch=6, precision="f64")
+    # (the same precision as the generator's default: pair 5's windows are flat maps -- one frame constant --, whose arg-max is
+    #  rounding noise of whichever float64 kernel instance transforms them; this test is about the post-validation)
+    plan = eng.Plan(H, W, 32, 16, n_pass=2, mode="CWS", max_batch=6)
     u, v, inv = plan.run(A, B)
     u, v, inv = u.cpu().numpy(), v.cpu().numpy(), inv.cpu().numpy().astype(bool)
     n_kept = 0

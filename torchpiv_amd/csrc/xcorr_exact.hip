@@ -256,8 +256,11 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     if (go && redo) to_f64_kernel();
     // (S - S_min) n^4 / (sum a sum b) + 1e-7: the integer difference is exact, sum a * sum b < 2^44 is exact
     const double scale = ((double)KD * (double)KD) / ((double)sa * (double)sb);
-    const unsigned mine = r0 == 5 ? (n_second ? s_second : s_m) : S;      // B:411: no cell left -> the first peak itself
+    const unsigned mine = r0 == 5 ? s_second : S;
     double v = __fma_rn((double)(mine - s_min), scale, 1e-7);
+    // B:410-411 with every cell inside the exclusion zone (2 val_win + 1 >= W): the reference zeroes its float64 map in
+    // place and divides by the 0 it then finds -- ratio inf, valid; the float64 kernels store 0 there too
+    v = (r0 == 5 && n_second == 0u) ? 0.0 : v;
     v = r0 == 6 ? (double)m : v;
     v = r0 == 7 ? 0.0 : v;
     if (go && !redo && r0 < 8 && writer) out[r0] = v;
