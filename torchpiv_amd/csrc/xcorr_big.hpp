@@ -173,46 +173,67 @@ __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[B
             // (all values are the shifted cells v = (c - min) + 1e-7 > 0: differences are those of the raw map)
             const float band = p.exact_band * __fsub_rn(graw, cmin);
             bool open = !(band > 0.0f);
+            // The few threads whose row extremum sits inside a band walk their 64 cells over the map in LDS
+            // (plane[ys][xe + par], the shifted cells just parked there) in two steps: a branch-free pass that only sets one bit
+            // per matching cell (sixteen reads in flight), then the bits -- one to three -- are visited.  (Two earlier forms: unrolled
+            // over the register copy with the append inside, 4 800 lines of code; a rolled loop with a branch per cell, one LDS
+            // round trip per cell = 8 000 cycles per walk with the whole workgroup waiting at the next barrier: the locating pass
+            // cost 20-25 % more than the plain float32 pass 1 either way.)
+            const float* const my_cells = plane + ys * BP + par;
+            auto walk = [&](auto&& pred) TPIV_LAMBDA_INLINE {
+                unsigned lo = 0u, hi = 0u;
+#pragma unroll 1
+                for (int jb = 0; jb < BH; jb += 16) {             // sixteen reads issued together, then their tests
+                    float v_[16];
+                    static_for<0, 16>([&](auto kc) TPIV_LAMBDA_INLINE {
+                        constexpr int k = decltype(kc)::value;
+                        v_[k] = my_cells[(2 * (jb + k) + 64) & 127];
+                    });
+                    unsigned bits = 0u;
+                    static_for<0, 16>([&](auto kc) TPIV_LAMBDA_INLINE {
+                        constexpr int k = decltype(kc)::value;
+                        bits |= (pred(v_[k]) ? 1u : 0u) << k;
+                    });
+                    if (jb < 32) lo |= bits << jb;
+                    else hi |= bits << (jb - 32);
+                }
+                return ((unsigned long long)hi << 32) | lo;
+            };
             // arg-max: exactly one cell inside the band of the maximum (then it is the cell found above)
             int cnt = 0;
-            if (rmax >= gmax - band) {
-#pragma unroll
-                for (int j = 0; j < BH; ++j) cnt += c[j] >= gmax - band ? 1 : 0;
-            }
+            if (rmax >= gmax - band) cnt = __popcll(walk([&](float v_) TPIV_LAMBDA_INLINE { return v_ >= gmax - band; }));
             // second peak: the cells outside the exclusion zone inside the band of their maximum
             if (smax > 0 && smax_mine > 0 && __int_as_float(smax_mine) >= __int_as_float(smax) - band) {
                 const float thr = __int_as_float(smax) - band;
                 const int dj = ys - ywin;
-                static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
-                    constexpr int j = decltype(jc)::value;
-                    constexpr int xe = (2 * j + 64) & 127;
-                    if (c[j] >= thr) {
-                        const int q = ys * BW + xe + par;
-                        // B:346-358 for one cell: q = clamp(m + i + BW jj), |i|, |jj| <= wv
-                        bool ex = false;
-                        for (int jj = dj - 1; jj <= dj + 1; ++jj) {
-                            const int i = q - m - BW * jj;
-                            ex = ex || (jj >= -wv && jj <= wv && i >= -wv && i <= wv);
-                        }
-                        ex = ex || (q == 0 && m - wv - wv * BW <= 0) || (q == KD - 1 && m + wv + wv * BW >= KD - 1);
-                        if (!ex) {
-                            const int k = atomicAdd(&sm.n_second, 1);
-                            if (k < EXACT_MAX_SECOND) sm.cand_second[k] = q;
-                        }
+                unsigned long long mk = walk([&](float v_) TPIV_LAMBDA_INLINE { return v_ >= thr; });
+                while (mk) {
+                    const int j = (int)__builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    const int q = ys * BW + ((2 * j + 64) & 127) + par;
+                    // B:346-358 for one cell: q = clamp(m + i + BW jj), |i|, |jj| <= wv
+                    bool ex = false;
+                    for (int jj = dj - 1; jj <= dj + 1; ++jj) {
+                        const int i = q - m - BW * jj;
+                        ex = ex || (jj >= -wv && jj <= wv && i >= -wv && i <= wv);
                     }
-                });
+                    ex = ex || (q == 0 && m - wv - wv * BW <= 0) || (q == KD - 1 && m + wv + wv * BW >= KD - 1);
+                    if (!ex) {
+                        const int k = atomicAdd(&sm.n_second, 1);
+                        if (k < EXACT_MAX_SECOND) sm.cand_second[k] = q;
+                    }
+                }
             }
             // minimum: the cells inside the band of it
             if (__fadd_rn(__fsub_rn(cmin_mine, cmin), 1e-7f) <= 1e-7f + band) {
                 const float thr = 1e-7f + band;
-                static_for<0, BH>([&](auto jc) TPIV_LAMBDA_INLINE {
-                    constexpr int j = decltype(jc)::value;
-                    constexpr int xe = (2 * j + 64) & 127;
-                    if (c[j] <= thr) {
-                        const int k = atomicAdd(&sm.n_min, 1);
-                        if (k < EXACT_MAX_MIN) sm.cand_min[k] = ys * BW + xe + par;
-                    }
-                });
+                unsigned long long mk = walk([&](float v_) TPIV_LAMBDA_INLINE { return v_ <= thr; });
+                while (mk) {
+                    const int j = (int)__builtin_ctzll(mk);
+                    mk &= mk - 1;
+                    const int k = atomicAdd(&sm.n_min, 1);
+                    if (k < EXACT_MAX_MIN) sm.cand_min[k] = ys * BW + ((2 * j + 64) & 127) + par;
+                }
             }
             auto iadd_ = [](int a, int b) TPIV_LAMBDA_INLINE { return a + b; };
             cnt = block_reduce(cnt, iadd_, sm.redc, wave, lane);          // (also: the lists are complete)
