@@ -377,6 +377,11 @@ def e2e_sharded(args):
                "host": {"budget_per_rank": budget, "host_cpu_s_per_pair": float(t[1]) / total,
                         "cores_needed_at_this_rate": float(t[1]) / float(tmax[0])},
                "distributed": {"world_size": world, "backend": backend, "collectives_per_gather": 2, "ranks": gathered}}
+        devices = {(g_["device_index"]) for g_ in gathered}
+        if len(devices) < world:
+            rec["rehearsal"] = (f"{world} ranks on {len(devices)} GPU(s) (TPIV_DIST_BACKEND=gloo): the ranks time-slice one device and the "
+                                "payload of the gather goes through the host -- a check of the launch, the per-rank host budget and "
+                                "the gather from device-resident fields, NOT a rate")
         print(json.dumps(rec), flush=True)
     piv.close()
     dist.barrier()

@@ -60,18 +60,33 @@ __device__ __forceinline__ float cws_sample_patch(const uint8_t* __restrict__ pa
     const float nx = (float)gx + vx, ny = (float)gy + vy;
     const float ux_f = ceilf(nx), dx_f = floorf(nx), uy_f = ceilf(ny), dy_f = floorf(ny);
     const int ux = f2i_sat_g(ux_f), dx = f2i_sat_g(dx_f), uy = f2i_sat_g(uy_f), dy = f2i_sat_g(dy_f);
-    auto px = [&](int yy, int xx) {
-        const int py = yy - by, pxx = xx - bx;
-        return ((unsigned)py < (unsigned)PD && (unsigned)pxx < (unsigned)PD) ? (float)patch[py * PD + pxx]
-                                                                               : fetch_clamped_g(f, (long long)yy * W + xx, HW);
-    };
-    const float f11 = px(dy, dx), f21 = px(dy, ux), f12 = px(uy, dx), f22 = px(uy, ux);
+    float f11, f21, f12, f22;
+    // the four corners span at most 2 x 2 pixels: both extreme corners inside the patch = all four inside (the usual case
+    // for every lane: one address and three small offsets instead of four bounds checks with a global-memory fallback each)
+    const int py0 = dy - by, px0 = dx - bx, py1 = uy - by, px1 = ux - bx;
+    const bool inside = ((unsigned)py0 < (unsigned)PD) & ((unsigned)px0 < (unsigned)PD) & ((unsigned)py1 < (unsigned)PD) &
+                        ((unsigned)px1 < (unsigned)PD);
+    if (__builtin_expect(__all(inside), 1)) {
+        const uint8_t* q0 = patch + py0 * PD + px0;
+        const int ox = px1 - px0, oy = (py1 - py0) * PD;
+        f11 = (float)q0[0];
+        f21 = (float)q0[ox];
+        f12 = (float)q0[oy];
+        f22 = (float)q0[oy + ox];
+    } else {
+        auto px = [&](int yy, int xx) {
+            const int py = yy - by, pxx = xx - bx;
+            return ((unsigned)py < (unsigned)PD && (unsigned)pxx < (unsigned)PD) ? (float)patch[py * PD + pxx]
+                                                                                   : fetch_clamped_g(f, (long long)yy * W + xx, HW);
+        };
+        f11 = px(dy, dx), f21 = px(dy, ux), f12 = px(uy, dx), f22 = px(uy, ux);
+    }
     const float wxu = ux_f - nx, wxd = nx - dx_f, wyu = uy_f - ny, wyd = ny - dy_f;
     float r = (f11 * wxu) * wyu;
     r = r + (f21 * wxd) * wyu;
     r = r + (f12 * wxu) * wyd;
     r = r + (f22 * wxd) * wyd;
-    const bool degenerate = ((long long)(ux - dx) * (long long)(uy - dy)) == 0;
+    const bool degenerate = (ux == dx) | (uy == dy);          // (ux - dx) * (uy - dy) == 0  (B:192-193)
     return degenerate ? f11 : r;
 }
 
@@ -478,6 +493,27 @@ __device__ __forceinline__ float wave_min(float v) {
     for (int o = 32; o > 0; o >>= 1) v = rmin(v, __shfl_xor(v, o, 64));
     return v;
 }
+__device__ __forceinline__ float wave_maxf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_mini(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_maxi(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
 __device__ __forceinline__ AM<float> wave_argmax(AM<float> a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a = better_g(a, AM<float>{__shfl_xor(a.v, o, 64), __shfl_xor(a.idx, o, 64)});
@@ -784,17 +820,94 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
             });
             fft_mixed<NC, -1>(x);                             // inverse over kx: corr(y = lane, x) = real part at slot MIXED_POS<x>
             __syncthreads();                                  // (rows read: the tile becomes the map)
+            // ---- peak analysis with the map row of the lane in registers: the decisions of the sweeps below (first flat
+            //      index of the maximum, largest cell outside the flat-index neighbourhood), without their passes over LDS
+            int ys = r + hshift;
+            ys -= ys >= n ? n : 0;
+            float rowv[NC];                                   // fftshift column order
+            float rmn = 3.4e38f;
+            static_for<0, NC>([&](auto xc) TPIV_LAMBDA_INLINE {
+                constexpr int xs = decltype(xc)::value;
+                rowv[xs] = x[fmx::MIXED_POS<(xs + NC / 2) % NC, NC>].x;
+                rmn = fminf(rmn, rowv[xs]);
+            });
+            cmin = wave_min(on ? rmn : 3.4e38f);
+            float rmx = -1.f;
+            static_for<0, NC>([&](auto xc) TPIV_LAMBDA_INLINE {
+                constexpr int xs = decltype(xc)::value;
+                rowv[xs] = add_eps(rowv[xs], cmin);           // B:518, B:381
+                rmx = fmaxf(rmx, rowv[xs]);
+            });
             if (on) {
-                int ys = r + hshift;
-                ys -= ys >= n ? n : 0;
+                static_for<0, NC>([&](auto xc) TPIV_LAMBDA_INLINE { map[ys * NC + decltype(xc)::value] = rowv[decltype(xc)::value]; });
+                if (p.dbg_corr != nullptr) {
+                    static_for<0, NC>([&](auto xc) TPIV_LAMBDA_INLINE {
+                        p.dbg_corr[fidx * nn + ys * NC + decltype(xc)::value] = rowv[decltype(xc)::value];
+                    });
+                }
+            }
+            const float gmax = wave_maxf(on ? rmx : -1.f);
+            // first flat index holding the maximum (B:383): smallest row, then smallest column of that row
+            const int ywin = wave_mini((on && rmx == gmax) ? ys : NC);
+            int xf = 0;
+            static_for<0, NC>([&](auto xc) TPIV_LAMBDA_INLINE {
+                constexpr int xs = NC - 1 - decltype(xc)::value;
+                xf = rowv[xs] == gmax ? xs : xf;
+            });
+            int row_lane = ywin + NC - hshift;                // the lane that holds map row ywin
+            row_lane -= row_lane >= NC ? NC : 0;
+            const int xwin = __shfl(xf, ywin < NC ? row_lane : 0, 64);
+            const int m = ywin < NC ? ywin * NC + xwin : 0;   // (no cell compared equal: an all-NaN map keeps index 0)
+            // largest cell outside the flat-index neighbourhood of m (B:346-358): q = clamp(m + i + n j), |i|, |j| <= wv -- in
+            // row y' the columns mx+i (j = y'-my), mx+i+n (j = y'-my+1), mx+i-n (j = y'-my-1), plus the two clamps
+            const int wv = p.val_win;
+            int smax = 0;                                     // every cell is > 0: positive floats order like their bits
+            {
+                const int my_ = m / NC, mx_ = m - my_ * NC, dj = ys - my_;
+                unsigned long long ex = 0ull;
+                auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
+                    lo_ = lo_ < 0 ? 0 : lo_;
+                    hi_ = hi_ > NC - 1 ? NC - 1 : hi_;
+                    if (lo_ > hi_) return 0ull;
+                    const unsigned long long ones = (hi_ - lo_ + 1) >= 64 ? ~0ull : ((1ull << (hi_ - lo_ + 1)) - 1ull);
+                    return ones << lo_;
+                };
+                if (dj >= -wv && dj <= wv) ex |= span(mx_ - wv, mx_ + wv);
+                if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(mx_ - wv + NC, mx_ + wv + NC);
+                if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx_ - wv - NC, mx_ + wv - NC);
+                if (ys == 0 && (m - wv - wv * NC) <= 0) ex |= 1ull;
+                if (ys == NC - 1 && (m + wv + wv * NC) >= nn - 1) ex |= 1ull << (NC - 1);
+                const int exl = (int)(unsigned)ex, exh = (int)(unsigned)(ex >> 32);
                 static_for<0, NC>([&](auto xc) TPIV_LAMBDA_INLINE {
-                    constexpr int xo = decltype(xc)::value;
-                    constexpr int xs = (xo + NC / 2) % NC;
-                    const float re = x[fmx::MIXED_POS<xo, NC>].x;
-                    map[ys * NC + xs] = re;
-                    cmin = rmin(cmin, re);
+                    constexpr int xs = decltype(xc)::value;
+                    const int kill = __builtin_amdgcn_sbfe(xs < 32 ? exl : exh, xs & 31, 1);
+                    const int cnd = __float_as_int(rowv[xs]) | kill;
+                    smax = cnd > smax ? cnd : smax;
                 });
             }
+            smax = wave_maxi(on ? smax : 0);
+            __syncthreads();                                  // (the map is complete)
+            if (tid < 8) {
+                int left = m + 1, right = m - 1, top = m + n, bot = m - n;    // B:385-392
+                if (left >= nn - 1) left = m;
+                if (right <= 0) right = m;
+                if (top >= nn - 1) top = m;
+                if (bot <= 0) bot = m;
+                int q = m;
+                q = (tid == 1) ? left : q;
+                q = (tid == 2) ? right : q;
+                q = (tid == 3) ? top : q;
+                q = (tid == 4) ? bot : q;
+                q = (tid == 5) ? 0 : q;
+                float outv = map[q];
+                // (nothing left outside the zone: the reference's second arg-max returns index 0 -- see xcorr_generic_kernel)
+                if (tid == 5) outv = smax > 0 ? __int_as_float(smax) : (MODE == MODE_PASS1 ? 0.f : outv);
+                outv = (tid == 6) ? __int_as_float(m) : outv;
+                outv = (tid == 7) ? __int_as_float(dead ? 1 : 0) : outv;
+                p.peak_raw[fidx * 8 + tid] = outv;
+            }
+            __syncthreads();
+            continue;
         } else {
         // mean removal (conditions the float32 transform; corr - min is unchanged by it) and the normalisation
 #pragma unroll 4
