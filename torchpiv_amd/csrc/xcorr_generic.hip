@@ -642,6 +642,15 @@ __device__ __forceinline__ void axis_transform(cff* a, cff* tmp, int n, int n1, 
     __syncthreads();
 }
 
+// byte offset of the per-window data of the compile-time form inside the dynamic LDS (behind the tiles and the patches)
+__host__ __device__ constexpr size_t ct_register_meta_offset(int n, int wpw) {
+    return ((size_t)wpw * n * (n | 1) * 8 + 2 * (size_t)(n + 4) * (n + 4) + 15) / 16 * 16;
+}
+// windows per wavefront of the compile-time form: 64 / n lane groups of n lanes (two windows of 28, five of 12) -- but one for
+// CWS: its staging (patch fetch + reference-order bilinear samples, all 64 lanes, window after window) is most of the pass,
+// and the packed form's registers (161 -> 208 at 28) cost it the third wavefront per SIMD: 28x28 CWS 155 -> 180 us per pair
+// packed, while DWS goes 124 -> 83
+__host__ __device__ constexpr int ct_register_wpw(int n, int mode) { return (n > 0 && n <= 64 && mode != MODE_CWS) ? 64 / n : 1; }
 // NC > 0: the window size as a compile-time constant -- ONE wavefront per window, lane = line, the four transforms as
 // in-register mixed-radix codelets (fft_mixed.hpp) with LDS only for the two transpositions; staging and peak analysis are
 // the loops of the run-time form with n known to the compiler.  NC = 0: the run-time form (any even n whose factors fit).
@@ -649,10 +658,14 @@ template <int MODE, int NC>
 __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(PassParams p, int n1, int n2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ct_smem[];
     const int n = NC > 0 ? NC : p.ws, nn = n * n, P = n | 1;      // tile pitch: odd (rows and columns both conflict-poor)
+    // compile-time form: WPW windows per wavefront (lane groups of NC lanes), one tile each
+    constexpr int WPW = ct_register_wpw(NC, MODE);
     cff* T0 = reinterpret_cast<cff*>(ct_smem);
-    cff* T1 = T0 + n * P;                                   // (NC > 0: no second tile -- the patches sit behind the first)
+    cff* T1 = T0 + WPW * n * P;                             // (NC > 0: no second tile -- the patches sit behind the WPW first ones)
     cff* tw = T1 + n * P;                                   // exp(-2 pi i k / n), k < n
     float* red = reinterpret_cast<float*>(tw + n);          // 2 x CT_WAVES reduction slots
+    // compile-time form: per window of the wavefront {mean a, mean b, 1 / mean a, 1 / mean b, dead, stored, record index}
+    float* wmeta = reinterpret_cast<float*>(ct_smem + ct_register_meta_offset(n, WPW));
     const int PD = n + 4;                                   // CWS: source patch of a shifted window incl. the interpolation margin
     uint8_t* patch_a = reinterpret_cast<uint8_t*>(T1);      // (the patches live in the second tile's memory: it is idle until the
     uint8_t* patch_b = patch_a + PD * PD;                   //  first transform -- more LDS would cost a resident wavefront per CU)
@@ -671,12 +684,23 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
         __syncthreads();
     }
 
-    for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+    const long long groups = (items + WPW - 1) / WPW;
+    for (long long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        // per window of the group: staging into its tile, then means, normalisation and record index into `wmeta` (a ROLLED
+        // loop: unrolled, the compiler overlaps the windows' sampling code and the CWS instance goes from 161 to 247 registers)
+        float ma = 0.f, mb = 0.f, ka = 1.f, kb = 1.f;
+        bool dead = false;
+        size_t fidx = 0;
+#pragma unroll 1
+        for (int wi = 0; wi < WPW; ++wi) {
+        const bool act = grp * WPW + wi < items;              // (a slot past the last window re-does it; its record is not stored)
+        const long long item = act ? grp * WPW + wi : items - 1;
+        cff* const Tw = T0 + wi * n * P;
         const int pair = (int)(item / N), win = (int)(item % N);
         const int y0 = (win / p.n_cols) * st, x0 = (win % p.n_cols) * st;
         const uint8_t* __restrict__ fa = p.A + (size_t)pair * HW;
         const uint8_t* __restrict__ fb = p.B + (size_t)pair * HW;
-        const size_t fidx = (size_t)item;
+        fidx = (size_t)item;
         float vx = 0.f, vy = 0.f;
         long long sh = 0;
         if constexpr (MODE == MODE_DWS) {
@@ -727,7 +751,7 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
                 a = bicubic_local(fa, p.W, y0, x0, n, x, y, -vx, -vy);
                 b = bicubic_local(fb, p.W, y0, x0, n, x, y, vx, vy);
             }
-            T0[y * P + x] = cff{a, b};
+            Tw[y * P + x] = cff{a, b};
             sa += a;
             sb += b;
             if (p.dbg_win != nullptr) {
@@ -737,24 +761,51 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
         }
         sa = ct_sum(sa, red);
         sb = ct_sum(sb, red);
-        const float ma = sa / (float)nn, mb = sb / (float)nn;
-        bool dead = false;
-        float ka = 1, kb = 1;
+        ma = sa / (float)nn, mb = sb / (float)nn;
+        dead = false;
+        ka = 1, kb = 1;
         if constexpr (MODE == MODE_PASS1 || MODE == MODE_CWSF) {      // a / mean(a): B:513-514, B:656-657
             dead = (sa == 0) || (sb == 0);
             ka = dead ? 0.f : 1.f / ma;
             kb = dead ? 0.f : 1.f / mb;
         }
-        __syncthreads();
+        if constexpr (NC > 0) {
+            if (tid == 0) {
+                float* mt = wmeta + wi * 8;
+                mt[0] = ma, mt[1] = mb, mt[2] = ka, mt[3] = kb;
+                mt[4] = __int_as_float(dead ? 1 : 0), mt[5] = __int_as_float(act ? 1 : 0);
+                mt[6] = __int_as_float((int)(unsigned)fidx), mt[7] = __int_as_float((int)(unsigned)(fidx >> 32));
+            }
+        }
+        __syncthreads();                                      // (tile complete; the patches are free for the next window)
+        }
         float* map = reinterpret_cast<float*>(T0);
         float cmin = 3.4e38f;
         const int hshift = n / 2;
         if constexpr (NC > 0) {
-            // ---- lane = line; every transform on registers, the tile only for the two transpositions
+            // ---- lane = line of window wq; every transform on registers, the tile only for the two transpositions
             using fmx::fft_mixed;
-            const int r = tid < NC ? tid : 0;                 // (lanes >= NC idle along with lane 0's data; their stores are masked)
-            const bool on = tid < NC;
-            const int mirror = (NC - r) % NC;                 // the lane that holds column -kx
+            const bool on = tid < WPW * NC;                   // (the lanes behind the last group idle along with lane 0's data; their stores are masked)
+            const int wq = on ? tid / NC : 0;
+            const int r = on ? tid - wq * NC : 0;
+            const int base = wq * NC;                         // first lane of the window's group
+            cff* const T0 = reinterpret_cast<cff*>(ct_smem) + wq * n * P;       // this lane's window: tile, then map
+            float* const map = reinterpret_cast<float*>(T0);
+            const float* mt = wmeta + wq * 8;                 // this lane's window
+            const float ma = mt[0], mb = mt[1], ka = mt[2], kb = mt[3];
+            const bool dead = __float_as_int(mt[4]) != 0, act = __float_as_int(mt[5]) != 0;
+            const size_t fidx = (size_t)(unsigned)__float_as_int(mt[6]) | ((size_t)(unsigned)__float_as_int(mt[7]) << 32);
+            const int mirror = base + (NC - r) % NC;          // the lane that holds column -kx
+            // reductions over the lanes of the window (groups of NC lanes, any NC): halving steps towards the group's
+            // first lane -- lane r takes lane r + o while that lane belongs to the group --, then a broadcast
+            auto seg = [&](auto v, auto&& op) TPIV_LAMBDA_INLINE {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const auto t_ = __shfl_down(v, o, 64);
+                    v = (o < NC && r + o < NC) ? op(v, t_) : v;
+                }
+                return __shfl(v, base, 64);
+            };
             cf x[NC];
             static_for<0, NC>([&](auto kc) TPIV_LAMBDA_INLINE {
                 constexpr int k = decltype(kc)::value;
@@ -831,7 +882,7 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
                 rowv[xs] = x[fmx::MIXED_POS<(xs + NC / 2) % NC, NC>].x;
                 rmn = fminf(rmn, rowv[xs]);
             });
-            cmin = wave_min(on ? rmn : 3.4e38f);
+            cmin = seg(on ? rmn : 3.4e38f, [](float a_, float b_) TPIV_LAMBDA_INLINE { return fminf(a_, b_); });
             float rmx = -1.f;
             static_for<0, NC>([&](auto xc) TPIV_LAMBDA_INLINE {
                 constexpr int xs = decltype(xc)::value;
@@ -846,9 +897,9 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
                     });
                 }
             }
-            const float gmax = wave_maxf(on ? rmx : -1.f);
+            const float gmax = seg(on ? rmx : -1.f, [](float a_, float b_) TPIV_LAMBDA_INLINE { return fmaxf(a_, b_); });
             // first flat index holding the maximum (B:383): smallest row, then smallest column of that row
-            const int ywin = wave_mini((on && rmx == gmax) ? ys : NC);
+            const int ywin = seg((on && rmx == gmax) ? ys : NC, [](int a_, int b_) TPIV_LAMBDA_INLINE { return a_ < b_ ? a_ : b_; });
             int xf = 0;
             static_for<0, NC>([&](auto xc) TPIV_LAMBDA_INLINE {
                 constexpr int xs = NC - 1 - decltype(xc)::value;
@@ -856,7 +907,7 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
             });
             int row_lane = ywin + NC - hshift;                // the lane that holds map row ywin
             row_lane -= row_lane >= NC ? NC : 0;
-            const int xwin = __shfl(xf, ywin < NC ? row_lane : 0, 64);
+            const int xwin = __shfl(xf, base + (ywin < NC ? row_lane : 0), 64);
             const int m = ywin < NC ? ywin * NC + xwin : 0;   // (no cell compared equal: an all-NaN map keeps index 0)
             // largest cell outside the flat-index neighbourhood of m (B:346-358): q = clamp(m + i + n j), |i|, |j| <= wv -- in
             // row y' the columns mx+i (j = y'-my), mx+i+n (j = y'-my+1), mx+i-n (j = y'-my-1), plus the two clamps
@@ -885,9 +936,10 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
                     smax = cnd > smax ? cnd : smax;
                 });
             }
-            smax = wave_maxi(on ? smax : 0);
+            smax = seg(on ? smax : 0, [](int a_, int b_) TPIV_LAMBDA_INLINE { return a_ > b_ ? a_ : b_; });
             __syncthreads();                                  // (the map is complete)
-            if (tid < 8) {
+            if (on && r < 8 && act) {
+                const int tid = r;                            // (record slot)
                 int left = m + 1, right = m - 1, top = m + n, bot = m - n;    // B:385-392
                 if (left >= nn - 1) left = m;
                 if (right <= 0) right = m;
@@ -1020,7 +1072,10 @@ static bool ct_register_size(int n) {
 #undef TPIV_CTR_IS
     return false;
 }
-static size_t ct_register_smem(int n) { return ((size_t)n * (n | 1) * sizeof(cff) + 2 * (size_t)(n + 4) * (n + 4) + 15) / 16 * 16; }
+// (one tile per window of a wavefront, one pair of CWS patches, and eight floats of per-window data)
+static size_t ct_register_smem(int n, int mode) {
+    return ct_register_meta_offset(n, ct_register_wpw(n, mode)) + (size_t)ct_register_wpw(n, mode) * 8 * sizeof(float);
+}
 constexpr int CT_MAX_RADIX = 8;
 // n = n1 n2 with 2 <= n1 <= n2 <= CT_MAX_RADIX, n1 as large as possible; false if there is no such split
 bool ct_factors(int n, int& n1, int& n2) {
@@ -1078,11 +1133,13 @@ hipError_t launch_xcorr_generic(const PassParams& p, int mode, int n_cu, void* s
         hipError_t e_ = hipSuccess;
         // sizes with a compile-time instance (in-register transforms, one wavefront per window): every mode but CWS_Fast
         if (mode != MODE_CWSF && ct_register_size(p.ws)) {
-            const size_t smem_r = ct_register_smem(p.ws);
+            const size_t smem_r = ct_register_smem(p.ws, mode);
             int per_cu_r = (int)((160 * 1024) / smem_r);
             per_cu_r = per_cu_r > 16 ? 16 : (per_cu_r < 1 ? 1 : per_cu_r);
             long long blocks_r = (long long)n_cu * per_cu_r;
-            if (blocks_r > items) blocks_r = items;
+            const int wpw_r = ct_register_wpw(p.ws, mode);
+            const long long groups_r = (items + wpw_r - 1) / wpw_r;
+            if (blocks_r > groups_r) blocks_r = groups_r;
 #define TPIV_CTR_LAUNCH(M, NCV)                                                                                         \
     e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcorr_generic_ct_kernel<M, NCV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_r); \
     if (e_ == hipSuccess) hipLaunchKernelGGL((xcorr_generic_ct_kernel<M, NCV>), dim3((unsigned)blocks_r), dim3(64), smem_r, stream, p, n1, n2);
