@@ -8,7 +8,7 @@ scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.5
 mode = sys.argv[3] if len(sys.argv) > 3 else "CWS"
 A0, B0 = synth.make_batch(2, 2048, 2048, device="cuda")
 A = A0.repeat(batch // 2, 1, 1).contiguous(); B = B0.repeat(batch // 2, 1, 1).contiguous()
-for prec in ("f64", "fast"):
+for prec in ("exact", "f64", "fast"):
     plan = engine.Plan(2048, 2048, 64, 32, n_pass=3, mode=mode, pass_scale=scale, max_batch=batch, precision=prec)
     out = plan.run(A, B); torch.cuda.synchronize()
     plan.set_timing(True)

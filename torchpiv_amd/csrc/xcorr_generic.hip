@@ -54,7 +54,7 @@ __device__ __forceinline__ float cws_sample_g(const uint8_t* __restrict__ f, int
 // The same sample with the four corner pixels taken from a patch of the frame that the wavefront loaded into LDS
 // (patch[py][px] = pixel with the flat index clamp((by + py) * W + (bx + px)), i.e. exactly what fetch_clamped_g returns for
 // that corner); a corner outside the patch -- a wild predictor -- falls back to the global fetch.
-__device__ __forceinline__ float cws_sample_patch(const uint8_t* __restrict__ patch, int PD, int bx, int by,
+__device__ __forceinline__ float cws_sample_patch(const uint8_t* __restrict__ patch, int PD, int pitch, int bx, int by,
                                                   const uint8_t* __restrict__ f, int HW, int W, int gx, int gy, float vx, float vy) {
 #pragma clang fp contract(off)
     const float nx = (float)gx + vx, ny = (float)gy + vy;
@@ -67,8 +67,8 @@ __device__ __forceinline__ float cws_sample_patch(const uint8_t* __restrict__ pa
     const bool inside = ((unsigned)py0 < (unsigned)PD) & ((unsigned)px0 < (unsigned)PD) & ((unsigned)py1 < (unsigned)PD) &
                         ((unsigned)px1 < (unsigned)PD);
     if (__builtin_expect(__all(inside), 1)) {
-        const uint8_t* q0 = patch + py0 * PD + px0;
-        const int ox = px1 - px0, oy = (py1 - py0) * PD;
+        const uint8_t* q0 = patch + py0 * pitch + px0;
+        const int ox = px1 - px0, oy = (py1 - py0) * pitch;
         f11 = (float)q0[0];
         f21 = (float)q0[ox];
         f12 = (float)q0[oy];
@@ -76,7 +76,7 @@ __device__ __forceinline__ float cws_sample_patch(const uint8_t* __restrict__ pa
     } else {
         auto px = [&](int yy, int xx) {
             const int py = yy - by, pxx = xx - bx;
-            return ((unsigned)py < (unsigned)PD && (unsigned)pxx < (unsigned)PD) ? (float)patch[py * PD + pxx]
+            return ((unsigned)py < (unsigned)PD && (unsigned)pxx < (unsigned)PD) ? (float)patch[py * pitch + pxx]
                                                                                    : fetch_clamped_g(f, (long long)yy * W + xx, HW);
         };
         f11 = px(dy, dx), f21 = px(dy, ux), f12 = px(uy, dx), f22 = px(uy, ux);
@@ -644,7 +644,7 @@ __device__ __forceinline__ void axis_transform(cff* a, cff* tmp, int n, int n1, 
 
 // byte offset of the per-window data of the compile-time form inside the dynamic LDS (behind the tiles and the patches)
 __host__ __device__ constexpr size_t ct_register_meta_offset(int n, int wpw) {
-    return ((size_t)wpw * n * (n | 1) * 8 + 2 * (size_t)(n + 4) * (n + 4) + 15) / 16 * 16;
+    return ((size_t)wpw * n * (n | 1) * 8 + 2 * (size_t)(n + 4) * ((n + 7) & ~3) + 15) / 16 * 16;
 }
 // windows per wavefront of the compile-time form: 64 / n lane groups of n lanes (two windows of 28, five of 12) -- but one for
 // CWS: its staging (patch fetch + reference-order bilinear samples, all 64 lanes, window after window) is most of the pass,
@@ -667,8 +667,9 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
     // compile-time form: per window of the wavefront {mean a, mean b, 1 / mean a, 1 / mean b, dead, stored, record index}
     float* wmeta = reinterpret_cast<float*>(ct_smem + ct_register_meta_offset(n, WPW));
     const int PD = n + 4;                                   // CWS: source patch of a shifted window incl. the interpolation margin
+    const int PDP = (PD + 3) & ~3;                          // its row pitch in LDS (rows start on dword boundaries)
     uint8_t* patch_a = reinterpret_cast<uint8_t*>(T1);      // (the patches live in the second tile's memory: it is idle until the
-    uint8_t* patch_b = patch_a + PD * PD;                   //  first transform -- more LDS would cost a resident wavefront per CU)
+    uint8_t* patch_b = patch_a + PD * PDP;                  //  first transform -- more LDS would cost a resident wavefront per CU)
     const int tid = threadIdx.x;
     const int N = p.n_rows * p.n_cols;
     const long long items = (long long)p.batch * N;
@@ -722,12 +723,30 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
             bya = y0 + f2i_sat_g(floorf(-vy)) - 1;
             bxb = x0 + f2i_sat_g(floorf(vx)) - 1;
             byb = y0 + f2i_sat_g(floorf(vy)) - 1;
-            const float rcp_pd = 1.0f / (float)PD;
+            // a patch that lies inside the frame with its pitch-padded rows (every window but the border ones, every predictor
+            // but a wild one) is fetched four pixels per load; its pixels are the same flat indices either way (B:177-180)
+            const long long lo_a = (long long)bya * p.W + bxa, hi_a = (long long)(bya + PD - 1) * p.W + bxa + PDP - 1;
+            const long long lo_b = (long long)byb * p.W + bxb, hi_b = (long long)(byb + PD - 1) * p.W + bxb + PDP - 1;
+            if (lo_a >= 0 && lo_b >= 0 && hi_a <= (long long)HW - 1 && hi_b <= (long long)HW - 1) {      // (wave-uniform)
+                const int ndw = PDP >> 2;
+                const float rcp_dw = 1.0f / (float)ndw;
 #pragma unroll 4
-            for (int i = tid; i < PD * PD; i += (int)blockDim.x) {
-                const int py = div_small(i, rcp_pd), px = i - py * PD;
-                patch_a[i] = (uint8_t)fetch_clamped_g(fa, (long long)(bya + py) * p.W + (bxa + px), HW);
-                patch_b[i] = (uint8_t)fetch_clamped_g(fb, (long long)(byb + py) * p.W + (bxb + px), HW);
+                for (int i = tid; i < PD * ndw; i += (int)blockDim.x) {
+                    const int py = div_small(i, rcp_dw), k = i - py * ndw;
+                    uint32_t da, db;
+                    __builtin_memcpy(&da, fa + lo_a + (long long)py * p.W + 4 * k, 4);
+                    __builtin_memcpy(&db, fb + lo_b + (long long)py * p.W + 4 * k, 4);
+                    reinterpret_cast<uint32_t*>(patch_a)[py * ndw + k] = da;
+                    reinterpret_cast<uint32_t*>(patch_b)[py * ndw + k] = db;
+                }
+            } else {
+                const float rcp_pd = 1.0f / (float)PD;
+#pragma unroll 4
+                for (int i = tid; i < PD * PD; i += (int)blockDim.x) {
+                    const int py = div_small(i, rcp_pd), px = i - py * PD;
+                    patch_a[py * PDP + px] = (uint8_t)fetch_clamped_g(fa, (long long)(bya + py) * p.W + (bxa + px), HW);
+                    patch_b[py * PDP + px] = (uint8_t)fetch_clamped_g(fb, (long long)(byb + py) * p.W + (bxb + px), HW);
+                }
             }
             __syncthreads();
         }
@@ -745,8 +764,8 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
                 a = fetch_clamped_g(fa, q - sh, HW);
                 b = fetch_clamped_g(fb, q + sh, HW);
             } else if constexpr (MODE == MODE_CWS) {
-                a = cws_sample_patch(patch_a, PD, bxa, bya, fa, HW, p.W, x0 + x, y0 + y, -vx, -vy);
-                b = cws_sample_patch(patch_b, PD, bxb, byb, fb, HW, p.W, x0 + x, y0 + y, vx, vy);
+                a = cws_sample_patch(patch_a, PD, PDP, bxa, bya, fa, HW, p.W, x0 + x, y0 + y, -vx, -vy);
+                b = cws_sample_patch(patch_b, PD, PDP, bxb, byb, fb, HW, p.W, x0 + x, y0 + y, vx, vy);
             } else {
                 a = bicubic_local(fa, p.W, y0, x0, n, x, y, -vx, -vy);
                 b = bicubic_local(fb, p.W, y0, x0, n, x, y, vx, vy);
@@ -1086,7 +1105,7 @@ bool ct_factors(int n, int& n1, int& n2) {
     n2 = n / n1;
     return n1 >= 2 && n2 <= CT_MAX_RADIX;
 }
-size_t ct_smem_bytes(int n) { return (size_t)(2 * n * (n | 1) + n) * sizeof(cff) + 2 * CT_WAVES * sizeof(float); }     // (2 (n + 4)^2 patch bytes fit the second tile, n >= 4)
+size_t ct_smem_bytes(int n) { return (size_t)(2 * n * (n | 1) + n) * sizeof(cff) + 2 * CT_WAVES * sizeof(float); }     // (the two (n + 4) x pitch patches fit the second tile, n >= 4)
 bool ct_usable(int n, int precision) {
     int a, b;
     return precision == 0 && (n & 1) == 0 && n >= 4 && n <= 96 && ct_factors(n, a, b) && ct_smem_bytes(n) <= 160 * 1024;
