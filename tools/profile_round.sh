@@ -13,7 +13,7 @@
 #   files_profile.txt           where the file path spends its time
 #   bench_e2e_gloo2.json        the GENERATOR path sharded over 2 gloo ranks on the one GPU (bench.py --gpus 2 --e2e): launch,
 #                               per-rank host budget and the end-of-run gather from device-resident fields -- a rehearsal
-#   generic_chain.txt           64/32 -> 42/21 -> 28/14 (multipass_scale 1.5) with the first- and second-generation generic kernel
+#   generic_chain.txt           64/32 -> 42/21 -> 28/14 (multipass_scale 1.5) with the three generations of the generic kernel
 # PART=a: the bench lines and the kernel statistics; PART=b: other configs, stamps, file path, rehearsals (two gpurun calls)
 # Outputs: gpurun_out/$1/ ; tools/collect_profile.py copies what is to be judged into profiles/<round>/.
 set -o pipefail
@@ -55,7 +55,8 @@ TPIV_LIB=tools/diag/libtorchpiv_hip_stamps.so python3 tools/stamp_f64.py > $OUT/
 python3 tools/dev/files_profile.py 8 8 8 spots 2 32 2> /dev/null | grep -v amdgpu.ids > $OUT/files_profile.txt
 TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --e2e --e2e-pairs 64 > $OUT/bench_e2e_gloo2.json 2> $OUT/e2e_g2.err || tail -3 $OUT/e2e_g2.err
 python3 bench.py --e2e --e2e-pairs 128 > $OUT/bench_e2e_n1.json 2> $OUT/e2e_n1.err || tail -3 $OUT/e2e_n1.err
-{ TPIV_GENERIC_CT=0 python3 tools/dev/generic_chain.py 16 1.5 CWS; python3 tools/dev/generic_chain.py 16 1.5 CWS; python3 tools/dev/generic_chain.py 16 1.5 DWS; } 2> /dev/null | grep -v amdgpu.ids > $OUT/generic_chain.txt
+# first generation (plain DFTs), second (run-time two-factor form), third (compile-time instances, in-register transforms)
+{ TPIV_GENERIC_CT=0 python3 tools/dev/generic_chain.py 16 1.5 CWS; TPIV_GENERIC_REG=0 python3 tools/dev/generic_chain.py 16 1.5 CWS; python3 tools/dev/generic_chain.py 16 1.5 CWS; python3 tools/dev/generic_chain.py 16 1.5 DWS; } 2> /dev/null | grep -v amdgpu.ids > $OUT/generic_chain.txt
 fi
 python3 - $OUT <<'PY'
 import json, sys, glob, os
