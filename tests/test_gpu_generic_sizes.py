@@ -11,7 +11,7 @@ from oracle import piv_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-REGISTER_SIZES = [12, 14, 18, 24, 28, 36, 42, 48, 56]       # TPIV_CT_REGISTER_SIZES, csrc/xcorr_generic.hip
+REGISTER_SIZES = [12, 14, 18, 20, 24, 28, 30, 36, 40, 42, 48, 56]       # TPIV_CT_REGISTER_SIZES, csrc/xcorr_generic.hip
 
 
 @pytest.fixture(scope="module")
@@ -26,8 +26,11 @@ def test_the_list_is_the_librarys(eng):
         plan = eng.Plan(8 * n, 8 * n, 2 * n, n, n_pass=2, mode="CWS", max_batch=1, precision="fast")
         assert plan.kernel_name(1) == f"xcorr_generic_ct_kernel<2, {n}>", (n, plan.kernel_name(1))
         plan.close()
-    plan = eng.Plan(320, 320, 80, 40, n_pass=2, mode="DWS", max_batch=1, precision="fast")      # 40 = 5 x 8: run-time form
-    assert plan.kernel_name(1) == "xcorr_generic_ct_kernel<1, 0>", plan.kernel_name(1)
+    plan = eng.Plan(352, 352, 88, 44, n_pass=2, mode="DWS", max_batch=1, precision="fast")      # 44 = 4 x 11: no two-factor split
+    assert plan.kernel_name(1) == "xcorr_generic_kernel<1, float>", plan.kernel_name(1)
+    plan.close()
+    plan = eng.Plan(160, 160, 20, 10, n_pass=2, mode="DWS", max_batch=1, precision="fast")      # 10 = 2 x 5: run-time form
+    assert plan.geometry[1][0] == 10 and plan.kernel_name(1) == "xcorr_generic_ct_kernel<1, 0>", (plan.geometry, plan.kernel_name(1))
     plan.close()
 
 

@@ -1081,7 +1081,7 @@ static int ct_threads(int n) { return n >= 40 ? CT_T : 64; }
 // 1.33 make of 128 / 64 / 48 / 32 first passes, each in the three reachable modes; anything else takes the run-time form.
 // (TPIV_GENERIC_REG=0: run-time form for every size -- A/B runs)
 #ifndef TPIV_CT_REGISTER_SIZES
-#define TPIV_CT_REGISTER_SIZES(X) X(12) X(14) X(18) X(24) X(28) X(36) X(42) X(48) X(56)
+#define TPIV_CT_REGISTER_SIZES(X) X(12) X(14) X(18) X(20) X(24) X(28) X(30) X(36) X(40) X(42) X(48) X(56)
 #endif
 static bool ct_register_size(int n) {
     static const bool off = [] { const char* e_ = getenv("TPIV_GENERIC_REG"); return e_ && e_[0] == '0'; }();
