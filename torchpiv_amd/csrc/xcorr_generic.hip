@@ -493,27 +493,6 @@ __device__ __forceinline__ float wave_min(float v) {
     for (int o = 32; o > 0; o >>= 1) v = rmin(v, __shfl_xor(v, o, 64));
     return v;
 }
-__device__ __forceinline__ float wave_maxf(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_mini(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int w = __shfl_xor(v, o, 64);
-        v = w < v ? w : v;
-    }
-    return v;
-}
-__device__ __forceinline__ int wave_maxi(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
-}
 __device__ __forceinline__ AM<float> wave_argmax(AM<float> a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a = better_g(a, AM<float>{__shfl_xor(a.v, o, 64), __shfl_xor(a.idx, o, 64)});
