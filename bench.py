@@ -531,6 +531,27 @@ def main():
         del u_all, v_all, i_all
         return res
 
+    def exact_against_f64():
+        """The first-pass fields of the bench batch at precision "exact" against the same batch through the float64 FFT
+        kernel (what the exact sums replace): every window of the workload the headline is measured on."""
+        out = {}
+        fields = {}
+        for prec in ("exact", "f64"):
+            plan = engine.Plan(H, W, ws, ov, n_pass=args.passes, mode=args.mode, max_batch=shards[0][1], device=dev, precision=prec)
+            plan.run(A[:shards[0][1]], B[:shards[0][1]])
+            fields[prec] = plan.pass_fields(0, shards[0][1]) if plan.n_pass > 1 else None
+            if prec == "exact":
+                out["undecided_windows"] = plan.exact_fallbacks()
+            plan.close()
+        if fields["exact"] is None:
+            return None
+        (ue, ve, ie), (uf, vf, i_f) = fields["exact"], fields["f64"]
+        d = torch.maximum((ue - uf).abs(), (ve - vf).abs())
+        out.update({"windows": int(d.numel()), "max_abs_diff_px": float(d.max()), "bit_identical_windows": int((d == 0).sum()),
+                    "validity_flags_differing": int((ie != i_f).sum()),
+                    "note": "first-pass u, v, invalid of one launch of the bench batch: precision \"exact\" against the float64 FFT of every window"})
+        return out
+
     if args.pmc_child:
         for prec in args.precision.split(","):
             measure(prec, args.steps, args.warmup, timed=False)
@@ -543,6 +564,12 @@ def main():
     also_f64 = also_fast and args.precision == "exact"
     f64_run = measure("f64", args.steps, args.warmup) if also_f64 else None
     fast = measure("fast", args.steps, args.warmup) if also_fast else None
+    parity = None
+    if also_f64 and "exact_timing" in head:
+        try:
+            parity = exact_against_f64()
+        except Exception as exc:                          # never let the side check break the bench line
+            parity = {"error": f"{type(exc).__name__}: {exc}"}
 
     # who ran: backend and devices as torch.distributed saw them (every rank reports, rank 0 prints)
     me = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(dev), "device_index": dev.index}
@@ -702,7 +729,7 @@ def main():
         }
         if "exact_timing" in head:
             rec["exact"] = {"pass1_ms": head["exact_timing"], "float64_path": head["exact_fallbacks"],
-                            "band": 1.0e-4, "min_contrast": 0.028,
+                            "band": 1.0e-4, "min_contrast": 0.028, "against_float64_fft": parity,
                             "note": "pass1_xcorr of kernel_ms = locate_f32 + refine_exact + undecided_f64 + finalize (HIP events "
                                     "behind each kernel); parity gates: tests/test_gpu_exact.py (<= 1e-11 px against the float64 "
                                     "kernel and the oracle, identical masks), error model: tools/research/exact_band.py"}

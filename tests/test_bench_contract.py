@@ -62,6 +62,10 @@ def test_committed_bench_line_keeps_the_contract():
     ex = line["exact"]
     assert math.isclose(sum(ex["pass1_ms"].values()), line["kernel_ms"]["pass1_xcorr"], rel_tol=0.02)
     assert 0 <= ex["float64_path"]["windows"] <= 0.01 * ex["float64_path"]["of"]
+    par = ex.get("against_float64_fft")
+    if par is not None:               # the same launch through the float64 FFT of every window: equal fields, equal flags
+        assert "error" not in par and par["max_abs_diff_px"] < 1e-11 and par["validity_flags_differing"] == 0
+        assert par["bit_identical_windows"] >= 0.99 * par["windows"]
     assert {"pass1_locate", "pass1_refine", "pass1_undecided_f64", "pass2_xcorr"} <= set(line["kernels"])
     # the float64-FFT run (the headline of rounds 2-3), the all-float32 run and the generator end to end ride on the same line
     assert line["f64_transform"]["dtype"] == "f64/f32" and line["f64_transform"]["value"] < line["value"]
