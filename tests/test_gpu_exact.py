@@ -154,3 +154,36 @@ def test_exact_on_windows_built_to_break_the_locating_pass(eng):
             assert n_fb <= 2, (name, n_fb)
         if name == "checkerboard vs stripes":
             assert n_fb == a.shape[0], (name, n_fb)          # map range 8e-6 of the scale: below the contrast guard, all of them
+
+
+
+def test_exact_random_geometries(eng):
+    """Frame sizes that are not multiples of anything, any overlap, any batch, validation windows 1..5: precision "exact"
+    against the float64 kernels on 40 seeded draws (row starts at every byte alignment, ragged last windows, one-window
+    grids)."""
+    rng = np.random.default_rng(20260)
+    for case in range(40):
+        ws = int(rng.choice([32, 64, 128]))
+        ov = int(rng.integers(0, ws))
+        H = int(rng.integers(ws, 5 * ws + 7))
+        W = int(rng.integers(ws, 5 * ws + 11))
+        batch = int(rng.integers(1, 5))
+        val_win = int(rng.integers(1, 6))
+        val_ratio = float(rng.choice([1.05, 1.2, 2.0]))
+        # particle-like frames with a shift, plus a dead block and a saturated block now and then
+        base = rng.integers(0, 40, (batch, H + 16, W + 16)).astype(np.float64)
+        for _ in range(H * W // 60):
+            y, x = int(rng.integers(2, H + 12)), int(rng.integers(2, W + 12))
+            base[:, y - 1:y + 2, x - 1:x + 2] += rng.uniform(60, 200)
+        sy, sx = int(rng.integers(0, 6)), int(rng.integers(0, 6))
+        A = np.clip(base[:, 5:5 + H, 5:5 + W], 0, 255).astype(np.uint8)
+        B = np.clip(base[:, 5 + sy:5 + sy + H, 5 + sx:5 + sx + W] + rng.integers(0, 6, (batch, H, W)), 0, 255).astype(np.uint8)
+        if case % 5 == 0:
+            A[0, : H // 3, : W // 2] = 0
+        if case % 7 == 0:
+            B[-1, H // 2:, W // 3:] = 255
+        kw = dict(val_ratio=val_ratio, val_win=val_win)
+        ue, ve, ie = eng.pass1(dev(A), dev(B), ws, ov, precision="exact", **kw)
+        uf, vf, i_f = eng.pass1(dev(A), dev(B), ws, ov, precision="f64", **kw)
+        d = max(float((ue - uf).abs().max()), float((ve - vf).abs().max()))
+        assert d < TOL_F64 and torch.equal(ie, i_f), (case, ws, ov, H, W, batch, val_win, d, int((ie != i_f).sum()))
