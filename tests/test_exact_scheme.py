@@ -69,9 +69,10 @@ def candidates(cmap, wv):
     else:
         second = np.zeros(0, np.int64)
     mins = np.flatnonzero(flat <= np.float32(lo) + band)
-    if mins.size > MAX_MIN:
-        return None
-    return m, [int(s) for s in second], [int(s) for s in mins]
+    overflow = mins.size > MAX_MIN          # (true-zero backgrounds: hundreds of cells at S = 0; see exact_window)
+    if overflow:
+        mins = mins[:MAX_MIN - 1]
+    return m, [int(s) for s in second], [int(s) for s in mins], overflow
 
 
 def exact_window(a, b, wv=3, val_ratio=1.2):
@@ -84,7 +85,7 @@ def exact_window(a, b, wv=3, val_ratio=1.2):
     cand = candidates(f32_map(a, b), wv)
     if cand is None:
         return None
-    m, second, mins = cand
+    m, second, mins, min_overflow = cand
     left, right, top, bot = m + 1, m - 1, m + W, m - W
     left = m if left >= KD - 1 else left
     right = m if right <= 0 else right
@@ -96,6 +97,8 @@ def exact_window(a, b, wv=3, val_ratio=1.2):
     smin = min(S[q] for q in mins)
     if min(S.values()) < smin:
         return None
+    if min_overflow and smin != 0:
+        return None                                 # S >= 0 everywhere: only an evaluated 0 is certainly the minimum
     ai, bi = a.astype(np.int64), b.astype(np.int64)
     e2 = (float((ai * ai).sum()) - float(sa) ** 2 / KD) * (float((bi * bi).sum()) - float(sb) ** 2 / KD)
     if not float(S[m] - smin) ** 2 >= MIN_CONTRAST ** 2 * e2:
@@ -168,3 +171,27 @@ def test_exact_sums_are_the_circular_correlation():
     c = O.xcorr_fft(a.astype(np.float64), b.astype(np.float64))
     for q in (0, 17, 100, 255, 136):
         assert abs(exact_sum(a, b, q) - c.reshape(-1)[q]) < 1e-6
+
+
+
+def test_exact_scheme_on_a_true_zero_background():
+    """Background-subtracted recordings: most map cells are exactly 0 (no particle pair overlaps at that shift) -- far more
+    minimum candidates than the record holds, and still decidable: S >= 0, so the evaluated zeros are the minimum."""
+    rng = np.random.default_rng(12)
+    H = W = 192
+    img = np.zeros((H + 8, W + 8))
+    for _ in range(120):
+        y, x = rng.integers(3, H + 4), rng.integers(3, W + 4)
+        img[y - 1:y + 2, x - 1:x + 2] += rng.uniform(80, 200)
+    A = np.clip(img[2:2 + H, 2:2 + W], 0, 255).astype(np.uint8)
+    B = np.clip(img[4:4 + H, 1:1 + W], 0, 255).astype(np.uint8)
+    u0, v0, _, _, m0 = O.pass1(A, B, 64, 32, validate=True)
+    aw, bw = O.windows(A, 64, 32), O.windows(B, 64, 32)
+    decided = 0
+    for i, (a, b) in enumerate(zip(aw, bw)):
+        r = exact_window(a, b)
+        if r is None:
+            continue
+        decided += 1
+        assert abs(r[0] - u0.reshape(-1)[i]) < 1e-10 and abs(r[1] - v0.reshape(-1)[i]) < 1e-10 and r[2] == bool(m0.reshape(-1)[i])
+    assert decided >= len(aw) // 2, (decided, len(aw))

@@ -152,6 +152,8 @@ def test_exact_on_windows_built_to_break_the_locating_pass(eng):
         assert d < TOL_F64 and torch.equal(ie, i_f), name
         if name.startswith("particles"):
             assert n_fb <= 2, (name, n_fb)
+        if name == "particles on a true-zero background":
+            assert n_fb <= a.shape[0] // 4, (name, n_fb)      # hundreds of minimum cells at S = 0 are decidable (S >= 0)
         if name == "checkerboard vs stripes":
             assert n_fb == a.shape[0], (name, n_fb)          # map range 8e-6 of the scale: below the contrast guard, all of them
 

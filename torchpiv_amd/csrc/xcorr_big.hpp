@@ -239,7 +239,9 @@ __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[B
             cnt = block_reduce(cnt, iadd_, sm.redc, wave, lane);          // (also: the lists are complete)
             if (t == 0) {
                 const int ns = sm.n_second, nn = sm.n_min;
-                open = open || cnt != 1 || ns > EXACT_MAX_SECOND || nn > EXACT_MAX_MIN;
+                // (more minimum cells than the record holds: three of them and -2 -- see peak_candidates, xcorr_tile.hpp)
+                open = open || cnt != 1 || ns > EXACT_MAX_SECOND;
+                if (nn > EXACT_MAX_MIN) sm.cand_min[EXACT_MAX_MIN - 1] = -2;
                 auto get = [](const int* l, int n, int k) TPIV_LAMBDA_INLINE { return k < n ? l[k] : -1; };
                 auto pack = [](int lo_, int hi_) TPIV_LAMBDA_INLINE { return ((unsigned)lo_ & 0xffffu) | ((unsigned)hi_ << 16); };
                 const int m_out = dead ? -2 : (open ? -1 : m);

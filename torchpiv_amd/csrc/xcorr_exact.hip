@@ -252,7 +252,11 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     const double range = (double)(s_m - s_min);
     const bool low_contrast = !(range * range >= (EXACT_MIN_CONTRAST * EXACT_MIN_CONTRAST) * ea2 * eb2);
     // (the first two cannot happen while the float32 map stays inside the band; sa, sb: the locating pass marks those)
-    const bool redo = s_top > s_m || s_low < s_min || s_min == 0xffffffffu || sa == 0u || sb == 0u || low_contrast;
+    // more minimum candidates than the record holds (-2 in its last slot): S >= 0 everywhere, so the evaluated ones settle
+    // it exactly when one of them is 0 (true-zero backgrounds); anything else goes to the float64 transform
+    const bool min_overflow = hi16(rec.w) == -2;
+    const bool redo = s_top > s_m || s_low < s_min || s_min == 0xffffffffu || sa == 0u || sb == 0u || low_contrast ||
+                      (min_overflow && s_min != 0u);
     if (go && redo) to_f64_kernel();
     // (S - S_min) n^4 / (sum a sum b) + 1e-7: the integer difference is exact, sum a * sum b < 2^44 is exact
     const double scale = ((double)KD * (double)KD) / ((double)sa * (double)sb);

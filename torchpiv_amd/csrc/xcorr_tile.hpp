@@ -1315,12 +1315,16 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
         }
         open = open || ns > EXACT_MAX_SECOND;
     }
-    // ---- minimum: the cells within the band of it (only the VALUE of the exact minimum is needed)
+    // ---- minimum: the cells within the band of it (only the VALUE of the exact minimum is needed).  More cells than the
+    //      record holds is NOT undecided by itself: frames with a true-zero background (background-subtracted recordings)
+    //      have hundreds of cells where no particle pair overlaps, all at S = 0 -- and S >= 0 for every cell, so an evaluated
+    //      cell with S = 0 IS the minimum.  The record then carries three cells and -2 in the fourth slot; the refinement
+    //      accepts it when their exact minimum is 0 and sends the window to the float64 transform otherwise.
     int n[EXACT_MAX_MIN] = {-1, -1, -1, -1};
     {
         const float thr = cmin + band;
         unsigned long long rows = wballot(rmin <= thr);
-        open = open || __popcll(rows) > EXACT_MAX_MIN;
+        bool over = __popcll(rows) > EXACT_MAX_MIN;
         int nn = 0;
         for (int it = 0; it < EXACT_MAX_MIN; ++it) {
             if (!any_left(rows)) break;
@@ -1330,10 +1334,11 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
             const int yr = row_of_lane(rl);
             unsigned long long cols = wballot(park(rl) <= thr);
             cols = on ? cols : 0ull;
-            for (int k = 0; k < WS; ++k) {
+            over = over || nn + __popcll(cols) > EXACT_MAX_MIN;
+            for (int k = 0; k < EXACT_MAX_MIN; ++k) {           // (the first cells of the row are as good as any)
                 if (!any_left(cols)) break;
-                const bool has = mine_left(cols);
-                const int q = yr * WS + (has ? (int)__builtin_ctzll(cols) : 0);
+                const bool has = mine_left(cols) && cols != 0ull && nn < EXACT_MAX_MIN;
+                const int q = yr * WS + (cols ? (int)__builtin_ctzll(cols) : 0);
                 cols &= cols - 1;
                 n[0] = (has && nn == 0) ? q : n[0];
                 n[1] = (has && nn == 1) ? q : n[1];
@@ -1342,7 +1347,7 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
                 nn += has ? 1 : 0;
             }
         }
-        open = open || nn > EXACT_MAX_MIN;
+        n[3] = over ? -2 : n[3];
     }
     if (r == 0 && active) {
         const int m_out = dead ? -2 : (open ? -1 : m);
