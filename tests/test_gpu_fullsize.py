@@ -78,14 +78,14 @@ FULLSIZE = __import__("os").environ.get("TPIV_FULLSIZE") == "1"
 
 def test_cfg3_full_size_against_oracle():
     """configs[3] LITERALLY: one 4096 x 4096 pair, 32/16 -> 16/8 -> 8/4, 3-pass CWS, 1 046 529 final vectors, against
-    the oracle by the same three gates at the default precision (float64 pass 1); TPIV_FULLSIZE=1 adds the all-float32
-    run (another pass over the same oracle fields)."""
+    the oracle by the same three gates at the default precision ("exact": exact sums in the 32x32 first pass);
+    TPIV_FULLSIZE=1 adds the float64-FFT and the all-float32 runs (further passes over the same oracle fields)."""
     from torchpiv_amd import engine, synth
     from test_gpu_parity import cascade_check
     a, b = synth.make_pair(4096, 4096, 987, kind="wavy", noise=2.0)
     geo = [(32, 16), (16, 8), (8, 4)]
     g = _oracle_fields(a.numpy(), b.numpy(), geo, "CWS", "cfg3full")
-    for precision in (("f64", "fast") if FULLSIZE else ("f64",)):
+    for precision in (("exact", "f64", "fast") if FULLSIZE else ("exact",)):
         counts = cascade_check(engine, g, "cfg3full", "CWS", precision, geo, max_differing=[8, 32, 128])     # observed: 0, 0, 0
         assert counts[-1][-1] == 1023 * 1023
 
