@@ -1,4 +1,4 @@
-"""Per-phase cycle shares of the float64 first-pass kernel for 64x64 windows (xcorr_f64.hip, second generation) from
+"""Per-phase cycle shares of the float64 first-pass kernel for 64x64 windows (xcorr_f64.hip) from
 the stamped diagnostic build (make -C torchpiv_amd/csrc stamps; TPIV_LIB=tools/diag/libtorchpiv_hip_stamps.so).
 Read the SHARES: the stamp fences forbid overlaps the real kernel has, and the counters are per wavefront (both
 wavefronts of a window add theirs)."""
@@ -22,5 +22,13 @@ s = stamps.cpu().numpy().astype(float)
 iters, tot = s[16], s[:8].sum()
 print(f"float64 pass 1 (64x64): {int(iters)} wave-iterations, {tot / iters:.0f} cycles per iteration; "
       f"shader clock {s[17] / s[18] * 100:.0f} MHz (s_memtime / s_memrealtime)")
-for n, v in zip(NAMES, s[:8]):
-    print(f"   {n:24s} {v / iters:9.0f} cyc  {100 * v / tot:5.1f} %")
+# (third generation: the inverse column transform is scheduled behind its stamp, into the phase of the T2 write -- the two
+#  are reported together)
+vals = list(s[:8])
+vals[5] += vals[4]
+names = list(NAMES)
+names[5] = "columns inverse + transposition 2"
+for k, (n, v) in enumerate(zip(names, vals)):
+    if k == 4:
+        continue
+    print(f"   {n:34s} {v / iters:9.0f} cyc  {100 * v / tot:5.1f} %")
