@@ -15,10 +15,22 @@ import torch
 
 from oracle import piv_oracle as O
 
-KAPPA = 1.0e-4          # band half-width relative to the map range (xcorr_tile.hpp: EXACT_BAND)
-MIN_CONTRAST = 0.028    # (S(m) - S_min) / (|a - mean a| |b - mean b|) below which the float64 transform decides (EXACT_MIN_CONTRAST)
+ETA = 6.66              # per radix-2 level of a float32 FFT: twiddle error + 4 roundings (piv_kernels.h: EXACT_ETA)
+U32 = 2.0 ** -24        # unit roundoff of float32
 MAX_SECOND = 3          # candidates carried per window (more -> float64 fallback)
 MAX_MIN = 4
+
+
+def band_coef(W):
+    """2 Gamma(W) (1 + 1/16): the proven bound on the float32 map's cell error, per unit of E+ (piv_kernels.h: exact_band_coef)."""
+    levels = 2 * int(np.ceil(np.log2(W)))
+    return 2.0 * (3 * levels * ETA + 6) * (1 + 1 / 16) * U32
+
+
+def e_plus(a, b):
+    """E+ = (|a'|^2 + |b'|^2) / 2 with a' = a / mean(a) - 1: the scale of the float32 transform's rounding error."""
+    af, bf = a.astype(np.float64), b.astype(np.float64)
+    return 0.5 * (((af / af.mean() - 1) ** 2).sum() + ((bf / bf.mean() - 1) ** 2).sum())
 
 
 def excluded(q, m, wv, W):
@@ -48,13 +60,13 @@ def exact_sum(a, b, q):
     return int((a.astype(np.int64) * np.roll(b.astype(np.int64), (-dy, -dx), axis=(0, 1))).sum())
 
 
-def candidates(cmap, wv):
+def candidates(cmap, wv, band):
     """-> (m, second candidates, minimum candidates) as flat indices, or None when a decision is open."""
     W = cmap.shape[0]
     flat = cmap.reshape(-1)
     lo, hi = float(flat.min()), float(flat.max())
-    band = np.float32(KAPPA) * np.float32(hi - lo)
-    if not band > 0:
+    band = np.float32(band)
+    if not band > 0 or not hi > lo:
         return None
     top = np.flatnonzero(flat >= np.float32(hi) - band)
     if top.size != 1:
@@ -82,7 +94,7 @@ def exact_window(a, b, wv=3, val_ratio=1.2):
     sa, sb = int(a.sum(dtype=np.int64)), int(b.sum(dtype=np.int64))
     if sa == 0 or sb == 0:
         return 0.0, 0.0, False                      # zero-mean window: NaN map in the reference -> (0, 0), valid
-    cand = candidates(f32_map(a, b), wv)
+    cand = candidates(f32_map(a, b), wv, band_coef(W) * e_plus(a, b))
     if cand is None:
         return None
     m, second, mins, min_overflow = cand
@@ -99,10 +111,6 @@ def exact_window(a, b, wv=3, val_ratio=1.2):
         return None
     if min_overflow and smin != 0:
         return None                                 # S >= 0 everywhere: only an evaluated 0 is certainly the minimum
-    ai, bi = a.astype(np.int64), b.astype(np.int64)
-    e2 = (float((ai * ai).sum()) - float(sa) ** 2 / KD) * (float((bi * bi).sum()) - float(sb) ** 2 / KD)
-    if not float(S[m] - smin) ** 2 >= MIN_CONTRAST ** 2 * e2:
-        return None                                 # the float32 transform's error is not small against this map's range
     scale = float(W) ** 4 / (float(sa) * float(sb))
     val = lambda q: (S[q] - smin) * scale + 1e-7
     cm, cl, cr, ct, cb = val(m), val(left), val(right), val(top), val(bot)

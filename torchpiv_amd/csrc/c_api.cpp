@@ -644,7 +644,7 @@ int tpiv_plan_create(tpiv_plan** out, int H, int W, int ws, int ov, int n_pass, 
         }
         pl->peak_raw_bytes = raw;
         if (raw) rc = pl->alloc(&pl->peak_raw, raw / sizeof(float) + 64);
-        if (rc == TPIV_OK && precision == TPIV_PREC_EXACT && (pl->geo[0].ws == 32 || pl->geo[0].ws == 64 || pl->geo[0].ws == 128))
+        if (rc == TPIV_OK && precision == TPIV_PREC_EXACT && tpiv::exact_refine_size(pl->geo[0].ws))
             rc = pl->alloc(&pl->exact_count, 4);
     }
     if (rc == TPIV_OK && n_pass > 1) {
@@ -688,7 +688,7 @@ const char* tpiv_plan_kernel_name(const tpiv_plan* plan, int pass, char* buf, in
 int tpiv_plan_exact_fallbacks(tpiv_plan* plan, long long* n_windows) {
     if (!plan || !n_windows) return fail(TPIV_EINVAL, "null argument");
     if (!plan->exact_count)
-        return fail(TPIV_EINVAL, "not a TPIV_PREC_EXACT plan with 32x32, 64x64 or 128x128 first-pass windows");
+        return fail(TPIV_EINVAL, "not a TPIV_PREC_EXACT plan with an even first-pass window size from 8 to 128");
     if (plan->last_batch <= 0) return fail(TPIV_EINVAL, "the plan has not run yet");
     HIP_TRY(hipDeviceSynchronize());
     unsigned n = 0;
@@ -1055,7 +1055,7 @@ int tpiv_plan_get_timing(tpiv_plan* plan, double* avg_ms, int n_slots, int* n_ru
 
 int tpiv_plan_exact_timing(const tpiv_plan* plan, double* ms4) {
     if (!plan || !ms4) return fail(TPIV_EINVAL, "null argument");
-    if (!plan->exact_count) return fail(TPIV_EINVAL, "not a TPIV_PREC_EXACT plan with 32x32, 64x64 or 128x128 first-pass windows");
+    if (!plan->exact_count) return fail(TPIV_EINVAL, "not a TPIV_PREC_EXACT plan with an even first-pass window size from 8 to 128");
     for (int s = 0; s < 4; ++s) ms4[s] = plan->exact_ms[s];
     return TPIV_OK;
 }

@@ -49,7 +49,8 @@ struct PassParams {
     uint4* cand;
     int* fb_list;
     unsigned* fb_count;
-    float exact_band;        // half-width of the decision band of the locating pass, relative to the map range (EXACT_BAND)
+    float exact_band;        // width of the decision band of the locating pass per unit of E+ (exact_band_coef(ws); "The band" below)
+    float exact_band_range;  // optional floor of the band relative to the map range (TPIV_EXACT_BAND_RANGE experiments; 0 by default)
     hipEvent_t* sub_events;  // host side only, optional: [3] recorded behind the locating pass, the refinement, the float64 list pass
     // n / d for n < 2^31 as (n * magic) >> shift (set by the tile launcher; keeps the per-item index
     // arithmetic in the scalar unit instead of a hoisted float reciprocal that occupies a VGPR)
@@ -57,16 +58,33 @@ struct PassParams {
     int groups_shift, ncols_shift;
 };
 
-// ---- precision "exact": constants shared by the locating pass (xcorr_tile.hpp, peak_candidates), the refinement
-// (xcorr_exact.hip) and the launcher
-// The band.  A decision of the locating pass is right whenever every cell of the float32 map is within band / 2 of the
-// exact one.  The float32 transform's cell error follows E = |a - mean a| |b - mean b| / (mean a mean b), not the map's
-// range R: tools/research/exact_band.py measures err <= 6.7e-7 E over particle images, noise, two-level and saturated
-// frames, sinusoids and nearly orthogonal patterns (R / E from 1.7 down to 8e-6).  With EXACT_BAND = 1e-4 of the range
-// the band covers twice that error for every window with R >= EXACT_MIN_CONTRAST x E = 0.028 E; the refinement computes
-// R and E exactly and sends the windows below that contrast (pure-noise windows sit at 0.1) to the float64 transform.
-constexpr float EXACT_BAND = 1.0e-4f;
-constexpr double EXACT_MIN_CONTRAST = 0.028;
+// ---- precision "exact": constants shared by the locating passes (xcorr_tile.hpp peak_candidates, xcorr_big.hpp,
+// xcorr_generic.hip), the refinement (xcorr_exact.hip) and the launcher
+// The band.  A decision of the locating pass is right whenever every cell of its float32 map is within band / 2 of the
+// exact one (up to a common offset and a common factor 1 + O(u), which change no order).  The float32 map's cell error is
+// BOUNDED -- DESIGN.md 3.4b derives it from the componentwise FFT error analysis (Higham, Accuracy and Stability of
+// Numerical Algorithms, Thm 24.2), u = 2^-24, t = 2 log2(W) butterfly levels per 2-D transform:
+//     |map32(d) - map(d)|  <=  Gamma(W) E+,     E+ = (|a'|^2 + |b'|^2) / 2 >= |a'| |b'|,   a' = a / mean(a) - 1,
+//     Gamma(W) = (3 t eta + 6) u,   eta = 6.66  (twiddle error + 4 roundings per radix-2 level; the radix-4 / radix-8
+//     codelets and the two-factor mixed-radix codelets of fft_mixed.hpp are below that per level pair)
+//   forward 2-D transform of a' + i b' (t eta u |Z|) and the rounding of its inputs (u |Z|), carried through the bilinear
+//   cross-spectrum by Cauchy-Schwarz: 2 (t eta + 1) u E+;  the cross-spectrum's own arithmetic: 4 u E+;  the inverse
+//   transform, componentwise |dy_d| <= t eta u sum_k |P_k| <= t eta u N |a'| |b'|: t eta u E+.
+// W = 64: 246 u = 1.47e-5 (measured over tools/research/exact_band.py's families and its adversarial search: <= 7e-7).
+// The locating pass forms E+ from the exact integer window sums (sum a, sum a^2: v_sad_u8 / v_dot4_u32_u8 on the bytes it
+// staged) and uses band = 2 Gamma(W) (1 + 1/16) E+ -- the 1/16 covers the float32 rounding of E+ itself and of the band
+// comparisons.  The plain O(n^2) DFTs of the first-generation generic kernel accumulate n terms per output:
+// eta_line = n + 3 per 1-D transform instead of log2(n) eta.
+constexpr double EXACT_ETA = 6.66;
+inline double exact_gamma_u(int ws, bool plain_dft) {       // Gamma(W) in units of u = 2^-24
+    double lg = 0.0;
+    for (int n = 1; n < ws; n *= 2) lg += 1.0;               // ceil(log2 ws): the two-factor codelets stay below it
+    const double t_eta = plain_dft ? 2.0 * (ws + 3) : 2.0 * lg * EXACT_ETA;
+    return 3.0 * t_eta + 6.0;
+}
+inline float exact_band_coef(int ws, bool plain_dft = false) {
+    return (float)(2.0 * exact_gamma_u(ws, plain_dft) * (1.0 + 1.0 / 16) * 5.9604644775390625e-08);
+}
 constexpr int EXACT_MAX_SECOND = 3, EXACT_MAX_MIN = 4;
 
 struct PredictParams {
@@ -189,6 +207,8 @@ __device__ __forceinline__ void pred_fallback(const PassParams& p, size_t i, dou
 const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int len);
 // bytes of PassParams::peak_raw a pass needs (records, work-queue counters, generic-size DFT scratch)
 size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool force_generic = false);
+// precision "exact": window sizes whose first pass runs the exact scheme (every even size from 8 to 128; xcorr_exact.hip)
+bool exact_refine_size(int ws);
 // precision "exact": byte offset of the float64-list counter (one unsigned) inside PassParams::peak_raw
 size_t exact_fallback_count_offset(int batch, int n_windows);
 // test hook: peak stage + finalize on caller-made maps; planar selects the LDS layout variant of the tile kernel

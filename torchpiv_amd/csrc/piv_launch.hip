@@ -26,11 +26,14 @@ int generic_blocks(int ws, long long items, int n_cu, int elem_bytes);
 bool generic_ct_usable(int ws);
 int generic_ct_register_size(int ws, int mode);
 hipError_t launch_xcorr_f64(const PassParams& p, int n_cu, hipStream_t stream);      // xcorr_f64.hip: 8..64, pass 1
-// precision "exact" (64x64 pass 1): float32 candidate pass, exact integer refinement, float64 pass for the undecided windows
-hipError_t launch_xcorr_cand_ws32(const PassParams& p, int n_cu, hipStream_t stream);       // xcorr_tile.hpp
+// precision "exact" (pass 1): float32 candidate pass, exact integer refinement, float64 pass for the undecided windows
+hipError_t launch_xcorr_cand_ws8(const PassParams& p, int n_cu, hipStream_t stream);        // xcorr_tile.hpp
+hipError_t launch_xcorr_cand_ws16(const PassParams& p, int n_cu, hipStream_t stream);
+hipError_t launch_xcorr_cand_ws32(const PassParams& p, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_cand_ws64(const PassParams& p, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_cand_ws128(const PassParams& p, int n_cu, hipStream_t stream);      // xcorr_big.hpp
 hipError_t launch_exact_refine(const PassParams& p, hipStream_t stream);                    // xcorr_exact.hip
+bool exact_refine_size(int ws);                                                             // every even size 8 ... 128
 hipError_t launch_xcorr_f64_list(const PassParams& p, int n_cu, hipStream_t stream);        // xcorr_f64.hip
 
 // ---- finalize: sub-pixel fit, validation and multipass combine, one thread per window -----------
@@ -177,25 +180,30 @@ static constexpr size_t WORK_CTR_BYTES = 8 * 16 * sizeof(unsigned);
 static size_t work_ctr_offset(int batch, int n_windows) { return (peak_bytes(batch, n_windows) + 127) / 128 * 128; }
 
 // precision "exact": float64 records | candidate cells (16 B per window) | float64 list | its counter | tile work counters
+// | generic sizes: the DFT scratch tiles of the first-generation kernel (float32 locating pass and float64 list pass)
 struct ExactLayout {
-    size_t cand, list, count, ctr, total;
+    size_t cand, list, count, ctr, scratch, total;
 };
-static ExactLayout exact_layout(int batch, int n_windows) {
+static ExactLayout exact_layout(int ws, int batch, int n_windows) {
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
     ExactLayout l;
     l.cand = peak_bytes(batch, n_windows, 1);
     l.list = l.cand + up((size_t)batch * n_windows * sizeof(uint4));
     l.count = l.list + up((size_t)batch * n_windows * sizeof(int));
     l.ctr = l.count + 256;
-    l.total = l.ctr + WORK_CTR_BYTES;
+    l.scratch = l.ctr + WORK_CTR_BYTES;
+    l.total = l.scratch;
+    if (!tile_size(ws) && ws != 128)
+        l.total += (size_t)generic_blocks(ws, (long long)batch * n_windows, 256, 8) * 2 * ws * ws * 2 * 8;
     return l;
 }
-static bool exact_size(int ws) { return ws == 32 || ws == 64 || ws == 128; }
-size_t exact_fallback_count_offset(int batch, int n_windows) { return exact_layout(batch, n_windows).count; }
+// window sizes whose first pass runs the exact scheme: every even size from 8 to 128 (xcorr_exact.hip: exact_refine_size)
+static bool exact_size(int ws) { return exact_refine_size(ws); }
+size_t exact_fallback_count_offset(int batch, int n_windows) { return exact_layout(64, batch, n_windows).count; }
 
 size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool force_generic) {
     if (precision == 3) {
-        if (exact_size(ws) && !force_generic) return exact_layout(batch, n_windows).total;
+        if (exact_size(ws) && !force_generic) return exact_layout(ws, batch, n_windows).total;
         precision = 1;                                                              // other sizes: the float64 kernels
     }
     if (tile_size(ws) && !force_generic) {
@@ -222,7 +230,9 @@ const char* xcorr_kernel_name(int ws, int mode, int precision, char* buf, int le
     precision = pass_precision(precision, mode, ws);
     if (precision == 3 && mode == MODE_PASS1) {
         if (ws == 128) snprintf(buf, len, "xcorr_big128_cand_kernel");
-        else snprintf(buf, len, "xcorr_tile_cand_kernel<%d>", ws);
+        else if (tile_size(ws)) snprintf(buf, len, "xcorr_tile_cand_kernel<%d>", ws);
+        else if (generic_ct_usable(ws)) snprintf(buf, len, "xcorr_generic_ct_kernel<0, %d> (cand)", generic_ct_register_size(ws, mode));
+        else snprintf(buf, len, "xcorr_generic_kernel<0, float> (cand)");
     } else if (precision && mode == MODE_PASS1) {
         if (ws == 64 || ws == 128) snprintf(buf, len, "xcorr_f64_split_kernel<%d>", ws);
         else if (tile_size(ws)) snprintf(buf, len, "xcorr_f64_tile_kernel<%d>", ws);
@@ -259,31 +269,54 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
     if (mode == MODE_CWSF) {
         e = generic();
     } else if (p.precision == 3) {
-        const ExactLayout l = exact_layout(p.batch, p.n_rows * p.n_cols);
+        const ExactLayout l = exact_layout(p.ws, p.batch, p.n_rows * p.n_cols);
         char* const base = reinterpret_cast<char*>(p.peak_raw);
         p.cand = reinterpret_cast<uint4*>(base + l.cand);
         p.fb_list = reinterpret_cast<int*>(base + l.list);
         p.fb_count = reinterpret_cast<unsigned*>(base + l.count);
         p.work_ctr = reinterpret_cast<unsigned*>(base + l.ctr);
-        // (TPIV_EXACT_BAND: experiments with the width of the locating pass's decision band, tools/research/exact_band.py)
-        static const float band = [] {
-            const char* env = getenv("TPIV_EXACT_BAND");
-            return env ? (float)atof(env) : EXACT_BAND;
+        // the decision band of the locating pass: 2 Gamma(ws) (1 + 1/16) E+ (piv_kernels.h, "The band"); the sizes that run
+        // the first-generation generic kernel transform by plain O(n^2) DFTs, whose bound grows with n
+        // (TPIV_EXACT_BAND_SCALE / TPIV_EXACT_BAND_RANGE: experiments with the band, tools/research/exact_band.py)
+        static const float band_scale = [] {
+            const char* env = getenv("TPIV_EXACT_BAND_SCALE");
+            return env ? (float)atof(env) : 1.0f;
         }();
-        p.exact_band = band;
+        static const float band_range = [] {
+            const char* env = getenv("TPIV_EXACT_BAND_RANGE");
+            return env ? (float)atof(env) : 0.0f;
+        }();
+        const bool plain_dft = !tile_size(p.ws) && p.ws != 128 && !generic_ct_usable(p.ws);
+        p.exact_band = band_scale * exact_band_coef(p.ws, plain_dft);
+        p.exact_band_range = band_range;
         e = hipMemsetAsync(p.fb_count, 0, 256 + WORK_CTR_BYTES, stream);
         if (e != hipSuccess) return e;
         auto mark = [&](int i) {
             if (p.sub_events) (void)hipEventRecord(p.sub_events[i], stream);
         };
-        e = p.ws == 32 ? launch_xcorr_cand_ws32(p, n_cu, stream)
-                       : (p.ws == 64 ? launch_xcorr_cand_ws64(p, n_cu, stream) : launch_xcorr_cand_ws128(p, n_cu, stream));
+        PassParams q = p;                    // generic sizes: the float32 kernels with `cand` set, the float64 one with the list
+        q.precision = 0;
+        void* const gscratch = base + l.scratch;
+        switch (p.ws) {
+            case 8: e = launch_xcorr_cand_ws8(p, n_cu, stream); break;
+            case 16: e = launch_xcorr_cand_ws16(p, n_cu, stream); break;
+            case 32: e = launch_xcorr_cand_ws32(p, n_cu, stream); break;
+            case 64: e = launch_xcorr_cand_ws64(p, n_cu, stream); break;
+            case 128: e = launch_xcorr_cand_ws128(p, n_cu, stream); break;
+            default: e = launch_xcorr_generic(q, MODE_PASS1, 256, gscratch, stream); break;
+        }
         if (e != hipSuccess) return e;
         mark(0);
         e = launch_exact_refine(p, stream);
         if (e != hipSuccess) return e;
         mark(1);
-        e = launch_xcorr_f64_list(p, n_cu, stream);
+        if (tile_size(p.ws) || p.ws == 128) {
+            e = launch_xcorr_f64_list(p, n_cu, stream);
+        } else {
+            q.precision = 1;
+            q.cand = nullptr;
+            e = launch_xcorr_generic(q, MODE_PASS1, 256, gscratch, stream);
+        }
         mark(2);
     } else if (f64) {
         // (TPIV_F64_GENERIC128=1: the generic-size DFT kernel for 128x128, as before the split kernel existed -- A/B runs)

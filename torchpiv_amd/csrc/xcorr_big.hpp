@@ -38,7 +38,7 @@ struct BigShared {
     float plane[BW * BP];
     float redf[8];                  // (min, raw max) of the map
     int redi[8];                    // row of the maximum / second peak
-    unsigned long long redu[4];     // window sums
+    unsigned long long redu[8];     // window sums; CAND: [4..7] the sums of squares
     // candidate-cell variant (precision "exact", xcorr_exact.hip): cells inside the band of the maximum (count only),
     // of the second peak and of the minimum
     int redc[4];
@@ -67,9 +67,10 @@ __device__ __forceinline__ T block_reduce(T v, OP op, T* slots, int wave, int la
 // thread-local minimum (the kernel issues the next window's row loads there).
 // CAND: instead of the record, the flat indices of the cells the exact refinement evaluates (see peak_candidates in
 // xcorr_tile.hpp for the rules; here the whole map sits in LDS and every thread looks through its own 64 cells)
+// band_abs (CAND): the proven part of the decision band, 2 Gamma(128) (1 + 1/16) E+ (piv_kernels.h, "The band")
 template <bool CAND = false, typename PREFETCH>
 __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[BH], BigShared& sm, int t, size_t fidx,
-                                               bool dead, PREFETCH&& prefetch) {
+                                               bool dead, PREFETCH&& prefetch, float band_abs = 0.f) {
     float* const plane = sm.plane;
     const int lane = t & 63, wave = t >> 6, par = t >> 7;
     {
@@ -171,8 +172,8 @@ __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[B
         smax = block_reduce(smax, imax_, sm.redi + 4, wave, lane);
         if constexpr (CAND) {
             // (all values are the shifted cells v = (c - min) + 1e-7 > 0: differences are those of the raw map)
-            const float band = p.exact_band * __fsub_rn(graw, cmin);
-            bool open = !(band > 0.0f);
+            const float band = fmaxf(p.exact_band_range * __fsub_rn(graw, cmin), band_abs);
+            bool open = !(band > 0.0f) || !(graw > cmin);
             // The few threads whose row extremum sits inside a band walk their 64 cells over the map in LDS
             // (plane[ys][xe + par], the shifted cells just parked there) in two steps: a branch-free pass that only sets one bit
             // per matching cell (sixteen reads in flight), then the bits -- one to three -- are visited.  (Two earlier forms: unrolled
@@ -326,14 +327,19 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
         // ---------------- stage 0: samples 2j + par of row `line`
         cf x[BH];
         float sa, sb;
+        unsigned sqa = 0u, sqb = 0u;
         {
             const uint32_t mask = par ? 0xff00ff00u : 0x00ff00ffu;
             const int sh = 8 * par;
-            unsigned ia = 0, ib = 0;
+            unsigned ia = 0, ib = 0, iaa = 0, ibb = 0;
 #pragma unroll
             for (int q = 0; q < 32; ++q) {
                 ia = __builtin_amdgcn_sad_u8(da[q] & mask, 0u, ia);
                 ib = __builtin_amdgcn_sad_u8(db[q] & mask, 0u, ib);
+                if constexpr (CAND) {     // sums of squares of this thread's bytes: E+, the scale of the decision band
+                    iaa = __builtin_amdgcn_udot4(da[q] & mask, da[q] & mask, iaa, false);
+                    ibb = __builtin_amdgcn_udot4(db[q] & mask, db[q] & mask, ibb, false);
+                }
                 da[q] >>= sh;
                 db[q] >>= sh;
             }
@@ -344,10 +350,19 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             });
             // window sums: exact integers (< 2^24), both in one reduction with one barrier
             auto uadd = [](unsigned long long a, unsigned long long b) TPIV_LAMBDA_INLINE { return a + b; };
+            if constexpr (CAND) {     // (window totals < 2^31: the packed halves do not carry into each other; same barrier)
+                const unsigned long long q2 = grp_reduce<64>((unsigned long long)iaa | ((unsigned long long)ibb << 32), uadd);
+                if (lane == 0) sm.redu[4 + wave] = q2;
+            }
             const unsigned long long s2_ =
                 block_reduce((unsigned long long)ia | ((unsigned long long)ib << 32), uadd, sm.redu, wave, lane);
             sa = (float)(unsigned)s2_;
             sb = (float)(unsigned)(s2_ >> 32);
+            if constexpr (CAND) {
+                const unsigned long long q2 = (sm.redu[4] + sm.redu[5]) + (sm.redu[6] + sm.redu[7]);
+                sqa = (unsigned)q2;
+                sqb = (unsigned)(q2 >> 32);
+            }
         }
         if (p.dbg_win != nullptr) {       // test hook: the staged window
             float* d = p.dbg_win + fidx * 2 * BW * BW + line * BW + par;
@@ -358,12 +373,20 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             }
         }
         const bool dead = (sa == 0.f) || (sb == 0.f);   // zero-mean window: 0/0 = NaN map in the reference
+        int band_s = 0;                                 // CAND: the decision band (float bits, scalar)
         {
             constexpr float PRE = 0.5f / (float)BW;     // 1/n^2 and the 1/4 of the cross-spectrum, exact
             const float ma = sa * (1.0f / (BW * BW)), mb = sb * (1.0f / (BW * BW));
             const float ka = dead ? 0.f : 1.0f / ma, kb = dead ? 0.f : 1.0f / mb;
             const float oa = -ma * ka, ob = -mb * kb;
             const float kas = ka * PRE, kbs = kb * PRE, oas = oa * PRE, obs = ob * PRE;
+            if constexpr (CAND) {     // E+ = (|a'|^2 + |b'|^2) / 2, |a'|^2 = (n sum a^2 - (sum a)^2) ka^2 / n  (see xcorr_tile.hpp)
+                constexpr double NN = (double)(BW * BW);
+                const double da_ = (double)sa, db_ = (double)sb;
+                const float ea = (float)__fma_rn(-da_, da_, NN * (double)sqa), eb = (float)__fma_rn(-db_, db_, NN * (double)sqb);
+                const float e_plus = (0.5f / (float)(BW * BW)) * (ea * (ka * ka) + eb * (kb * kb));
+                band_s = __builtin_amdgcn_readfirstlane(__float_as_int(dead ? 0.f : p.exact_band * e_plus));
+            }
 #pragma unroll
             for (int j = 0; j < BH; ++j) {
                 x[j].x = fmaf(x[j].x, kas, oas);
@@ -581,7 +604,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             // prefetch: the last iteration re-loads its own window (no branch around the loads)
             big_peak_stage<CAND>(p, c, sm, t, fidx, dead, [&]() TPIV_LAMBDA_INLINE {
                 issue_loads(item + per_xcd < hi ? item + per_xcd : item);
-            });
+            }, __int_as_float(band_s));
         }
     }
 }

@@ -1,20 +1,24 @@
-// Exact first pass for 32x32, 64x64 and 128x128 windows (precision "exact"): the values behind the sub-pixel fit and the validity ratio
-// as EXACT integer correlation sums of the uint8 windows.
+// Exact first pass for every even window size 8 ... 128 (precision "exact"): the values behind the sub-pixel fit and the
+// validity ratio as EXACT integer correlation sums of the uint8 windows.
 //
 // The reference (PIVbackend.py:513-518) divides both windows by their means in float64, correlates them through a
 // float64 FFT, subtracts the map minimum and adds 1e-7; every cell of that map is
 //     (S(d) - S_min) n^4 / (sum a  sum b) + 1e-7,      S(d) = sum_p a[p] b[(p + d) mod W]   (integers < 2^30)
 // up to the rounding of the transform.  Only a handful of cells per window ever reach the result (B:383-411): the
 // arg-max, its four flat-index neighbours, the second peak, and the minimum.  So:
-//   1. xcorr_tile_cand_kernel<32 | 64> (xcorr_tile.hpp, peak_candidates) / xcorr_big128_cand_kernel (xcorr_big.hpp): the
-//      float32 FFT pass LOCATES those cells, with an error band around every decision;
-//   2. xcorr_exact_refine_kernel<W> (here): the lanes of a window (32: half a wavefront, 64: one, 128: two) evaluate S
-//      at the located cells -- lane = window row,
+//   1. xcorr_tile_cand_kernel<8 | 16 | 32 | 64> (xcorr_tile.hpp, peak_candidates) / xcorr_big128_cand_kernel (xcorr_big.hpp) /
+//      the CAND forms of the generic-size kernels (xcorr_generic.hip, map_candidates): the float32 FFT pass LOCATES those
+//      cells, with a PROVEN error band around every decision (piv_kernels.h, "The band");
+//   2. xcorr_exact_refine_kernel<W> (here; W = 16, 32, 64, 128): the lanes of a window (16: a quarter of a wavefront, 32: half,
+//      64: one, 128: two) evaluate S at the located cells -- lane = window row,
 //      frame-a row in registers, frame b's rows parked twice over in LDS so that a row rotated by dx is one contiguous
 //      span; W / 4 v_dot4_u32_u8 per lane and cell --, re-checks the decisions on the exact values (no neighbour or second
 //      candidate above the arg-max, no evaluated cell below the minimum) and writes the 8-double record of
-//      finalize_kernel<true>.  Undecided windows are appended to a list;
-//   3. xcorr_f64_list_kernel<W> (xcorr_f64.hip) runs the float64 transform for the listed windows only.
+//      finalize_kernel<true>.  Undecided windows are appended to a list.
+//      xcorr_exact_refine_any_kernel<G> (here): the same for any even W <= 128 (8, the generic sizes 12 ... 126) with lane =
+//      CELL: both windows in LDS, the lane of a cell walks all rows of its rotation;
+//   3. xcorr_f64_list_kernel<W> / xcorr_f64_tile_list_kernel<W> (xcorr_f64.hip) / the float64 generic kernel run the float64
+//      transform for the listed windows only.
 // tests/test_exact_scheme.py is the numpy statement of the scheme (checked against the oracle: 7e-15 px);
 // tests/test_gpu_exact.py compares this file with it and with the float64 kernel.
 #include <hip/hip_runtime.h>
@@ -65,6 +69,45 @@ __device__ __forceinline__ void read_span(const uint32_t* src, uint32_t (&w)[N])
     static_for<0, N>([&](auto ic) TPIV_LAMBDA_INLINE { w[decltype(ic)::value] = lds_rd32<4 * decltype(ic)::value>(addr); });
     lds_landed();
     static_for<0, N>([&](auto ic) TPIV_LAMBDA_INLINE { lds_tie(w[decltype(ic)::value]); });
+}
+
+// ---- the decisions, re-checked on the exact values, and the record.  Called by the 16 first lanes of a window (all of
+// them: the reductions are row-wide DPP steps): lane r0 < XCELLS holds S of cell r0 (`have`: the cell exists), every lane
+// the window sums.  (No contrast guard any more: round 4 sent low-contrast windows to the float64 transform because its band
+// was a measured constant times the map range; the band of the locating passes is now the proven bound on their float32
+// error, piv_kernels.h "The band", whatever the contrast.)
+__device__ __forceinline__ void decide_and_store(const PassParams& p, const uint4& rec, int r0, bool go, bool writer, bool have,
+                                                 int m, unsigned S, unsigned sa, unsigned sb, double kd, double* out, long long it) {
+    auto hi16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v >> 16); };
+    auto umin = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x < y ? x : y; };
+    auto umax = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x > y ? x : y; };
+    auto uadd = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x + y; };
+    constexpr int S0 = 5, N0 = 5 + EXACT_MAX_SECOND;         // first second-peak / minimum slot
+    S = r0 < XCELLS ? S : 0u;
+    // (the cells sit in lanes 0..11 of the window and the results are used by lanes 0..7: reductions over its first 16 lanes)
+    const unsigned s_min = grp_reduce<16>((have && r0 >= N0 && r0 < XCELLS) ? S : 0xffffffffu, umin);
+    const unsigned s_low = grp_reduce<16>((have && r0 < XCELLS) ? S : 0xffffffffu, umin);
+    const unsigned s_top = grp_reduce<16>((have && r0 < N0) ? S : 0u, umax);
+    const unsigned s_m = grp_reduce<16>(r0 == 0 ? S : 0u, umax);
+    const unsigned s_second = grp_reduce<16>((have && r0 >= S0 && r0 < N0) ? S : 0u, umax);
+    const unsigned n_second = grp_reduce<16>((have && r0 >= S0 && r0 < N0) ? 1u : 0u, uadd);
+    // (the first two cannot happen while the float32 map stays inside the band; sa, sb: the locating pass marks those)
+    // more minimum candidates than the record holds (-2 in its last slot): S >= 0 everywhere, so the evaluated ones settle
+    // it exactly when one of them is 0 (true-zero backgrounds); anything else goes to the float64 transform
+    const bool min_overflow = hi16(rec.w) == -2;
+    const bool redo = s_top > s_m || s_low < s_min || s_min == 0xffffffffu || sa == 0u || sb == 0u ||
+                      (min_overflow && s_min != 0u);
+    if (go && redo && r0 == 0 && writer) p.fb_list[atomicAdd(p.fb_count, 1u)] = (int)it;
+    // (S - S_min) n^4 / (sum a sum b) + 1e-7: the integer difference is exact, sum a * sum b < 2^44 is exact
+    const double scale = (kd * kd) / ((double)sa * (double)sb);
+    const unsigned mine = r0 == 5 ? s_second : S;
+    double v = __fma_rn((double)(mine - s_min), scale, 1e-7);
+    // B:410-411 with every cell inside the exclusion zone (2 val_win + 1 >= W): the reference zeroes its float64 map in
+    // place and divides by the 0 it then finds -- ratio inf, valid; the float64 kernels store 0 there too
+    v = (r0 == 5 && n_second == 0u) ? 0.0 : v;
+    v = r0 == 6 ? (double)m : v;
+    v = r0 == 7 ? 0.0 : v;
+    if (go && !redo && r0 < 8 && writer) out[r0] = v;
 }
 
 // Everything below is per-lane data with predicated control flow: for 32x32 the two windows of a wavefront take their
@@ -139,7 +182,7 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
         q = r0 == 11 ? hi16(rec.w) : q;
     }
 
-    // per-lane partial sums P[0..11]: S at the requested cells, P[12..15]: window sums and sums of squares (< 2^22 / 2^30 per window)
+    // per-lane partial sums P[0..11]: S at the requested cells, P[12..13]: window sums (< 2^22 per window)
     unsigned P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) P[k] = 0u;
@@ -147,8 +190,6 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     for (int i = 0; i < NDW; ++i) {
         P[12] = __builtin_amdgcn_sad_u8(a[i], 0u, P[12]);
         P[13] = __builtin_amdgcn_sad_u8(b[i], 0u, P[13]);
-        P[14] = __builtin_amdgcn_udot4(a[i], a[i], P[14], false);
-        P[15] = __builtin_amdgcn_udot4(b[i], b[i], P[15], false);
         rows_b[row * XP + i] = b[i];
         rows_b[row * XP + NDW + i] = b[i];
     }
@@ -160,11 +201,12 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
         constexpr int c = decltype(cc)::value;
         int qc = __builtin_amdgcn_readlane(q, c);
         bool any = qc >= 0;
-        if constexpr (G::WPW == 2) {
-            const int q1 = __builtin_amdgcn_readlane(q, 32 + c);
-            any = any || q1 >= 0;
-            qc = g ? q1 : qc;
-        }
+        static_for<1, G::WPW>([&](auto wc) TPIV_LAMBDA_INLINE {          // (the other windows of the wavefront)
+            constexpr int k = decltype(wc)::value;
+            const int qk = __builtin_amdgcn_readlane(q, k * G::GROUP + c);
+            any = any || qk >= 0;
+            qc = g == k ? qk : qc;
+        });
         if (any) {                                      // (wave-uniform)
             const bool on = qc >= 0;
             const int qq = on ? qc : 0;
@@ -221,7 +263,7 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
         T[3] = S;                                       // (lanes 12..15; the quad broadcasts below read exactly those)
     }
     // the window sums to every lane of their quad (lanes 12..15 hold them; every lane r0 < 16 needs them: same row)
-    unsigned sa, sb, saa, sbb;
+    unsigned sa, sb;
     {
         // row_bcast within the row of 16 lanes: lane 12 / 13 / 14 / 15 of the row through a row rotation + quad broadcast
         const unsigned t3 = (r0 & 12) == 12 ? T[3] : 0u;                  // only the last quad of the first row carries sums
@@ -230,46 +272,161 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
         rowsum += (unsigned)dpp_i<0x124>((int)rowsum);                    // row_ror:4  -> every quad of the row holds the four sums
         sa = (unsigned)dpp_i<0x00>((int)rowsum);                          // quad_perm [0,0,0,0]
         sb = (unsigned)dpp_i<0x55>((int)rowsum);                          // quad_perm [1,1,1,1]
-        saa = (unsigned)dpp_i<0xAA>((int)rowsum);                         // quad_perm [2,2,2,2]
-        sbb = (unsigned)dpp_i<0xFF>((int)rowsum);                         // quad_perm [3,3,3,3]
     }
     S = r0 < XCELLS ? S : 0u;
 
-    // ---- the decisions, re-checked on the exact values
-    const bool have = q >= 0;
-    auto umin = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x < y ? x : y; };
-    auto umax = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x > y ? x : y; };
-    constexpr int S0 = 5, N0 = 5 + EXACT_MAX_SECOND;         // first second-peak / minimum slot
-    // (the cells sit in lanes 0..11 of the window and the results are used by lanes 0..7: reductions over its first 16 lanes)
-    auto uadd = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x + y; };
-    const unsigned s_min = grp_reduce<16>((have && r0 >= N0 && r0 < XCELLS) ? S : 0xffffffffu, umin);
-    const unsigned s_low = grp_reduce<16>((have && r0 < XCELLS) ? S : 0xffffffffu, umin);
-    const unsigned s_top = grp_reduce<16>((have && r0 < N0) ? S : 0u, umax);
-    const unsigned s_m = grp_reduce<16>(r0 == 0 ? S : 0u, umax);
-    const unsigned s_second = grp_reduce<16>((have && r0 >= S0 && r0 < N0) ? S : 0u, umax);
-    const unsigned n_second = grp_reduce<16>((have && r0 >= S0 && r0 < N0) ? 1u : 0u, uadd);
-    // contrast of the map against the scale the float32 transform's error follows (piv_kernels.h, "The band"):
-    // R = S(m) - S_min, E^2 = (sum a^2 - (sum a)^2 / n) (sum b^2 - (sum b)^2 / n), all from exact integers
-    const double ea2 = (double)saa - (double)sa * (double)sa * (1.0 / KD), eb2 = (double)sbb - (double)sb * (double)sb * (1.0 / KD);
-    const double range = (double)(s_m - s_min);
-    const bool low_contrast = !(range * range >= (EXACT_MIN_CONTRAST * EXACT_MIN_CONTRAST) * ea2 * eb2);
-    // (the first two cannot happen while the float32 map stays inside the band; sa, sb: the locating pass marks those)
-    // more minimum candidates than the record holds (-2 in its last slot): S >= 0 everywhere, so the evaluated ones settle
-    // it exactly when one of them is 0 (true-zero backgrounds); anything else goes to the float64 transform
-    const bool min_overflow = hi16(rec.w) == -2;
-    const bool redo = s_top > s_m || s_low < s_min || s_min == 0xffffffffu || sa == 0u || sb == 0u || low_contrast ||
-                      (min_overflow && s_min != 0u);
-    if (go && redo) to_f64_kernel();
-    // (S - S_min) n^4 / (sum a sum b) + 1e-7: the integer difference is exact, sum a * sum b < 2^44 is exact
-    const double scale = ((double)KD * (double)KD) / ((double)sa * (double)sb);
-    const unsigned mine = r0 == 5 ? s_second : S;
-    double v = __fma_rn((double)(mine - s_min), scale, 1e-7);
-    // B:410-411 with every cell inside the exclusion zone (2 val_win + 1 >= W): the reference zeroes its float64 map in
-    // place and divides by the 0 it then finds -- ratio inf, valid; the float64 kernels store 0 there too
-    v = (r0 == 5 && n_second == 0u) ? 0.0 : v;
-    v = r0 == 6 ? (double)m : v;
-    v = r0 == 7 ? 0.0 : v;
-    if (go && !redo && r0 < 8 && writer) out[r0] = v;
+    decide_and_store(p, rec, r0, go, writer, q >= 0, m, S, sa, sb, (double)KD, out, it);
+}
+
+// ---- any even window size up to 128: lane = CELL.  Both windows sit in LDS (frame a's rows as zero-padded dwords,
+// frame b's rows twice over at byte granularity, so that a row rotated by dx is one contiguous byte span for any W); the
+// lane of cell j walks the rows of its rotation: per dword of a row one broadcast read of a, one read of b, v_alignbyte,
+// v_dot4_u32_u8.  G = 4: four windows per wavefront, 16 lanes each (W <= 32: 8x8 first passes, the small generic sizes);
+// G = 1: the 64 lanes are 4 row slices x 16 cells of one window, joined by two permlane swaps.  One wavefront per workgroup:
+// LDS exchanges need no barrier.
+template <int G>
+__global__ __launch_bounds__(64) void xcorr_exact_refine_any_kernel(PassParams p, int ndw, int xp) {
+    extern __shared__ uint32_t any_smem[];
+    constexpr int LPW = 64 / G, SL = LPW / 16;               // lanes per window, row slices per cell
+    const int W = p.ws, KD = W * W;
+    const int lane = (int)threadIdx.x;
+    const int g = lane / LPW, c = lane & 15, k = (lane % LPW) >> 4;
+    const int N = p.n_rows * p.n_cols;
+    const long long total = (long long)p.batch * N;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long long chunk = (total + 7) / 8;
+    const int st = p.ws - p.ov;
+    const bool dwords = (W & 3) == 0;
+    const float rcp_ndw = 1.0f / (float)ndw;
+
+    // ---- staging, window after window, all 64 lanes (the loads of the G windows are independent of each other)
+    unsigned sa_w[G], sb_w[G];
+    long long it_w[G];
+    bool valid_w[G];
+    static_for<0, G>([&](auto gc) TPIV_LAMBDA_INLINE {
+        constexpr int gi = decltype(gc)::value;
+        const long long in_chunk = (long long)slot * G + gi;
+        const long long it_raw = (long long)xcd * chunk + in_chunk;
+        valid_w[gi] = in_chunk < chunk && it_raw < total;
+        it_w[gi] = valid_w[gi] ? it_raw : 0;
+        const unsigned itu = (unsigned)it_w[gi];
+        const int pair = (int)(itu / (unsigned)N), win = (int)(itu - (unsigned)pair * (unsigned)N);
+        const size_t off = (size_t)pair * p.H * p.W + (size_t)((win / p.n_cols) * st) * p.W + (size_t)(win % p.n_cols) * st;
+        const uint8_t* __restrict__ A0 = p.A + off;
+        const uint8_t* __restrict__ B0 = p.B + off;
+        uint32_t* const ag = any_smem + gi * W * ndw;
+        uint32_t* const bg = any_smem + G * W * ndw + gi * W * xp;
+        uint8_t* const bgb = reinterpret_cast<uint8_t*>(bg);
+        unsigned pa = 0u, pb = 0u;
+        for (int idx = lane; idx < W * ndw; idx += 64) {
+            const int row = (int)(((float)idx + 0.5f) * rcp_ndw), i = idx - row * ndw;
+            const uint8_t* ra = A0 + (size_t)row * p.W + 4 * i;
+            const uint8_t* rb = B0 + (size_t)row * p.W + 4 * i;
+            uint32_t da = 0u, db = 0u;
+            const int nb = W - 4 * i < 4 ? W - 4 * i : 4;   // bytes of this dword inside the window row
+            if (nb == 4) {
+                __builtin_memcpy(&da, ra, 4);
+                __builtin_memcpy(&db, rb, 4);
+            } else {                                        // (the tail of a row whose length is not a multiple of four)
+                for (int t = 0; t < nb; ++t) {
+                    da |= (uint32_t)ra[t] << (8 * t);
+                    db |= (uint32_t)rb[t] << (8 * t);
+                }
+            }
+            ag[row * ndw + i] = da;
+            pa = __builtin_amdgcn_sad_u8(da, 0u, pa);
+            pb = __builtin_amdgcn_sad_u8(db, 0u, pb);
+            if (dwords) {
+                bg[row * xp + i] = db;
+                bg[row * xp + ndw + i] = db;
+            } else {
+                for (int t = 0; t < nb; ++t) {
+                    const uint8_t v = (uint8_t)(db >> (8 * t));
+                    bgb[row * xp * 4 + 4 * i + t] = v;
+                    bgb[row * xp * 4 + W + 4 * i + t] = v;
+                }
+            }
+        }
+        auto uadd = [](unsigned x, unsigned y) TPIV_LAMBDA_INLINE { return x + y; };
+        sa_w[gi] = grp_reduce<64>(pa, uadd);
+        sb_w[gi] = grp_reduce<64>(pb, uadd);
+    });
+    wave_sync();
+
+    // ---- this lane's window
+    long long it = it_w[0];
+    bool valid = valid_w[0];
+    unsigned sa = sa_w[0], sb = sb_w[0];
+    static_for<1, G>([&](auto gc) TPIV_LAMBDA_INLINE {
+        constexpr int gi = decltype(gc)::value;
+        it = g == gi ? it_w[gi] : it;
+        valid = g == gi ? valid_w[gi] : valid;
+        sa = g == gi ? sa_w[gi] : sa;
+        sb = g == gi ? sb_w[gi] : sb;
+    });
+    const uint4 rec = p.cand[it];
+    auto lo16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v & 0xffffu); };
+    auto hi16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v >> 16); };
+    const int m = valid ? lo16(rec.x) : -3;
+    double* const out = reinterpret_cast<double*>(p.peak_raw) + (size_t)it * 8;
+    const bool writer = k == 0;
+    if (m == -1 && c == 0 && writer) p.fb_list[atomicAdd(p.fb_count, 1u)] = (int)it;
+    if (m == -2 && c < 8 && writer) out[c] = c == 6 ? 0.0 : 1.0;          // zero-mean window (B:513): finalize_kernel looks at the flag [7] only
+    const bool go = m >= 0;
+    if (__ballot(go) == 0ull) return;
+    int q = -1;
+    if (go) {
+        int left = m + 1, right = m - 1, top = m + W, bot = m - W;      // B:385-392
+        if (left >= KD - 1) left = m;
+        if (right <= 0) right = m;
+        if (top >= KD - 1) top = m;
+        if (bot <= 0) bot = m;
+        q = c == 0 ? m : q;
+        q = c == 1 ? left : q;
+        q = c == 2 ? right : q;
+        q = c == 3 ? top : q;
+        q = c == 4 ? bot : q;
+        q = c == 5 ? hi16(rec.x) : q;
+        q = c == 6 ? lo16(rec.y) : q;
+        q = c == 7 ? hi16(rec.y) : q;
+        q = c == 8 ? lo16(rec.z) : q;
+        q = c == 9 ? hi16(rec.z) : q;
+        q = c == 10 ? lo16(rec.w) : q;
+        q = c == 11 ? hi16(rec.w) : q;
+    }
+    // ---- S(q): the rows k, k + SL, ... of this lane's rotation
+    unsigned S = 0u;
+    {
+        const bool on = q >= 0;
+        const int qq = on ? q : 0;
+        const int qy = qq / W, qx = qq - qy * W;
+        int dy = qy - W / 2, bx = qx - W / 2;
+        bx += bx < 0 ? W : 0;
+        const unsigned sh = (unsigned)(bx & 3);
+        const uint32_t* const ag = any_smem + g * W * ndw;
+        const uint32_t* const bg = any_smem + G * W * ndw + g * W * xp + (bx >> 2);
+        for (int y = k; y < W; y += SL) {
+            int by = y + dy;
+            by += by < 0 ? W : 0;
+            by -= by >= W ? W : 0;
+            const uint32_t* ar = ag + y * ndw;
+            const uint32_t* br = bg + by * xp;
+            uint32_t prev = br[0];
+            for (int i = 0; i < ndw; ++i) {
+                const uint32_t nxt = br[i + 1];
+                S = __builtin_amdgcn_udot4(ar[i], __builtin_amdgcn_alignbyte(nxt, prev, sh), S, false);
+                prev = nxt;
+            }
+        }
+        S = on ? S : 0u;
+    }
+    if constexpr (SL == 4) {        // the four row slices of a cell sit in the four rows of 16 lanes
+        auto r = __builtin_amdgcn_permlane16_swap(S, S, false, false);
+        S = r[0] + r[1];
+        auto r2 = __builtin_amdgcn_permlane32_swap(S, S, false, false);
+        S = r2[0] + r2[1];
+    }
+    decide_and_store(p, rec, c, go, writer, q >= 0, m, S, sa, sb, (double)KD, out, it);
 }
 
 }  // namespace
@@ -285,15 +442,34 @@ static hipError_t launch_refine(const PassParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int G>
+static hipError_t launch_refine_any(const PassParams& p, hipStream_t stream) {
+    const int W = p.ws, ndw = (W + 3) / 4;
+    const int xp = ((2 * W + 6 + 3) / 4) | 1;              // dwords per parked row: reads reach byte 2 W + 5; odd pitch
+    const long long total = (long long)p.batch * p.n_rows * p.n_cols;
+    const long long chunk = (total + 7) / 8;
+    const long long slots = (chunk + G - 1) / G;
+    const size_t smem = (size_t)G * W * (ndw + xp) * sizeof(uint32_t);
+    if (smem > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((xcorr_exact_refine_any_kernel<G>), dim3((unsigned)(slots * 8)), dim3(64), smem, stream, p, ndw, xp);
+    return hipGetLastError();
+}
+
+// window sizes the exact scheme covers: every even size from 8 to 128 (odd sizes have the reference's ws x (ws - 1) map,
+// B:255 -- not a plain circular correlation --, larger ones do not fit the refinement's LDS: both run the float64 kernels)
+bool exact_refine_size(int ws) { return ws >= 8 && ws <= 128 && (ws & 1) == 0; }
+
 hipError_t launch_exact_refine(const PassParams& p, hipStream_t stream) {
     const long long total = (long long)p.batch * p.n_rows * p.n_cols;
-    if (total <= 0 || total >= (1ll << 31) || p.cand == nullptr || p.fb_list == nullptr || p.fb_count == nullptr)
+    if (total <= 0 || total >= (1ll << 31) || p.cand == nullptr || p.fb_list == nullptr || p.fb_count == nullptr ||
+        !exact_refine_size(p.ws))
         return hipErrorInvalidValue;
     switch (p.ws) {
+        case 16: return launch_refine<16>(p, stream);
         case 32: return launch_refine<32>(p, stream);
         case 64: return launch_refine<64>(p, stream);
         case 128: return launch_refine<128>(p, stream);
-        default: return hipErrorInvalidValue;
+        default: return p.ws <= 32 ? launch_refine_any<4>(p, stream) : launch_refine_any<1>(p, stream);
     }
 }
 

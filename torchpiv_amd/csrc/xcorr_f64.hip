@@ -717,10 +717,12 @@ static hipError_t launch_f64_tile(const PassParams& p, int n_cu, hipStream_t str
 hipError_t launch_xcorr_f64_list(const PassParams& p, int n_cu, hipStream_t stream) {
     if (p.fb_list == nullptr || p.fb_count == nullptr) return hipErrorInvalidValue;
     const long long items = (long long)p.batch * p.n_rows * p.n_cols;
-    const int per_cu = p.ws == 32 ? 8 : (p.ws == 64 ? 4 : 1);
+    const int per_cu = p.ws <= 32 ? 8 : (p.ws == 64 ? 4 : 1);
     long long blocks = items < (long long)n_cu * per_cu ? items : (long long)n_cu * per_cu;
     blocks = (blocks + 7) / 8 * 8;
     switch (p.ws) {
+        case 8: hipLaunchKernelGGL((xcorr_f64_tile_list_kernel<8>), dim3((unsigned)blocks), dim3(64), 0, stream, p); break;
+        case 16: hipLaunchKernelGGL((xcorr_f64_tile_list_kernel<16>), dim3((unsigned)blocks), dim3(64), 0, stream, p); break;
         case 32: hipLaunchKernelGGL((xcorr_f64_tile_list_kernel<32>), dim3((unsigned)blocks), dim3(64), 0, stream, p); break;
         case 64: hipLaunchKernelGGL((xcorr_f64_list_kernel<64>), dim3((unsigned)blocks), dim3(128), 0, stream, p); break;
         case 128: hipLaunchKernelGGL((xcorr_f64_split_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, stream, p); break;

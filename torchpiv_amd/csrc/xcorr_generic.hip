@@ -198,6 +198,66 @@ __device__ AM<R> block_argmax(AM<R> a, R* red, int* redi) {
     return AM<R>{red[0], redi[0]};
 }
 
+// ---- precision "exact" (xcorr_exact.hip): the float32 map of a generic-size window only LOCATES the cells the refinement
+// evaluates as exact integer sums.  PassParams::cand != nullptr (first pass only) switches the kernels of this file from
+// the 8-float record to the candidate record of xcorr_tile.hpp's peak_candidates: the arg-max if it is the only cell within
+// the band of the maximum, up to EXACT_MAX_SECOND cells outside the exclusion zone within the band of their maximum, up to
+// EXACT_MAX_MIN cells within the band of the minimum (more: three and -2); undecided -1, dead -2.
+// E+ = (|a'|^2 + |b'|^2) / 2, a' = a / mean(a) - 1, from the exact integer sums of the staged bytes (piv_kernels.h, "The band")
+__device__ __forceinline__ float exact_e_plus(unsigned sa, unsigned sb, unsigned saa, unsigned sbb, int nn) {
+    const double n_ = (double)nn, da = (double)sa, db = (double)sb;
+    const float ea = (float)__fma_rn(-da, da, n_ * (double)saa), eb = (float)__fma_rn(-db, db, n_ * (double)sbb);
+    const float ka = (float)nn / (float)sa, kb = (float)nn / (float)sb;
+    return (0.5f / (float)nn) * (ea * (ka * ka) + eb * (kb * kb));
+}
+// map: n x n cells v = (c - min) + 1e-7 in fftshift layout (LDS or global), complete and visible to the workgroup; m / gmax:
+// first peak; second_v: largest cell outside the exclusion zone (has_second: there is one); scr: 10 ints of LDS.
+// Every thread of the workgroup calls it (two barriers).
+__device__ __forceinline__ void map_candidates(const PassParams& p, const float* map, int n, int m, float gmax, float second_v,
+                                               bool has_second, float band_abs, bool dead, bool store, size_t fidx, int* scr) {
+    const int nn = n * n, wv = p.val_win, tid = (int)threadIdx.x, nthreads = (int)blockDim.x;
+    if (tid < 3) scr[tid] = 0;
+    __syncthreads();
+    const float band = fmaxf(p.exact_band_range * (gmax - 1e-7f), band_abs);
+    const float top_thr = gmax - band, sec_thr = second_v - band, min_thr = 1e-7f + band;
+    for (int i = tid; i < nn; i += nthreads) {
+        const float v = map[i];
+        if (v >= top_thr) atomicAdd(&scr[0], 1);
+        if (has_second && v >= sec_thr) {
+            bool excl = false;                               // B:346-358: i == clamp(m + t + n j), |t|, |j| <= wv
+            for (int j = -wv; j <= wv; ++j) {
+                const int t = i - m - n * j;
+                excl = excl || (t >= -wv && t <= wv);
+            }
+            excl = excl || (i == 0 && (m - wv - wv * n) <= 0) || (i == nn - 1 && (m + wv + wv * n) >= nn - 1);
+            if (!excl) {
+                const int k = atomicAdd(&scr[1], 1);
+                if (k < EXACT_MAX_SECOND) scr[3 + k] = i;
+            }
+        }
+        if (v <= min_thr) {
+            const int k = atomicAdd(&scr[2], 1);
+            if (k < EXACT_MAX_MIN) scr[3 + EXACT_MAX_SECOND + k] = i;
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && store) {
+        const int cnt = scr[0], ns = scr[1], nm_ = scr[2];
+        const bool open = !(band > 0.0f) || !(gmax > 1e-7f) || cnt != 1 || ns > EXACT_MAX_SECOND;
+        auto get = [&](int base, int cnt_, int k) { return k < cnt_ ? scr[base + k] : -1; };
+        auto pack = [](int lo_, int hi_) { return ((unsigned)lo_ & 0xffffu) | ((unsigned)hi_ << 16); };
+        const int m_out = dead ? -2 : (open ? -1 : m);
+        const int n3 = nm_ > EXACT_MAX_MIN ? -2 : get(3 + EXACT_MAX_SECOND, nm_, 3);
+        uint4 rec;
+        rec.x = pack(m_out, get(3, ns, 0));
+        rec.y = pack(get(3, ns, 1), get(3, ns, 2));
+        rec.z = pack(get(3 + EXACT_MAX_SECOND, nm_, 0), get(3 + EXACT_MAX_SECOND, nm_, 1));
+        rec.w = pack(get(3 + EXACT_MAX_SECOND, nm_, 2), n3);
+        p.cand[fidx] = rec;
+    }
+    __syncthreads();
+}
+
 template <int MODE, typename R>
 __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>* scratch) {
     using cf = cplx<R>;
@@ -206,6 +266,10 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
     __shared__ cf tw2[256];           // odd n: exp(-2 pi i k / (n - 1)) for the last inverse transform
     __shared__ R red[GT];
     __shared__ int redi[GT];
+    __shared__ int cscr[16];          // candidate lists of the exact scheme (map_candidates)
+    // LIST (float64 pass 1 under precision "exact"): the windows of PassParams::fb_list, counted on the device
+    const bool listed = F64 && MODE == MODE_PASS1 && p.fb_list != nullptr;
+    constexpr bool CAN_CAND = !F64 && MODE == MODE_PASS1;
     const int n = p.ws, nn = n * n;
     const int tid = threadIdx.x;
     const int N = p.n_rows * p.n_cols;
@@ -225,7 +289,9 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
     }
     __syncthreads();
 
-    for (long long item = blockIdx.x; item < items; item += gridDim.x) {
+    const long long n_items = listed ? (long long)*p.fb_count : items;
+    for (long long item_ = blockIdx.x; item_ < n_items; item_ += gridDim.x) {
+        const long long item = listed ? (long long)p.fb_list[item_] : item_;
         const int pair = (int)(item / N), win = (int)(item % N);
         const int y0 = (win / p.n_cols) * st, x0 = (win % p.n_cols) * st;
         const uint8_t* __restrict__ fa = p.A + (size_t)pair * HW;
@@ -245,13 +311,19 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
         }
         // ---- staging
         R sa = 0, sb = 0;
+        unsigned iaa = 0u, ibb = 0u;      // CAND: sums of squares of the bytes (exact)
         for (int i = tid; i < nn; i += GT) {
             const int y = i / n, x = i % n;
             R a, b;
             if constexpr (MODE == MODE_PASS1) {
                 const size_t q = (size_t)(y0 + y) * p.W + x0 + x;
-                a = (R)fa[q];
-                b = (R)fb[q];
+                const unsigned ba = fa[q], bb = fb[q];
+                a = (R)ba;
+                b = (R)bb;
+                if constexpr (CAN_CAND) {
+                    iaa += ba * ba;
+                    ibb += bb * bb;
+                }
             } else if constexpr (MODE == MODE_DWS) {
                 const long long q = (long long)(y0 + y) * p.W + x0 + x;
                 a = fetch_clamped_g(fa, q - sh, HW);
@@ -280,6 +352,14 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
             dead = (sa == 0) || (sb == 0);
             ka = dead ? (R)0 : (R)1 / ma;
             kb = dead ? (R)0 : (R)1 / mb;
+        }
+        float band_abs = 0.f;
+        if constexpr (CAN_CAND) {
+            if (p.cand != nullptr) {      // (window sums of squares < 2^31 for n <= 181; sa, sb < 2^24: exact in float)
+                const unsigned saa = block_sum(iaa, reinterpret_cast<unsigned*>(red));
+                const unsigned sbb = block_sum(ibb, reinterpret_cast<unsigned*>(red));
+                band_abs = dead ? 0.f : p.exact_band * exact_e_plus((unsigned)sa, (unsigned)sb, saa, sbb, nn);
+            }
         }
         __syncthreads();
         if constexpr (F64) {
@@ -436,6 +516,13 @@ __global__ __launch_bounds__(GT) void xcorr_generic_kernel(PassParams p, cplx<R>
         }
         second = block_argmax(second, red, redi);
         __syncthreads();
+        if constexpr (CAN_CAND) {
+            if (p.cand != nullptr) {      // (even sizes only: launch_xcorr)
+                map_candidates(p, reinterpret_cast<const float*>(map), n, m, (float)best.v, (float)second.v, second.idx < nm,
+                               band_abs, dead, true, fidx, cscr);
+                continue;
+            }
+        }
         if (tid < 8) {
             int left = m + 1, right = m - 1, top = m + mc, bot = m - mc;    // B:385-392
             if (left >= nm - 1) left = m;
@@ -508,6 +595,19 @@ __device__ __forceinline__ float ct_sum(float v, float* red) {
     __syncthreads();
     float r = red[0];
     for (int w = 1; w < nw; ++w) r += red[w];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ unsigned ct_sum_u(unsigned v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o, 64);
+    const int nw = (int)blockDim.x >> 6;
+    if (nw == 1) return v;
+    unsigned* redu = reinterpret_cast<unsigned*>(red);
+    if ((threadIdx.x & 63) == 0) redu[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned r = redu[0];
+    for (int w = 1; w < nw; ++w) r += redu[w];
     __syncthreads();
     return r;
 }
@@ -642,9 +742,13 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
     cff* T0 = reinterpret_cast<cff*>(ct_smem);
     cff* T1 = T0 + WPW * n * P;                             // (NC > 0: no second tile -- the patches sit behind the WPW first ones)
     cff* tw = T1 + n * P;                                   // exp(-2 pi i k / n), k < n
-    float* red = reinterpret_cast<float*>(tw + n);          // 2 x CT_WAVES reduction slots
-    // compile-time form: per window of the wavefront {mean a, mean b, 1 / mean a, 1 / mean b, dead, stored, record index}
+    float* red = reinterpret_cast<float*>(tw + n);          // 2 x CT_WAVES reduction slots (run-time form)
+    // compile-time form: per window of the wavefront {mean a, mean b, 1 / mean a, 1 / mean b, dead | stored << 1, decision band
+    // of the exact scheme, record index}
     float* wmeta = reinterpret_cast<float*>(ct_smem + ct_register_meta_offset(n, WPW));
+    // candidate lists of the exact scheme (map_candidates): 16 ints behind the reduction slots / the per-window data
+    int* cscr = NC > 0 ? reinterpret_cast<int*>(wmeta + WPW * 8) : reinterpret_cast<int*>(red + 2 * CT_WAVES);
+    float band_abs = 0.f;
     const int PD = n + 4;                                   // CWS: source patch of a shifted window incl. the interpolation margin
     const int PDP = (PD + 3) & ~3;                          // its row pitch in LDS (rows start on dword boundaries)
     uint8_t* patch_a = reinterpret_cast<uint8_t*>(T1);      // (the patches live in the second tile's memory: it is idle until the
@@ -730,14 +834,18 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
             __syncthreads();
         }
         float sa = 0, sb = 0;
+        unsigned iaa = 0u, ibb = 0u;      // first pass: sums of squares of the bytes (exact; the band of the exact scheme)
 #pragma unroll 4
         for (int i = tid; i < nn; i += (int)blockDim.x) {
             const int y = div_small(i, rcp_n), x = i - y * n;
             float a, b;
             if constexpr (MODE == MODE_PASS1) {
                 const size_t q = (size_t)(y0 + y) * p.W + x0 + x;
-                a = (float)fa[q];
-                b = (float)fb[q];
+                const unsigned ba = fa[q], bb = fb[q];
+                a = (float)ba;
+                b = (float)bb;
+                iaa += ba * ba;
+                ibb += bb * bb;
             } else if constexpr (MODE == MODE_DWS) {
                 const long long q = (long long)(y0 + y) * p.W + x0 + x;
                 a = fetch_clamped_g(fa, q - sh, HW);
@@ -767,11 +875,17 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
             ka = dead ? 0.f : 1.f / ma;
             kb = dead ? 0.f : 1.f / mb;
         }
+        if constexpr (MODE == MODE_PASS1) {
+            if (p.cand != nullptr) {
+                const unsigned saa = ct_sum_u(iaa, red), sbb = ct_sum_u(ibb, red);
+                band_abs = dead ? 0.f : p.exact_band * exact_e_plus((unsigned)sa, (unsigned)sb, saa, sbb, nn);
+            }
+        }
         if constexpr (NC > 0) {
             if (tid == 0) {
                 float* mt = wmeta + wi * 8;
                 mt[0] = ma, mt[1] = mb, mt[2] = ka, mt[3] = kb;
-                mt[4] = __int_as_float(dead ? 1 : 0), mt[5] = __int_as_float(act ? 1 : 0);
+                mt[4] = __int_as_float((dead ? 1 : 0) | (act ? 2 : 0)), mt[5] = band_abs;
                 mt[6] = __int_as_float((int)(unsigned)fidx), mt[7] = __int_as_float((int)(unsigned)(fidx >> 32));
             }
         }
@@ -791,7 +905,7 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
             float* const map = reinterpret_cast<float*>(T0);
             const float* mt = wmeta + wq * 8;                 // this lane's window
             const float ma = mt[0], mb = mt[1], ka = mt[2], kb = mt[3];
-            const bool dead = __float_as_int(mt[4]) != 0, act = __float_as_int(mt[5]) != 0;
+            const bool dead = (__float_as_int(mt[4]) & 1) != 0, act = (__float_as_int(mt[4]) & 2) != 0;
             const size_t fidx = (size_t)(unsigned)__float_as_int(mt[6]) | ((size_t)(unsigned)__float_as_int(mt[7]) << 32);
             const int mirror = base + (NC - r) % NC;          // the lane that holds column -kx
             // reductions over the lanes of the window (groups of NC lanes, any NC): halving steps towards the group's
@@ -936,6 +1050,22 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
             }
             smax = seg(on ? smax : 0, [](int a_, int b_) TPIV_LAMBDA_INLINE { return a_ > b_ ? a_ : b_; });
             __syncthreads();                                  // (the map is complete)
+            if constexpr (MODE == MODE_PASS1) {
+                if (p.cand != nullptr) {      // precision "exact": candidate cells instead of the record, window after window
+#pragma unroll 1
+                    for (int wi = 0; wi < WPW; ++wi) {
+                        const int src = wi * NC;                                  // first lane of window wi
+                        const float* mw = wmeta + wi * 8;
+                        const int flags = __float_as_int(mw[4]);
+                        const size_t fw = (size_t)(unsigned)__float_as_int(mw[6]) | ((size_t)(unsigned)__float_as_int(mw[7]) << 32);
+                        const int sw = __shfl(smax, src, 64);
+                        map_candidates(p, reinterpret_cast<const float*>(reinterpret_cast<cff*>(ct_smem) + wi * n * P), NC,
+                                       __shfl(m, src, 64), __shfl(gmax, src, 64), __int_as_float(sw), sw > 0, mw[5],
+                                       (flags & 1) != 0, (flags & 2) != 0, fw, cscr);
+                    }
+                    continue;
+                }
+            }
             if (on && r < 8 && act) {
                 const int tid = r;                            // (record slot)
                 int left = m + 1, right = m - 1, top = m + n, bot = m - n;    // B:385-392
@@ -1033,6 +1163,12 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
         }
         second = ct_argmax(second, red);
         __syncthreads();
+        if constexpr (MODE == MODE_PASS1) {
+            if (p.cand != nullptr) {          // precision "exact": candidate cells instead of the record
+                map_candidates(p, map, n, m, best.v, second.v, second.idx < nn, band_abs, dead, true, fidx, cscr);
+                continue;
+            }
+        }
         if (tid < 8) {
             int left = m + 1, right = m - 1, top = m + n, bot = m - n;    // B:385-392
             if (left >= nn - 1) left = m;
@@ -1072,7 +1208,7 @@ static bool ct_register_size(int n) {
 }
 // (one tile per window of a wavefront, one pair of CWS patches, and eight floats of per-window data)
 static size_t ct_register_smem(int n, int mode) {
-    return ct_register_meta_offset(n, ct_register_wpw(n, mode)) + (size_t)ct_register_wpw(n, mode) * 8 * sizeof(float);
+    return ct_register_meta_offset(n, ct_register_wpw(n, mode)) + (size_t)ct_register_wpw(n, mode) * 8 * sizeof(float) + 16 * sizeof(int);
 }
 constexpr int CT_MAX_RADIX = 8;
 // n = n1 n2 with 2 <= n1 <= n2 <= CT_MAX_RADIX, n1 as large as possible; false if there is no such split
@@ -1084,7 +1220,7 @@ bool ct_factors(int n, int& n1, int& n2) {
     n2 = n / n1;
     return n1 >= 2 && n2 <= CT_MAX_RADIX;
 }
-size_t ct_smem_bytes(int n) { return (size_t)(2 * n * (n | 1) + n) * sizeof(cff) + 2 * CT_WAVES * sizeof(float); }     // (the two (n + 4) x pitch patches fit the second tile, n >= 4)
+size_t ct_smem_bytes(int n) { return (size_t)(2 * n * (n | 1) + n) * sizeof(cff) + 2 * CT_WAVES * sizeof(float) + 16 * sizeof(int); }     // (the two (n + 4) x pitch patches fit the second tile, n >= 4)
 bool ct_usable(int n, int precision) {
     int a, b;
     return precision == 0 && (n & 1) == 0 && n >= 4 && n <= 96 && ct_factors(n, a, b) && ct_smem_bytes(n) <= 160 * 1024;

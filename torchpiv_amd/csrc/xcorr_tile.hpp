@@ -783,10 +783,15 @@ __device__ __forceinline__ uint32_t read_unit_x(const uint4* src) {
 // instructions per sample; differs from the reference's evaluation order by float32 rounding only), and the per-sample window sums are not formed here (the mean is
 // removed in the DC bin after the row transform, see the kernel).  !FAST keeps the reference's
 // operation order: staged windows bit-identical to biliniar_interpolation_CWS (B:187-193).
-template <int WS, int MODE, int RBH = 1, bool FAST = false>
+// SQ (locating pass of precision "exact"): also the lane's sums of squares of the raw bytes (exact integers), from which
+// the kernel forms E+, the scale of its decision band (piv_kernels.h, "The band")
+struct RowSquares {
+    unsigned aa, bb;
+};
+template <int WS, int MODE, int RBH = 1, bool FAST = false, bool SQ = false>
 __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom& g, int r, int lane, float vx,
                                              float vy, RawRows<WS, MODE>& raw, cf (&x)[WS], float& sa,
-                                             float& sb, float* lds) {
+                                             float& sb, float* lds, RowSquares* sq = nullptr) {
     const int HW = p.H * p.W;
     const uint8_t* __restrict__ fa = p.A + (size_t)g.pair * HW;
     const uint8_t* __restrict__ fb = p.B + (size_t)g.pair * HW;
@@ -805,6 +810,16 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         }
         sa = (float)ia;
         sb = (float)ib;
+        if constexpr (SQ) {
+            unsigned iaa = 0, ibb = 0;
+#pragma unroll
+            for (int q = 0; q < WS / 4; ++q) {
+                iaa = __builtin_amdgcn_udot4(raw.a[q], raw.a[q], iaa, false);
+                ibb = __builtin_amdgcn_udot4(raw.b[q], raw.b[q], ibb, false);
+            }
+            sq->aa = iaa;
+            sq->bb = ibb;
+        }
         static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
             constexpr int k = decltype(kc)::value;
             x[k].x = byte_f<k, WS / 4>(raw.a);
@@ -1219,16 +1234,17 @@ __device__ __forceinline__ unsigned long long exclusion_row_mask(int m, int ys, 
     return ex;
 }
 
+// band_abs: the proven part of the decision band, 2 Gamma(WS) (1 + 1/16) E+ of this lane's window (piv_kernels.h, "The band")
 template <int WS>
 __device__ __forceinline__ void peak_candidates(const PassParams& p, const float (&row)[WS], float* tile, int w, int r,
-                                                bool active, bool dead, size_t fidx) {
-    static_assert(WS == 32 || WS == 64, "one or two windows per wavefront");
-    // ballot over the lanes of this lane's window (WS = 32: the two windows of the wavefront decide independently --
+                                                bool active, bool dead, size_t fidx, float band_abs) {
+    static_assert(WS == 8 || WS == 16 || WS == 32 || WS == 64, "64 / WS windows per wavefront");
+    // ballot over the lanes of this lane's window (WS < 64: the windows of the wavefront decide independently --
     // everything below is per-lane data and predicated control flow, uniform only within a window)
     auto wballot = [&](bool pred) TPIV_LAMBDA_INLINE {
         const unsigned long long b_ = __ballot(pred);
         if constexpr (WS == 64) return b_;
-        else return (b_ >> (w * 32)) & 0xffffffffull;
+        else return (b_ >> (w * WS)) & ((1ull << WS) - 1ull);
     };
     // "some window of the wavefront still has a bit set" / "this lane's window has": with one window per wavefront the
     // masks are wave-uniform and both are the plain scalar test
@@ -1250,8 +1266,8 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
     }
     const float cmin = grp_min<WS>(rmin);
     const float gmax = grp_reduce<WS>(rmax, [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); });
-    const float band = p.exact_band * (gmax - cmin);
-    bool open = !(band > 0.0f);                       // flat or NaN map
+    const float band = fmaxf(p.exact_band_range * (gmax - cmin), band_abs);
+    bool open = !(band > 0.0f) || !(gmax > cmin);     // flat or NaN map
     // map row of lane rl of the window (fftshift column order) through LDS: lane r receives column r
     auto park = [&](int rl) TPIV_LAMBDA_INLINE {
         wave_sync();
@@ -1500,8 +1516,13 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
 
         cf x[WS];
         float sa, sb;                      // window sums (for the mean)
+        // CAND: the decision band of the lane's window (float bits).  Register-bound tiles keep it in scalar registers, one
+        // per window of the wavefront; small tiles have registers to spare
+        constexpr int NBS = WS >= 32 ? G::WPW : 1;
+        int band_s[NBS];
         TPIV_STAMP(0);      // loop head: geometry, next shifts, combine loads
-        convert_rows<WS, MODE, RBH, FAST>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile);
+        RowSquares sq;
+        convert_rows<WS, MODE, RBH, FAST, CAND>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile, &sq);
         TPIV_STAMP(1);      // wait for the rows + conversion / bilinear sampling
         // 64x64 (register-bound): the dequeue issued at the loop head has landed by now; move it to a
         // scalar register (kept in a VGPR to the loop end it would be spilled, and the reload would
@@ -1543,6 +1564,25 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
                 dead = (sa == 0.f) || (sb == 0.f);
                 ka = dead ? 0.f : 1.0f / ma;
                 kb = dead ? 0.f : 1.0f / mb;
+            }
+            if constexpr (CAND) {
+                // E+ = (|a'|^2 + |b'|^2) / 2 with a' = a / mean(a) - 1:  |a'|^2 = n (n sum a^2 - (sum a)^2) / (sum a)^2, the
+                // bracket from exact integers (< 2^42: exact in float64), the rest in float32 (relative error ~1e-6 against
+                // the 1/16 margin of exact_band_coef).  Kept in scalar registers to the peak stage: one per window.
+                auto uadd = [](unsigned a_, unsigned b_) TPIV_LAMBDA_INLINE { return a_ + b_; };
+                const unsigned saa = grp_reduce<WS>(sq.aa, uadd), sbb = grp_reduce<WS>(sq.bb, uadd);
+                constexpr double NN = (double)(WS * WS);
+                const double da = (double)sa, db = (double)sb;
+                const float ea = (float)__fma_rn(-da, da, NN * (double)saa), eb = (float)__fma_rn(-db, db, NN * (double)sbb);
+                const float e_plus = (0.5f / (float)(WS * WS)) * (ea * (ka * ka) + eb * (kb * kb));       // ka = n / sum a
+                const float bnd = dead ? 0.f : p.exact_band * e_plus;
+                if constexpr (WS >= 32) {
+                    static_for<0, G::WPW>([&](auto wc) TPIV_LAMBDA_INLINE {
+                        band_s[decltype(wc)::value] = __builtin_amdgcn_readlane(__float_as_int(bnd), decltype(wc)::value * WS);
+                    });
+                } else {
+                    band_s[0] = __float_as_int(bnd);
+                }
             }
             // The 1/n^2 of the inverse transform and the 1/4 of the cross-spectrum algebra are applied
             // HERE, as the power of two 0.5/WS on both inputs: exact (no rounding anywhere changes), and
@@ -1661,6 +1701,11 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
         wave_sync();                                  // tile reads done: it becomes the map
         TPIV_STAMP(9);      // inverse row FFT
 
+        auto band_of = [&](int w_) TPIV_LAMBDA_INLINE {
+            int b_ = band_s[0];
+            static_for<1, NBS>([&](auto wc) TPIV_LAMBDA_INLINE { b_ = w_ == decltype(wc)::value ? band_s[decltype(wc)::value] : b_; });
+            return __int_as_float(b_);
+        };
         // ---- prefetch: the next item's row loads fly while this item's peak search runs
         if constexpr (WS > 32) {
             const int lane_p = fresh_lane();
@@ -1680,10 +1725,11 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
             const bool active_e = win_raw_e < N;
             const int win_e = active_e ? win_raw_e : N - 1;
             const size_t fidx_e = (size_t)pair_e * N + win_e;
-            if constexpr (CAND) peak_candidates<WS>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e);
+            if constexpr (CAND) peak_candidates<WS>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e, band_of(w_e));
             else peak_analysis<WS, PLANAR, FASTN>(p, crow, tile, w_e, r_e, active_e, dead, fidx_e, end_scale);
         } else {
-            peak_analysis<WS, PLANAR, FASTN>(p, crow, tile, w, r, active, dead, fidx, end_scale);
+            if constexpr (CAND) peak_candidates<WS>(p, crow, tile, w, r, active, dead, fidx, band_of(w));
+            else peak_analysis<WS, PLANAR, FASTN>(p, crow, tile, w, r, active, dead, fidx, end_scale);
         }
         wave_sync();
         if constexpr (WS < 64) nnitem = q_take(q_raw);
@@ -1698,9 +1744,8 @@ __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
 }
 // float32 first pass of the exact scheme: same transforms, candidate cells out
 template <int WS>
-__global__ __launch_bounds__(64, 3) void xcorr_tile_cand_kernel(PassParams p) {
-    static_assert(tile_occ_c(WS, MODE_PASS1) == 3, "built for the three-wavefront planar layout");
-    xcorr_tile_body<WS, MODE_PASS1, 3, true, true>(p);
+__global__ __launch_bounds__(64, tile_occ_c(WS, MODE_PASS1)) void xcorr_tile_cand_kernel(PassParams p) {
+    xcorr_tile_body<WS, MODE_PASS1, tile_occ_c(WS, MODE_PASS1), true, true>(p);
 }
 
 // ---- test hook: feed hand-made correlation maps straight into peak_analysis ------------------------

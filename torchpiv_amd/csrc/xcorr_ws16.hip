@@ -4,6 +4,9 @@ namespace tpiv {
 hipError_t launch_xcorr_ws16(const PassParams& p, int mode, int n_cu, hipStream_t stream) {
     return launch_xcorr_tile_ws<16>(p, mode, n_cu, stream);
 }
+hipError_t launch_xcorr_cand_ws16(const PassParams& p, int n_cu, hipStream_t stream) {
+    return launch_xcorr_tile_cand_ws<16>(p, n_cu, stream);
+}
 hipError_t launch_peak_debug_ws16(const PassParams& p, const float* maps, int n_maps, int planar, hipStream_t stream) {
     return launch_peak_debug<16>(p, maps, n_maps, planar, stream);
 }
