@@ -82,6 +82,7 @@ def parse_args():
                     help="exact (default): pass 1 from exact integer correlation sums (64x64 windows), shifted passes float32; "
                          "f64: pass 1 through a float64 FFT like the reference (PIVbackend.py:513-514); "
                          "reference: the same with the reference's operation order in the CWS sampling; fast: pass 1 in float32 too")
+    ap.add_argument("--no-gpu-sampling", action="store_true", help="do not sample the GPU clock / power from sysfs during the timed steps")
     ap.add_argument("--no-fast", action="store_true", help="N = 1: skip the float64-FFT and all-float32 runs reported beside the headline")
     ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end_to_end block (generator rates)")
     ap.add_argument("--batch", type=int, default=None, help="pairs per GPU per launch (config 1: 256; config 2: shard 500)")
@@ -414,6 +415,90 @@ PREC_NOTE = {
 }
 
 
+class GpuSampler:
+    """Shader clock and board power of one GPU, sampled from sysfs (amdgpu hwmon: freq1_input in Hz, power1_average /
+    power1_input in microwatts) by a thread while the timed steps run.  The roofline peaks assume the 2.4 GHz boost clock;
+    the in-kernel stamps of round 4 read 2.08-2.13 GHz under these kernels.  Everything is optional: a box that does not show
+    the files yields {"available": False, ...}."""
+
+    def __init__(self, torch_dev_index, period_s=0.02):
+        import threading
+        self.period = period_s
+        self.clk, self.pwr = [], []
+        self.files = {}
+        self.note = None
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch_dev_index)
+            bdf = None
+            if hasattr(pr, "pci_bus_id"):
+                bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}.0"
+            cands = []
+            if bdf and os.path.isdir(f"/sys/bus/pci/devices/{bdf}"):
+                cands = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if not cands:
+                cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+                if len(cards) == 1:
+                    cands = cards
+                else:
+                    self.note = f"{len(cards)} amdgpu hwmon nodes, none matched PCI {bdf}"
+            for h in cands[:1]:
+                for key, names in (("clk", ("freq1_input",)), ("pwr", ("power1_average", "power1_input"))):
+                    for n_ in names:
+                        f_ = os.path.join(h, n_)
+                        if os.path.exists(f_):
+                            self.files[key] = f_
+                            break
+        except Exception as exc:
+            self.note = f"{type(exc).__name__}: {exc}"
+
+    def _read(self, key):
+        try:
+            with open(self.files[key]) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            c = self._read("clk") if "clk" in self.files else None
+            w = self._read("pwr") if "pwr" in self.files else None
+            if c:
+                self.clk.append(c / 1e6)
+            if w:
+                self.pwr.append(w / 1e6)
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        if self.files:
+            self._stop.clear()
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+            self._thread = None
+
+    def summary(self):
+        def st(v):
+            if not v:
+                return None
+            v = sorted(v)
+            return {"median": v[len(v) // 2], "min": v[0], "max": v[-1], "samples": len(v)}
+        out = {"available": bool(self.clk or self.pwr), "gpu_clock_mhz": st(self.clk), "power_w": st(self.pwr),
+               "source": self.files or None,
+               "note": "sampled every 20 ms from the amdgpu hwmon files while the timed steps ran; the vector peaks of `roofline` "
+                       "assume 2400 MHz"}
+        if self.note:
+            out["problem"] = self.note
+        return out
+
+
 def main():
     args = parse_args()
     if args.e2e:
@@ -480,14 +565,22 @@ def main():
         v_all = torch.empty_like(u_all)
         i_all = torch.empty(max(n_local, 1), nr, nc, dtype=torch.uint8, device=dev)
 
-        def one_step(gather):
+        gather_ev, gather_stats = [], {}
+
+        def one_step(gather, timed_gather=False):
             for s_, n_ in shards:
                 # (every shard reads the same resident synthetic frames; its fields land in its own slice)
                 plan.run(A[:n_], B[:n_], out=(u_all[s_:s_ + n_], v_all[s_:s_ + n_], i_all[s_:s_ + n_]))
             if gather and world > 1:
                 # the single collective: (u, v) of every rank's pairs onto rank 0, float64 as yielded
+                if timed_gather:        # events on the launch stream around the two collectives (the stream waits for them)
+                    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    g0.record()
                 uv = torch.stack([u_all[:n_local], v_all[:n_local]], dim=1)
-                pdist.gather_fields(pair_ids, uv)
+                pdist.gather_fields(pair_ids, uv, stats=gather_stats)
+                if timed_gather:
+                    g1.record()
+                    gather_ev.append((g0, g1))
 
         for _ in range(warmup):
             one_step(True)       # (also rehearses the gather: communicator / buffer setup of the first call)
@@ -500,15 +593,21 @@ def main():
             return None
         plan.set_timing(True)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        sampler = GpuSampler(dev.index) if (rank == 0 and not args.no_gpu_sampling) else None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        if sampler:
+            sampler.start()
         t0 = time.perf_counter()
         ev[0].record()
         for k in range(steps):
-            one_step(gather_every_step or k == steps - 1)
+            one_step(gather_every_step or k == steps - 1, timed_gather=True)
             ev[k + 1].record()
         torch.cuda.synchronize()
+        elapsed_local = time.perf_counter() - t0           # this rank's own clock, before it waits for the others
+        if sampler:
+            sampler.stop()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
@@ -521,8 +620,10 @@ def main():
         plan.set_timing(False)
         res = {"precision": precision, "elapsed": elapsed, "step_ms": step_ms, "timing": timing, "n_runs": n_runs,
                "geometry": list(plan.geometry), "names": [plan.kernel_name(p_) for p_ in range(plan.n_pass)],
-               "n_pass": plan.n_pass}
-        if precision == "exact" and plan.geometry[0][0] == 64:
+               "n_pass": plan.n_pass, "elapsed_local": elapsed_local,
+               "gather_ms": [g0.elapsed_time(g1) for g0, g1 in gather_ev], "gather_stats": dict(gather_stats),
+               "gpu": sampler.summary() if sampler else None}
+        if precision == "exact" and plan.exact_capable():
             # slot pass1_xcorr taken apart (events behind each kernel), and how many windows the float64 transform decided
             res["exact_timing"] = plan.exact_timing()
             res["exact_fallbacks"] = {"windows": plan.exact_fallbacks(), "of": shards[-1][1] * plan.geometry[0][2] * plan.geometry[0][3],
@@ -572,7 +673,14 @@ def main():
             parity = {"error": f"{type(exc).__name__}: {exc}"}
 
     # who ran: backend and devices as torch.distributed saw them (every rank reports, rank 0 prints)
-    me = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(dev), "device_index": dev.index}
+    # ... and what a scaling curve needs to be read: every rank's own step times (HIP events on its launch stream), its own
+    # wall clock over the timed steps (before it waits for the others), its gather times and the bytes it put into the gather
+    st_me = sorted(head["step_ms"])
+    me = {"rank": rank, "local_rank": local, "device": torch.cuda.get_device_name(dev), "device_index": dev.index,
+          "step_ms_median": statistics.median(st_me), "step_ms_min": st_me[0], "step_ms_max": st_me[-1],
+          "ms_per_step_own_clock": head["elapsed_local"] / args.steps * 1e3,
+          "gather_ms": head["gather_ms"], "gather_payload_bytes": head["gather_stats"].get("payload_bytes", 0),
+          "gather_useful_bytes": head["gather_stats"].get("useful_bytes", 0)}
     ranks_info = [me]
     if world > 1:
         gathered = [None] * world
@@ -677,6 +785,10 @@ def main():
             }
             return kernels, roof
 
+        def spread(v):
+            v = sorted(float(t) for t in v)
+            return {"min": v[0], "median": statistics.median(v), "max": v[-1]} if v else None
+
         def stats(m):
             st = sorted(m["step_ms"])
             return {"median": statistics.median(st), "min": st[0], "max": st[-1],
@@ -722,17 +834,33 @@ def main():
                            "valu_frac_of_f32_peak": f_pair * value / world / 1e12 / FP32_VALU_PEAK_TFLOPS},
             "distributed": {"world_size": dist.get_world_size() if world > 1 else 1,
                             "backend": dist.get_backend() if world > 1 else None,
-                            "collectives_per_gather": 2 if world > 1 else 0, "ranks": ranks_info},
+                            "collectives_per_gather": 2 if world > 1 else 0,
+                            "per_rank_ms_per_step": spread([r_["ms_per_step_own_clock"] for r_ in ranks_info]),
+                            "per_rank_step_ms_median": spread([r_["step_ms_median"] for r_ in ranks_info]),
+                            "gather_ms": spread([g_ for r_ in ranks_info for g_ in r_["gather_ms"]]),
+                            "gathers_timed_per_rank": len(ranks_info[0]["gather_ms"]),
+                            "gather_payload_bytes_per_rank": spread([r_["gather_payload_bytes"] for r_ in ranks_info]),
+                            "gather_useful_bytes_total": sum(r_["gather_useful_bytes"] for r_ in ranks_info),
+                            "note": "per_rank_ms_per_step: every rank's own wall clock over the timed steps (min / median / max "
+                                    "over the ranks; `ms_per_step` of the line is the max plus the closing barrier); gather_ms: "
+                                    "HIP events around the two collectives of a gather on every rank's launch stream",
+                            "ranks": ranks_info},
+            "gpu": head["gpu"],
             "published_ref": {"value": 6.7, "unit": "pairs/s",
                               "note": "'>6.7 pairs/s' incl. file I/O, GPU unnamed (GTX 1660 Ti era), "
                                       "reference README.md:58; not this exact metric, so vs_baseline is null"},
         }
         if "exact_timing" in head:
             rec["exact"] = {"pass1_ms": head["exact_timing"], "float64_path": head["exact_fallbacks"],
-                            "band": 1.0e-4, "min_contrast": 0.028, "against_float64_fft": parity,
+                            "band": {"per_unit_of_E_plus": 2.0 * (3 * 12 * 6.66 + 6) * (1 + 1 / 16) * 2.0 ** -24,
+                                     "gamma_bound_u": 3 * 12 * 6.66 + 6,
+                                     "note": "decision band of the locating pass = 2 Gamma (1 + 1/16) E+, Gamma = 246 u the proven bound "
+                                             "on the float32 map's cell error (DESIGN.md 3.4b), E+ from exact integer window sums"},
+                            "against_float64_fft": parity,
                             "note": "pass1_xcorr of kernel_ms = locate_f32 + refine_exact + undecided_f64 + finalize (HIP events "
                                     "behind each kernel); parity gates: tests/test_gpu_exact.py (<= 1e-11 px against the float64 "
-                                    "kernel and the oracle, identical masks), error model: tools/research/exact_band.py"}
+                                    "kernel and the oracle, identical masks), error bound: DESIGN.md 3.4b, measured: tools/research/exact_band.py, "
+                                    "tools/research/exact_adversarial.py"}
         if f64_run is not None:
             k64, roof64 = analyse(f64_run)
             rec["f64_transform"] = {"dtype": DTYPE["f64"], "precision": PREC_NOTE["f64"],

@@ -147,6 +147,52 @@ def test_gather_four_ranks_one_all_dropped():
     assert vals == [float(i) for i in ids]
 
 
+def _worker8(rank, world, port, q):
+    """Eight ranks (the node the scaling run uses) and five pairs: ranks 5..7 own nothing (n < world), rank 1 drops its
+    only pair; the `stats` of the gather -- what bench.py puts on its line -- are checked on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from torchpiv_amd import dist as pdist
+    pdist.init_from_env(backend="gloo")
+    n_pairs = 5
+    mine = pdist.shard_indices(n_pairs, rank, world, "block")            # 1, 1, 1, 1, 1, 0, 0, 0
+    assert len(mine) == (1 if rank < 5 else 0)
+    kept = [] if rank == 1 else mine
+    fields = torch.stack([torch.full((2, 6, 7), float(i) + 0.5, dtype=torch.float64) for i in kept]) \
+        if kept else torch.zeros(0, 2, 0, 0, dtype=torch.float64)
+    st = {}
+    ids, allf = pdist.gather_fields(torch.tensor(kept, dtype=torch.int64), fields, stats=st)
+    assert st["collectives"] == 2 and st["counts"] == [1, 0, 1, 1, 1, 0, 0, 0]
+    assert st["payload_bytes"] == 2 * 6 * 7 * 8 + 8                      # every rank ships the largest shard's size
+    assert st["useful_bytes"] == len(kept) * (2 * 6 * 7 * 8 + 8)
+    if rank == 0:
+        assert tuple(allf.shape) == (4, 2, 6, 7)
+        q.put((ids.tolist(), allf[:, 1, 5, 6].tolist()))
+    else:
+        assert ids is None and allf is None
+    # a second gather on the same group (config 2 gathers in every step): same result, same statistics
+    st2 = {}
+    ids2, _ = pdist.gather_fields(torch.tensor(kept, dtype=torch.int64), fields, stats=st2)
+    assert st2 == st and (rank != 0 or ids2.tolist() == ids.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gather_eight_ranks_three_empty_one_all_dropped():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    ids, vals = q.get(timeout=240)
+    for p in procs:
+        p.join(90)
+        assert p.exitcode == 0
+    assert ids == [0, 2, 3, 4] and vals == [i + 0.5 for i in ids]
+
+
 @pytest.mark.timeout(180)
 def test_gather_two_ranks():
     port = _free_port()

@@ -1,4 +1,4 @@
-"""precision="exact" (csrc/xcorr_exact.hip; 32x32, 64x64 and 128x128 first-pass windows): pass 1 from exact integer
+"""precision="exact" (csrc/xcorr_exact.hip; every even first-pass window size from 8 to 128): pass 1 from exact integer
 correlation sums, located by a float32 FFT pass, with the float64 transform for the windows that pass cannot decide.
 
 Gates: (1) against the oracle's float64 pass 1 and the numpy statement of the scheme (tests/test_exact_scheme.py),
@@ -36,23 +36,33 @@ def fields(eng, A, B, precision, ws=64, **kw):
     return u.cpu().numpy(), v.cpu().numpy(), inv.cpu().numpy()
 
 
-@pytest.mark.parametrize("ws", [32, 64, 128])
+@pytest.mark.parametrize("ws", [8, 16, 32, 64, 128, 12, 28, 42, 48, 22, 96])
 @pytest.mark.parametrize("seed,shift", [(1, (2.3, -1.6)), (2, (0.0, 0.0)), (3, (-7.4, 11.2))])
 def test_exact_pass1_against_oracle_and_model(eng, seed, shift, ws):
     A, B = synthetic_pair(256, 256, seed, shift)
+    if shift[1] > ws / 4:
+        shift = (shift[0] * ws / 64, shift[1] * ws / 64)      # (keep the displacement inside the small windows)
+        A, B = synthetic_pair(256, 256, seed, shift)
     u0, v0, _, _, m0 = O.pass1(A, B, ws, ws // 2, validate=True)
     u, v, inv = fields(eng, A[None], B[None], "exact", ws)
-    assert np.abs(u[0] - u0).max() < TOL_F64 and np.abs(v[0] - v0).max() < TOL_F64
-    assert np.array_equal(inv[0].astype(bool), m0)
+    # sparse small windows have peak neighbours at the map minimum, where the log fit amplifies the float64 transform's own
+    # rounding (the value there is 1e-7 + 1e-16 noise): the strict float64 gates set those aside the same way
+    tol = TOL_F64 if ws >= 32 else 1e-9
+    from test_gpu_parity import near_tie_windows, pass1_constant
+    excused = pass1_constant(A, B, ws, ws // 2) | near_tie_windows(A, B, ws, ws // 2, rel=64 * 2.0 ** -52)
+    bad = ((np.abs(u[0] - u0) > tol) | (np.abs(v[0] - v0) > tol) | (inv[0].astype(bool) != m0)) & ~excused
+    assert not bad.any() and excused.mean() < 0.02, (ws, int(bad.sum()), int(excused.sum()), np.argwhere(bad)[:5].tolist())
     # the numpy statement of the scheme, window by window (its own float32 map may send other windows to the fallback)
-    aw, bw = O.windows(A, ws, ws // 2), O.windows(B, ws, ws // 2)
-    for i, (a, b) in list(enumerate(zip(aw, bw)))[:: max(1, len(aw) // 50)]:
-        r = exact_window(a, b)
-        if r is not None:
-            assert abs(r[0] - u[0].reshape(-1)[i]) < 1e-13 and abs(r[1] - v[0].reshape(-1)[i]) < 1e-13, i
+    if ws in (32, 64, 128):
+        aw, bw = O.windows(A, ws, ws // 2), O.windows(B, ws, ws // 2)
+        for i, (a, b) in list(enumerate(zip(aw, bw)))[:: max(1, len(aw) // 50)]:
+            r = exact_window(a, b)
+            if r is not None:
+                assert abs(r[0] - u[0].reshape(-1)[i]) < 1e-13 and abs(r[1] - v[0].reshape(-1)[i]) < 1e-13, i
 
 
-@pytest.mark.parametrize("ws,ov", [(64, 32), (64, 48), (64, 10), (64, 0), (32, 16), (32, 7), (128, 64), (128, 100)])
+@pytest.mark.parametrize("ws,ov", [(64, 32), (64, 48), (64, 10), (64, 0), (32, 16), (32, 7), (128, 64), (128, 100),
+                                   (16, 8), (16, 3), (8, 4), (8, 0), (24, 12), (42, 21), (56, 5), (100, 50), (126, 63), (10, 5)])
 def test_exact_equals_float64_kernel_on_full_frames(eng, ws, ov):
     from torchpiv_amd import synth
     A, B = synth.make_batch(4, 1024, 1024, device="cuda", noise=3.0, first_index=ov + 1)
@@ -90,11 +100,14 @@ def test_exact_edge_windows(eng, ws):
     assert np.abs(ue - uf).max() < TOL_F64 and np.abs(ve - vf).max() < TOL_F64
     assert np.array_equal(ie, i_f)
     assert np.all(ue[2] == 0.0) and np.all(ve[2] == 0.0)
-    for k in (0, 1, 3):                       # and against the oracle itself where the reference is deterministic
+    from test_gpu_parity import near_tie_windows, pass1_constant
+    for k in (0, 1, 3):                       # and against the oracle itself, every window: the excuse set of the float64 gates --
+        # constant windows (0/0 or all-rounding maps) and maps whose two largest float64 cells agree to 64 ulp
         u0, v0, _, _, m0 = O.pass1(A[k], B[k], ws, ws // 2, validate=True)
-        ok = np.abs(ue[k] - u0) < 1e-9
-        # pure-noise windows: the arg-max of the reference's own map is decided at 1e-16 relative; count, don't compare
-        assert ok.mean() > 0.9, k
+        excused = pass1_constant(A[k], B[k], ws, ws // 2) | near_tie_windows(A[k], B[k], ws, ws // 2, rel=64 * 2.0 ** -52)
+        bad = ((np.abs(ue[k] - u0) > 1e-9) | (np.abs(ve[k] - v0) > 1e-9) | (ie[k].astype(bool) != m0)) & ~excused
+        print(f"  edge windows ws {ws} frame {k}: {int(excused.sum())} of {excused.size} excused (constant / float64 tie), {int(bad.sum())} differing")
+        assert not bad.any(), (k, np.argwhere(bad)[:5].tolist())
 
 
 def test_exact_fallback_share_and_whole_chain(eng):
@@ -164,8 +177,8 @@ def test_exact_random_geometries(eng):
     against the float64 kernels on 40 seeded draws (row starts at every byte alignment, ragged last windows, one-window
     grids)."""
     rng = np.random.default_rng(20260)
-    for case in range(40):
-        ws = int(rng.choice([32, 64, 128]))
+    for case in range(60):
+        ws = int(rng.choice([32, 64, 128, 8, 16, 12, 20, 30, 36, 40, 48, 26, 34, 72]))
         ov = int(rng.integers(0, ws))
         H = int(rng.integers(ws, 5 * ws + 7))
         W = int(rng.integers(ws, 5 * ws + 11))

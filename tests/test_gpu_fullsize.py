@@ -43,10 +43,11 @@ def test_cfg2_against_oracle(pair, mode, precision):
     assert counts[-1][-1] == 127 * 127
 
 
-@pytest.mark.parametrize("precision", ["reference", "f64", "fast"])
+@pytest.mark.parametrize("precision", ["reference", "f64", "fast", "exact"])
 def test_cfg4_large_windows_against_oracle(pair, precision):
     """configs[4] geometry (2048^2, 128/64 -> 64/32, 2-pass CWS; pass 1 runs the two-threads-per-line 128x128
-    kernel, or its float64 form at reference precision) against the oracle, same rule."""
+    kernel, its float64 form at reference precision, or -- at the default "exact" -- the 128x128 locating pass + exact
+    integer sums) against the oracle, same rule."""
     from torchpiv_amd import engine
     from test_gpu_parity import cascade_check
     a, b = pair
@@ -66,7 +67,7 @@ def test_cfg3_geometry_against_oracle(mode):
     a, b = synth.make_pair(1024, 1536, 654, kind="vortex", noise=2.0)
     geo = [(32, 16), (16, 8), (8, 4)]
     g = _oracle_fields(a.numpy(), b.numpy(), geo, mode, "cfg3")
-    for precision in ("reference", "f64", "fast"):
+    for precision in ("reference", "f64", "fast", "exact"):
         # absolute caps on the vectors that differ from the oracle's chain at all (observed: 0, 0 and -- DWS, 8x8 pass --
         # 5 of 97 665, every one inside the 16-ulp band)
         counts = cascade_check(engine, g, "cfg3", mode, precision, geo, max_differing=[2, 4, 16])

@@ -560,9 +560,10 @@ def test_banded_predictor_equals_dense(eng, H, W, ws, n_pass, mode):
     plan.close()
 
 
-@pytest.mark.parametrize("precision", ["fast", "f64"])
+@pytest.mark.parametrize("precision", ["fast", "f64", "exact"])
 def test_generic_sizes_pass1(eng, golden, precision):
-    """Window sizes outside 8/16/32/64/128 run the generic-size kernel (plain DFT)."""
+    """Window sizes outside 8/16/32/64/128 run the generic-size kernels ("exact", the default: their candidate forms +
+    the lane-per-cell refinement for every even size up to 128; odd sizes and 256 the float64 plain-DFT kernel)."""
     g = golden("g7_generic")
     for name in g["p1_names"]:
         ws, ov = (int(t) for t in g[name + "_cfg"])
@@ -687,7 +688,7 @@ def test_errors(eng):
         eng.pass1(a.cpu(), a.cpu(), 32, 16)
 
 
-@pytest.mark.parametrize("precision", ["fast", "f64"])
+@pytest.mark.parametrize("precision", ["fast", "f64", "exact"])
 def test_black_and_saturated_windows(eng, precision):
     """All-black windows: the reference's 0/0 map gives u = v = 0 flagged valid in pass 1."""
     a = torch.zeros(128, 128, dtype=torch.uint8)

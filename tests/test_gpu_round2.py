@@ -125,7 +125,7 @@ def test_shifted_128_windows(eng, golden, mode):
     _, _, _, win, _ = eng.debug_pass(mode, dev(a), dev(b), w, o, u2, v2)
     assert np.array_equal(win[0, :, 0].cpu().numpy(), aa.astype(np.float32))
     assert np.array_equal(win[0, :, 1].cpu().numpy(), bb.astype(np.float32))
-    for precision in ("reference", "f64", "fast"):
+    for precision in ("reference", "f64", "fast", "exact"):       # ("exact": a 66-pixel first pass -- generic candidate kernel)
         cascade_check(eng, g, name, mode, precision, [(ws, ov), (w, o)], max_differing=[2, 2])       # observed: 0, 0
 
 
@@ -526,11 +526,11 @@ def test_odd_window_in_a_shifted_pass(eng, golden, mode):
                         f"{name} {mode} pass 1", max_flip_frac=0.0, max_bad_frac=0.0,
                         excused=fp32_noise_excuse(aa, bb, nr, nc), constant=constant_windows(aa, bb, nr, nc))
     print(f"odd window 33 {mode}: max err {e:.2e} px, mask flips {f}")
-    for precision in ("reference", "f64", "fast"):
+    for precision in ("reference", "f64", "fast", "exact"):       # ("exact": a 66-pixel first pass -- generic candidate kernel)
         cascade_check(eng, g, name, mode, precision, [(ws, ov), (w, o)], max_differing=[2, 2])       # observed: 0, 0
 
 
-@pytest.mark.parametrize("precision", ["reference", "f64", "fast"])
+@pytest.mark.parametrize("precision", ["reference", "f64", "fast", "exact"])
 @pytest.mark.parametrize("mode", ["DWS", "CWS"])
 def test_other_scales_and_zero_overlap(eng, golden, mode, precision):
     """Whole plans at multipass_scale 1.5 (64/32 -> 42/21 -> 28/14: generic sizes in shifted passes), 4.0

@@ -1,0 +1,155 @@
+"""Adversarial search for the float32 locating pass of precision="exact" (GPU): hill-climb on uint8 windows that MAXIMISES
+the float32 map's cell error relative to E+ = (|a'|^2 + |b'|^2) / 2, the quantity the decision band is proportional to
+(piv_kernels.h "The band": band = 2 Gamma (1 + 1/16) E+, Gamma the proven bound -- 246 u = 1.47e-5 at 64 x 64).
+
+A population of window pairs per seed family (particles, noise, two-level, sinusoids, checkerboards, impulses, saturated)
+is mutated -- single pixels, blocks, rows, copies between the frames, level shifts -- and a mutant replaces its parent
+when err / E+ grows.  err is the largest deviation of the float32 map (tile kernel, debug hook: the same transforms as the
+candidate kernels) from the float64 map, after removing the common offset (which changes no decision).  Output: the worst
+ratio per family and size against Gamma, and the worst windows as tests/golden/g12_adversarial.npz
+(tests/test_gpu_exact.py::test_exact_on_adversarial_windows runs precision="exact" against the float64 kernels on them).
+
+    python tools/research/exact_adversarial.py [--iters 400] [--pop 128] [--sizes 64 32 16 8 128] [--save]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+import torch
+
+from torchpiv_amd import engine
+
+U32 = 2.0 ** -24
+
+
+def gamma_u(W):
+    return 2 * (2 * np.ceil(np.log2(W)) * 6.66 + 1) + 4 + 2 * np.ceil(np.log2(W)) * 6.66
+
+
+def seeds(W, pop, rng):
+    yy, xx = np.mgrid[0:W, 0:W]
+    fam = {}
+
+    def particles(n_p, noise, bg):
+        out = np.zeros((pop, 2, W, W))
+        for i in range(pop):
+            py, px = rng.uniform(0, W, n_p), rng.uniform(0, W, n_p)
+            amp = rng.uniform(80, 250, n_p)
+            sh = rng.uniform(-W / 8, W / 8, 2)
+            for f, (oy, ox) in enumerate(((0, 0), sh)):
+                img = np.full((W, W), float(bg))
+                for y, x, a_ in zip(py + oy, px + ox, amp):
+                    img += a_ * np.exp(-(((yy - y + W / 2) % W - W / 2) ** 2 + ((xx - x + W / 2) % W - W / 2) ** 2) / 2.0)
+                out[i, f] = img + rng.normal(0, noise, img.shape)
+        return out
+
+    fam["particles"] = particles(max(2, W * W // 120), 2.0, 8)
+    fam["particles, bright background"] = particles(max(2, W * W // 120), 2.0, 180)
+    fam["uniform noise"] = rng.integers(0, 256, (pop, 2, W, W)).astype(float)
+    fam["two levels"] = 200 + rng.integers(0, 2, (pop, 2, W, W)).astype(float)
+    k = rng.integers(1, max(2, W // 2 - 1), (pop, 1, 1, 1))
+    ph = rng.uniform(0, 6.28, (pop, 2, 1, 1))
+    fam["sinusoids"] = 127 + 120 * np.sin(2 * np.pi * k * xx[None, None] / W + ph)
+    fam["checkerboards"] = 255.0 * (((xx + yy)[None, None] + rng.integers(0, 2, (pop, 2, 1, 1))) & 1) * (rng.random((pop, 2, W, W)) > 0.02)
+    imp = np.full((pop, 2, W, W), 3.0)
+    for i in range(pop):
+        for f in range(2):
+            imp[i, f, rng.integers(0, W, 3), rng.integers(0, W, 3)] = 255
+    fam["impulses"] = imp
+    sat = np.full((pop, 2, W, W), 255.0)
+    sat[rng.random(sat.shape) < 0.01] = 0
+    fam["saturated"] = sat
+    fam["all 255 / all 1 blocks"] = np.where(rng.random((pop, 2, W // 4, W // 4)).repeat(4, 2).repeat(4, 3) < 0.5, 255.0, 1.0)
+    return {k_: np.clip(np.rint(v), 0, 255).astype(np.uint8) for k_, v in fam.items()}
+
+
+def evaluate(P, W):
+    """P: uint8 [n, 2, W, W] on the device -> (err / E+ offset-free, err / E+ plain, R / E+) per individual (float64, device)."""
+    a, b = P[:, 0].contiguous(), P[:, 1].contiguous()
+    _, _, _, _, corr = engine.debug_pass(0, a, b, W, 0, precision="fast")
+    c32 = corr.reshape(-1, W, W).double()
+    af, bf = a.double(), b.double()
+    ma, mb = af.mean(dim=(1, 2), keepdim=True), bf.mean(dim=(1, 2), keepdim=True)
+    an, bn = af / ma - 1, bf / mb - 1
+    c64 = torch.fft.fftshift(torch.fft.irfft2(torch.fft.rfft2(an).conj() * torch.fft.rfft2(bn), s=(W, W)), dim=(1, 2))
+    c64 = c64 - c64.amin(dim=(1, 2), keepdim=True) + 1e-7
+    e = (c32 - c64).reshape(-1, W * W)
+    ep = 0.5 * ((an ** 2).sum(dim=(1, 2)) + (bn ** 2).sum(dim=(1, 2)))
+    free = 0.5 * (e.amax(dim=1) - e.amin(dim=1))
+    plain = e.abs().amax(dim=1)
+    R = c64.reshape(-1, W * W).amax(dim=1) - 1e-7
+    ok = (ep > 0) & torch.isfinite(free) & (ma.reshape(-1) > 0) & (mb.reshape(-1) > 0)
+    z = torch.zeros_like(free)
+    return torch.where(ok, free / ep, z), torch.where(ok, plain / ep, z), torch.where(ok, R / ep, z)
+
+
+def mutate(P, rng, W):
+    """P: uint8 numpy [n, 2, W, W] -> a mutated copy (one random edit per individual)."""
+    n = P.shape[0]
+    Q = P.copy()
+    kind = rng.integers(0, 6, n)
+    for i in range(n):
+        f = int(rng.integers(0, 2))
+        k = kind[i]
+        if k == 0:        # a few single pixels
+            m = int(rng.integers(1, 9))
+            Q[i, f, rng.integers(0, W, m), rng.integers(0, W, m)] = rng.integers(0, 256, m)
+        elif k == 1:      # a block to one level
+            y, x, h, w = (int(t) for t in rng.integers(0, W, 4))
+            Q[i, f, y:y + 1 + h // 4, x:x + 1 + w // 4] = int(rng.choice([0, 1, 128, 254, 255, rng.integers(0, 256)]))
+        elif k == 2:      # a row or a column
+            if rng.random() < 0.5:
+                Q[i, f, int(rng.integers(0, W))] = int(rng.integers(0, 256))
+            else:
+                Q[i, f, :, int(rng.integers(0, W))] = int(rng.integers(0, 256))
+        elif k == 3:      # copy the other frame, rolled
+            Q[i, f] = np.roll(Q[i, 1 - f], (int(rng.integers(0, W)), int(rng.integers(0, W))), (0, 1))
+        elif k == 4:      # level shift / contrast change
+            s = float(rng.choice([0.5, 0.9, 1.1, 2.0]))
+            o = float(rng.integers(-40, 41))
+            Q[i, f] = np.clip(Q[i, f].astype(np.float32) * s + o, 0, 255).astype(np.uint8)
+        else:             # binarise
+            Q[i, f] = np.where(Q[i, f] > int(rng.integers(1, 255)), 255, int(rng.integers(0, 4))).astype(np.uint8)
+    return Q
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=300)
+    ap.add_argument("--pop", type=int, default=96)
+    ap.add_argument("--sizes", type=int, nargs="*", default=[64, 32, 16, 8, 128])
+    ap.add_argument("--save", action="store_true")
+    args = ap.parse_args()
+    rng = np.random.default_rng(20261)
+    keep = {}
+    print(f"{'W':>4s} {'family':30s} {'start err/E+':>13s} {'found err/E+':>13s} {'(plain)':>10s} {'R/E+ there':>11s} {'Gamma':>10s} {'Gamma / found':>13s}")
+    for W in args.sizes:
+        pop = args.pop if W <= 64 else max(16, args.pop // 4)
+        G = gamma_u(W) * U32
+        for name, s in seeds(W, pop, rng).items():
+            P = s.copy()
+            fit, plain, re = (t.cpu().numpy() for t in evaluate(torch.from_numpy(P).cuda(), W))
+            start = float(fit.max())
+            for it in range(args.iters):
+                Q = mutate(P, rng, W)
+                fq, pq, rq = (t.cpu().numpy() for t in evaluate(torch.from_numpy(Q).cuda(), W))
+                better = fq > fit
+                P[better] = Q[better]
+                fit, plain, re = np.where(better, fq, fit), np.where(better, pq, plain), np.where(better, rq, re)
+            j = int(fit.argmax())
+            print(f"{W:4d} {name:30s} {start:13.3e} {float(fit[j]):13.3e} {float(plain[j]):10.2e} {float(re[j]):11.2e} {G:10.3e} {G / max(float(fit[j]), 1e-30):13.1f}",
+                  flush=True)
+            if W == 64:
+                keep[name] = P[np.argsort(-fit)[:4]].copy()
+    if args.save and keep:
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        names = sorted(keep)
+        np.savez_compressed(os.path.join(root, "tests", "golden", "g12_adversarial.npz"), names=np.array(names),
+                            **{f"w{i}": keep[n_] for i, n_ in enumerate(names)})
+        print("saved tests/golden/g12_adversarial.npz:", {n_: keep[n_].shape for n_ in names})
+
+
+if __name__ == "__main__":
+    main()

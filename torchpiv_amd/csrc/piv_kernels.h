@@ -59,31 +59,40 @@ struct PassParams {
 };
 
 // ---- precision "exact": constants shared by the locating passes (xcorr_tile.hpp peak_candidates, xcorr_big.hpp,
-// xcorr_generic.hip), the refinement (xcorr_exact.hip) and the launcher
+// xcorr_generic.hip map_candidates), the refinement (xcorr_exact.hip) and the launcher
 // The band.  A decision of the locating pass is right whenever every cell of its float32 map is within band / 2 of the
 // exact one (up to a common offset and a common factor 1 + O(u), which change no order).  The float32 map's cell error is
-// BOUNDED -- DESIGN.md 3.4b derives it from the componentwise FFT error analysis (Higham, Accuracy and Stability of
-// Numerical Algorithms, Thm 24.2), u = 2^-24, t = 2 log2(W) butterfly levels per 2-D transform:
-//     |map32(d) - map(d)|  <=  Gamma(W) E+,     E+ = (|a'|^2 + |b'|^2) / 2 >= |a'| |b'|,   a' = a / mean(a) - 1,
-//     Gamma(W) = (3 t eta + 6) u,   eta = 6.66  (twiddle error + 4 roundings per radix-2 level; the radix-4 / radix-8
-//     codelets and the two-factor mixed-radix codelets of fft_mixed.hpp are below that per level pair)
-//   forward 2-D transform of a' + i b' (t eta u |Z|) and the rounding of its inputs (u |Z|), carried through the bilinear
-//   cross-spectrum by Cauchy-Schwarz: 2 (t eta + 1) u E+;  the cross-spectrum's own arithmetic: 4 u E+;  the inverse
-//   transform, componentwise |dy_d| <= t eta u sum_k |P_k| <= t eta u N |a'| |b'|: t eta u E+.
-// W = 64: 246 u = 1.47e-5 (measured over tools/research/exact_band.py's families and its adversarial search: <= 7e-7).
+// BOUNDED -- DESIGN.md 3.4b derives it from the standard FFT error analysis (Higham, Accuracy and Stability of Numerical
+// Algorithms, 2nd ed., Thm 24.2), u = 2^-24:
+//     |map32(d) - map(d)|  <=  Gamma E+,     E+ = (|a'|^2 + |b'|^2) / 2  >=  |a'| |b'|,     a' = a / mean(a) - 1,
+//     Gamma = 2 (F + 1) u + 4 u + I u
+//   F u: normwise relative error of the forward 2-D transform of a' + i b' (+ 1 u for the rounding of its inputs), carried
+//        through the bilinear cross-spectrum by Cauchy-Schwarz: sum_k |dP_k| <= |dZ| |Z| = (F + 1) u N (|a'|^2 + |b'|^2);
+//   4 u: the cross-spectrum's own arithmetic;
+//   I u: the inverse 2-D transform, componentwise: |dy_d| <= I u sum_k |P_k| <= I u N |a'| |b'|.
+// Per 1-D transform of length n (a 2-D transform is two of them):
+//   radix-2/4 codelets (fft_inreg.hpp; tile kernels and 128x128): F = I = eta log2 n, eta = 6.66 per radix-2 level
+//       (twiddle error + 4 roundings; a radix-4 butterfly with its one twiddle per two levels is below two radix-2 levels);
+//   two-factor mixed-radix transforms (fft_mixed.hpp, radix_pass: n = n1 n2, direct small DFTs of radix r <= 8, each
+//       (r + 3) sqrt(r) u normwise, + 4 u for the twiddle between them): F = I <= 64 for every pair;
+//   plain O(n^2) DFTs (first-generation generic kernel): componentwise (n + 3) u sum |x|: I = n + 3, F = (n + 3) sqrt(n).
+// 64 x 64: Gamma = 246 u = 1.47e-5 (measured over tools/research/exact_band.py's families and its adversarial search: <= 8e-7).
 // The locating pass forms E+ from the exact integer window sums (sum a, sum a^2: v_sad_u8 / v_dot4_u32_u8 on the bytes it
-// staged) and uses band = 2 Gamma(W) (1 + 1/16) E+ -- the 1/16 covers the float32 rounding of E+ itself and of the band
-// comparisons.  The plain O(n^2) DFTs of the first-generation generic kernel accumulate n terms per output:
-// eta_line = n + 3 per 1-D transform instead of log2(n) eta.
+// staged) and uses band = 2 Gamma (1 + 1/16) E+ -- the 1/16 covers the float32 rounding of E+ itself and of the band
+// comparisons.
 constexpr double EXACT_ETA = 6.66;
-inline double exact_gamma_u(int ws, bool plain_dft) {       // Gamma(W) in units of u = 2^-24
-    double lg = 0.0;
-    for (int n = 1; n < ws; n *= 2) lg += 1.0;               // ceil(log2 ws): the two-factor codelets stay below it
-    const double t_eta = plain_dft ? 2.0 * (ws + 3) : 2.0 * lg * EXACT_ETA;
-    return 3.0 * t_eta + 6.0;
+enum { EXACT_FFT_RADIX2 = 0, EXACT_FFT_MIXED = 1, EXACT_FFT_PLAIN = 2 };
+inline double exact_gamma_u(int ws, int kind) {       // Gamma in units of u = 2^-24
+    double lg = 0.0, rt = 1.0;
+    for (int n = 1; n < ws; n *= 2) lg += 1.0;         // ceil(log2 ws)
+    while ((rt + 1.0) * (rt + 1.0) <= (double)ws) rt += 1.0;
+    rt += 1.0;                                         // >= sqrt(ws)
+    const double f1 = kind == EXACT_FFT_PLAIN ? (ws + 3) * rt : (kind == EXACT_FFT_MIXED ? 64.0 : lg * EXACT_ETA);
+    const double i1 = kind == EXACT_FFT_PLAIN ? (double)(ws + 3) : f1;
+    return 2.0 * (2.0 * f1 + 1.0) + 4.0 + 2.0 * i1;
 }
-inline float exact_band_coef(int ws, bool plain_dft = false) {
-    return (float)(2.0 * exact_gamma_u(ws, plain_dft) * (1.0 + 1.0 / 16) * 5.9604644775390625e-08);
+inline float exact_band_coef(int ws, int kind = EXACT_FFT_RADIX2) {
+    return (float)(2.0 * exact_gamma_u(ws, kind) * (1.0 + 1.0 / 16) * 5.9604644775390625e-08);
 }
 constexpr int EXACT_MAX_SECOND = 3, EXACT_MAX_MIN = 4;
 

@@ -275,8 +275,8 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
         p.fb_list = reinterpret_cast<int*>(base + l.list);
         p.fb_count = reinterpret_cast<unsigned*>(base + l.count);
         p.work_ctr = reinterpret_cast<unsigned*>(base + l.ctr);
-        // the decision band of the locating pass: 2 Gamma(ws) (1 + 1/16) E+ (piv_kernels.h, "The band"); the sizes that run
-        // the first-generation generic kernel transform by plain O(n^2) DFTs, whose bound grows with n
+        // the decision band of the locating pass: 2 Gamma (1 + 1/16) E+ (piv_kernels.h, "The band"), Gamma by the kind of
+        // transform the size's locating kernel runs
         // (TPIV_EXACT_BAND_SCALE / TPIV_EXACT_BAND_RANGE: experiments with the band, tools/research/exact_band.py)
         static const float band_scale = [] {
             const char* env = getenv("TPIV_EXACT_BAND_SCALE");
@@ -286,8 +286,8 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
             const char* env = getenv("TPIV_EXACT_BAND_RANGE");
             return env ? (float)atof(env) : 0.0f;
         }();
-        const bool plain_dft = !tile_size(p.ws) && p.ws != 128 && !generic_ct_usable(p.ws);
-        p.exact_band = band_scale * exact_band_coef(p.ws, plain_dft);
+        const int fft_kind = (tile_size(p.ws) || p.ws == 128) ? EXACT_FFT_RADIX2 : (generic_ct_usable(p.ws) ? EXACT_FFT_MIXED : EXACT_FFT_PLAIN);
+        p.exact_band = band_scale * exact_band_coef(p.ws, fft_kind);
         p.exact_band_range = band_range;
         e = hipMemsetAsync(p.fb_count, 0, 256 + WORK_CTR_BYTES, stream);
         if (e != hipSuccess) return e;

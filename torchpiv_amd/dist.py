@@ -56,7 +56,7 @@ def _numel(shape) -> int:
     return n
 
 
-def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=None):
+def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=None, stats: dict = None):
     """Gather variable-length shards onto rank `dst`.
 
     ids    int64 [n_local]            dataset index of every field this rank produced
@@ -64,12 +64,17 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
     Returns (ids_all, fields_all) sorted by dataset index on `dst`, (None, None) elsewhere.
     Ranks with nothing to send pass fields of shape [0, ...]; their tail shape is taken from the ranks
     that have data (exchanged with the counts), so an empty shard needs no plan.
+    stats (optional dict) receives what a scaling run needs to be read: the bytes this rank put into the payload collective
+    (`payload_bytes`, padded to the largest shard), the bytes of it that are fields and ids (`useful_bytes`), the shard
+    sizes of all ranks (`counts`) and the number of collectives issued.
     TWO collectives: one count / shape all-gather (56 bytes per rank) + one payload gather onto `dst` whose
     byte buffer carries the fields AND their ids: on xGMI's full mesh the seven shards arrive over seven
     different links at once, and no other rank has to hold the whole result (an all-gather would move and
     store world x more).
     """
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if stats is not None:
+            stats.update(payload_bytes=0, useful_bytes=0, counts=[int(ids.numel())], collectives=0)
         order = torch.argsort(ids)
         return ids[order], fields[order]
     world = dist.get_world_size(group)
@@ -104,6 +109,8 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
                 raise ValueError(f"gather_fields: rank {r_} holds fields of shape {t_r}, rank {int(have[0])} {tail}")
     if ids.numel() == 0:
         fields = fields.new_zeros((0,) + tail)
+    if stats is not None:
+        stats.update(payload_bytes=0, useful_bytes=0, counts=[int(c) for c in counts.tolist()], collectives=1)
     if n_max == 0:          # nothing anywhere (every rank knows it from the counts: no second collective)
         if rank != dst:
             return None, None
@@ -124,6 +131,9 @@ def gather_fields(ids: torch.Tensor, fields: torch.Tensor, dst: int = 0, group=N
         lst = list(all_b.unbind(0))
     else:
         lst = None
+    if stats is not None:
+        stats.update(payload_bytes=int(buf.numel()), collectives=2,
+                     useful_bytes=int(ids.numel()) * (_numel(tail) * fields.element_size() + 8))
     dst_global = dist.get_global_rank(group, dst) if group is not None else dst
     # (gather is implemented by both backends this package runs on -- RCCL and gloo; any error here is a
     #  real one and propagates: a fallback decided per rank could leave the ranks in different collectives)

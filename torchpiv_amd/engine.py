@@ -354,6 +354,11 @@ class Plan:
         lib.tpiv_plan_kernel_name(self._h, p, buf, 128)
         return buf.value.decode()
 
+    def exact_capable(self):
+        """precision="exact" and a first-pass window size the exact scheme covers (every even size from 8 to 128)?"""
+        ws = self.geometry[0][0]
+        return self.precision == "exact" and 8 <= ws <= 128 and ws % 2 == 0
+
     def exact_fallbacks(self):
         """precision="exact": windows of the last run whose first pass took the float64 transform (waits for the device)."""
         n = C.c_longlong()
