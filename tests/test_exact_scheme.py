@@ -203,3 +203,25 @@ def test_exact_scheme_on_a_true_zero_background():
         decided += 1
         assert abs(r[0] - u0.reshape(-1)[i]) < 1e-10 and abs(r[1] - v0.reshape(-1)[i]) < 1e-10 and r[2] == bool(m0.reshape(-1)[i])
     assert decided >= len(aw) // 2, (decided, len(aw))
+
+
+def test_float32_map_error_stays_inside_the_proven_bound():
+    """|map32 - map| <= Gamma E+ (piv_kernels.h "The band") on the adversarial windows of
+    tools/research/exact_adversarial.py (tests/golden/g12_adversarial.npz -- hill-climbed on the GPU kernel's own error) and on
+    random ones, for this file's float32 FFT (pocketfft / MKL: the analysis does not depend on the radix schedule)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_adversarial.npz"))
+    gamma = band_coef(64) / (2 * (1 + 1 / 16))
+    assert abs(gamma - 245.76 * U32) < 1e-12
+    rng = np.random.default_rng(7)
+    fams = [g[f"w{i}"] for i in range(len(g["names"]))] + [rng.integers(0, 256, (4, 2, 64, 64)).astype(np.uint8)]
+    worst = 0.0
+    for P in fams:
+        for a, b in P:
+            if a.sum() == 0 or b.sum() == 0:
+                continue
+            af, bf = a.astype(np.float64), b.astype(np.float64)
+            c64 = np.fft.fftshift(np.fft.irfft2(np.conj(np.fft.rfft2(af / af.mean() - 1)) * np.fft.rfft2(bf / bf.mean() - 1), s=a.shape))
+            e = f32_map(a, b).astype(np.float64) - c64
+            worst = max(worst, 0.5 * (e.max() - e.min()) / e_plus(a, b))
+    assert 0 < worst < gamma / 8, (worst, gamma)
