@@ -852,9 +852,9 @@ def main():
         }
         if "exact_timing" in head:
             rec["exact"] = {"pass1_ms": head["exact_timing"], "float64_path": head["exact_fallbacks"],
-                            "band": {"per_unit_of_E_plus": 2.0 * (3 * 12 * 6.66 + 6) * (1 + 1 / 16) * 2.0 ** -24,
-                                     "gamma_bound_u": 3 * 12 * 6.66 + 6,
-                                     "note": "decision band of the locating pass = 2 Gamma (1 + 1/16) E+, Gamma = 246 u the proven bound "
+                            "band": {"per_unit_of_E_plus": 2.0 * (3 * 12 * 6.66 + 7) * (1 + 1 / 16) * 2.0 ** -24,
+                                     "gamma_bound_u": 3 * 12 * 6.66 + 7,
+                                     "note": "decision band of the locating pass = 2 Gamma (1 + 1/16) E+, Gamma = 247 u the proven bound "
                                              "on the float32 map's cell error (DESIGN.md 3.4b), E+ from exact integer window sums"},
                             "against_float64_fft": parity,
                             "note": "pass1_xcorr of kernel_ms = locate_f32 + refine_exact + undecided_f64 + finalize (HIP events "

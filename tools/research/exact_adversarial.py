@@ -1,6 +1,6 @@
 """Adversarial search for the float32 locating pass of precision="exact" (GPU): hill-climb on uint8 windows that MAXIMISES
 the float32 map's cell error relative to E+ = (|a'|^2 + |b'|^2) / 2, the quantity the decision band is proportional to
-(piv_kernels.h "The band": band = 2 Gamma (1 + 1/16) E+, Gamma the proven bound -- 246 u = 1.47e-5 at 64 x 64).
+(piv_kernels.h "The band": band = 2 Gamma (1 + 1/16) E+, Gamma the proven bound -- 247 u = 1.47e-5 at 64 x 64).
 
 A population of window pairs per seed family (particles, noise, two-level, sinusoids, checkerboards, impulses, saturated)
 is mutated -- single pixels, blocks, rows, copies between the frames, level shifts -- and a mutant replaces its parent
@@ -25,7 +25,7 @@ U32 = 2.0 ** -24
 
 
 def gamma_u(W):
-    return 2 * (2 * np.ceil(np.log2(W)) * 6.66 + 1) + 4 + 2 * np.ceil(np.log2(W)) * 6.66
+    return 2 * (2 * np.ceil(np.log2(W)) * 6.66 + 1) + 5 + 2 * np.ceil(np.log2(W)) * 6.66
 
 
 def seeds(W, pop, rng):

@@ -65,10 +65,10 @@ struct PassParams {
 // BOUNDED -- DESIGN.md 3.4b derives it from the standard FFT error analysis (Higham, Accuracy and Stability of Numerical
 // Algorithms, 2nd ed., Thm 24.2), u = 2^-24:
 //     |map32(d) - map(d)|  <=  Gamma E+,     E+ = (|a'|^2 + |b'|^2) / 2  >=  |a'| |b'|,     a' = a / mean(a) - 1,
-//     Gamma = 2 (F + 1) u + 4 u + I u
+//     Gamma = 2 (F + 1) u + 5 u + I u
 //   F u: normwise relative error of the forward 2-D transform of a' + i b' (+ 1 u for the rounding of its inputs), carried
 //        through the bilinear cross-spectrum by Cauchy-Schwarz: sum_k |dP_k| <= |dZ| |Z| = (F + 1) u N (|a'|^2 + |b'|^2);
-//   4 u: the cross-spectrum's own arithmetic;
+//   5 u: the cross-spectrum's own arithmetic (re = 2 (ad + bc), im = (c^2 - a^2) + (d^2 - b^2): <= 5 u (|z_k|^2 + |z_-k|^2) / 4 per bin);
 //   I u: the inverse 2-D transform, componentwise: |dy_d| <= I u sum_k |P_k| <= I u N |a'| |b'|.
 // Per 1-D transform of length n (a 2-D transform is two of them):
 //   radix-2/4 codelets (fft_inreg.hpp; tile kernels and 128x128): F = I = eta log2 n, eta = 6.66 per radix-2 level
@@ -76,7 +76,7 @@ struct PassParams {
 //   two-factor mixed-radix transforms (fft_mixed.hpp, radix_pass: n = n1 n2, direct small DFTs of radix r <= 8, each
 //       (r + 3) sqrt(r) u normwise, + 4 u for the twiddle between them): F = I <= 64 for every pair;
 //   plain O(n^2) DFTs (first-generation generic kernel): componentwise (n + 3) u sum |x|: I = n + 3, F = (n + 3) sqrt(n).
-// 64 x 64: Gamma = 246 u = 1.47e-5 (measured over tools/research/exact_band.py's families and its adversarial search: <= 8e-7).
+// 64 x 64: Gamma = 247 u = 1.47e-5 (measured over tools/research/exact_band.py's families and its adversarial search: <= 8e-7).
 // The locating pass forms E+ from the exact integer window sums (sum a, sum a^2: v_sad_u8 / v_dot4_u32_u8 on the bytes it
 // staged) and uses band = 2 Gamma (1 + 1/16) E+ -- the 1/16 covers the float32 rounding of E+ itself and of the band
 // comparisons.
@@ -89,7 +89,7 @@ inline double exact_gamma_u(int ws, int kind) {       // Gamma in units of u = 2
     rt += 1.0;                                         // >= sqrt(ws)
     const double f1 = kind == EXACT_FFT_PLAIN ? (ws + 3) * rt : (kind == EXACT_FFT_MIXED ? 64.0 : lg * EXACT_ETA);
     const double i1 = kind == EXACT_FFT_PLAIN ? (double)(ws + 3) : f1;
-    return 2.0 * (2.0 * f1 + 1.0) + 4.0 + 2.0 * i1;
+    return 2.0 * (2.0 * f1 + 1.0) + 5.0 + 2.0 * i1;
 }
 inline float exact_band_coef(int ws, int kind = EXACT_FFT_RADIX2) {
     return (float)(2.0 * exact_gamma_u(ws, kind) * (1.0 + 1.0 / 16) * 5.9604644775390625e-08);
