@@ -16,13 +16,14 @@ ap.add_argument("--kind", default="wavy")
 ap.add_argument("--noise", type=float, default=0.0)
 ap.add_argument("--width", type=int, default=0, help="frame width when it differs from --size (row-pitch experiments)")
 ap.add_argument("--precision", default="fast", choices=("fast", "f64", "reference", "exact"))
+ap.add_argument("--scale", type=float, default=2.0, help="multipass_scale (window size of pass p+1 = int(ws_p // scale))")
 a = ap.parse_args()
 H = a.size
 W = a.width or a.size
 A0, B0 = synth.make_batch(a.distinct, H, W, device="cuda", kind=a.kind, noise=a.noise)
 A = A0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
 B = B0.repeat((a.batch + a.distinct - 1) // a.distinct, 1, 1)[:a.batch].contiguous()
-plan = engine.Plan(H, W, a.ws, a.ws // 2, n_pass=a.passes, mode=a.mode, max_batch=a.batch, precision=a.precision)
+plan = engine.Plan(H, W, a.ws, a.ws // 2, n_pass=a.passes, mode=a.mode, pass_scale=a.scale, max_batch=a.batch, precision=a.precision)
 out = plan.run(A, B)
 torch.cuda.synchronize()
 for p in range(a.passes):
@@ -45,7 +46,7 @@ tm, n = plan.get_timing()
 print("per-kernel ms per batch:", {k: round(v, 3) for k, v in tm.items()}, " us/pair:",
       {k: round(v / a.batch * 1000, 1) for k, v in tm.items()})
 u, v, inv = out
-if a.precision == "exact" and a.ws in (32, 64, 128):
+if plan.exact_capable():
     print("exact pass 1, ms per batch:", {k: round(v, 3) for k, v in plan.exact_timing().items()})
     n_fb = plan.exact_fallbacks()
     n_w = a.batch * plan.geometry[0][2] * plan.geometry[0][3]

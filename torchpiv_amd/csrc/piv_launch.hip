@@ -32,7 +32,7 @@ hipError_t launch_xcorr_cand_ws16(const PassParams& p, int n_cu, hipStream_t str
 hipError_t launch_xcorr_cand_ws32(const PassParams& p, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_cand_ws64(const PassParams& p, int n_cu, hipStream_t stream);
 hipError_t launch_xcorr_cand_ws128(const PassParams& p, int n_cu, hipStream_t stream);      // xcorr_big.hpp
-hipError_t launch_exact_refine(const PassParams& p, hipStream_t stream);                    // xcorr_exact.hip
+hipError_t launch_exact_refine(const PassParams& p, int n_cu, hipStream_t stream);                    // xcorr_exact.hip
 bool exact_refine_size(int ws);                                                             // every even size 8 ... 128
 hipError_t launch_xcorr_f64_list(const PassParams& p, int n_cu, hipStream_t stream);        // xcorr_f64.hip
 
@@ -307,7 +307,7 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
         }
         if (e != hipSuccess) return e;
         mark(0);
-        e = launch_exact_refine(p, stream);
+        e = launch_exact_refine(p, n_cu, stream);
         if (e != hipSuccess) return e;
         mark(1);
         if (tile_size(p.ws) || p.ws == 128) {

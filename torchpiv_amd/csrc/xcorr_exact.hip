@@ -128,27 +128,48 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     uint32_t* const rows_b = parked[wslot];
     const int N = p.n_rows * p.n_cols;
     const long long total = (long long)p.batch * N;
-    // XCD-aware static order: workgroups b, b+8, ... share an XCD (and its L2) and cover one contiguous run of windows
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    // PERSISTENT (round 5): the grid is the resident set; workgroups b, b+8, ... share an XCD (and its L2) and walk one
+    // contiguous run of windows together, G::WINS windows per step.  The rows and the candidate record of the NEXT step are
+    // requested before the current one is evaluated: with one window per wavefront LIFETIME (round 4) the kernel was a chain
+    // of memory latencies and workgroup launches -- 1.26 ms per 1 016 064 windows for 0.35 ms worth of instruction issue.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (int)(gridDim.x >> 3);
     const long long chunk = (total + 7) / 8;
-    const long long in_chunk = (long long)slot * G::WINS + wslot;
-    const long long it_raw = (long long)xcd * chunk + in_chunk;
-    const bool valid = in_chunk < chunk && it_raw < total;
-    const long long it = valid ? it_raw : 0;
-
-    // ---- window rows: lane = row.  Issued together with the candidate record, IN FRONT of the decisions that depend on
-    //      it: the kernel is a chain of memory latencies (one window per wavefront lifetime), and the rows' addresses do not
-    //      depend on the record.  (The 0.1 % of windows that do not go load their rows for nothing: in-bounds, unused.)
-    const unsigned itu = (unsigned)it;                       // (total < 2^31: 32-bit divisions)
-    const int pair = (int)(itu / (unsigned)N), win = (int)(itu - (unsigned)pair * (unsigned)N);
+    const long long lo = (long long)xcd * chunk;
+    const long long hi = lo + chunk < total ? lo + chunk : total;
+    const long long stride = (long long)per_xcd * G::WINS;
     const int st = p.ws - p.ov;
-    const size_t off = (size_t)pair * p.H * p.W + (size_t)((win / p.n_cols) * st + row) * p.W + (size_t)(win % p.n_cols) * st;
-    uint32_t a[NDW], b[NDW];
-    load_dwords<NDW>(p.A + off, a);
-    load_dwords<NDW>(p.B + off, b);
-    const uint4 rec = p.cand[it];
     auto lo16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v & 0xffffu); };
     auto hi16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v >> 16); };
+    // window `itr` of this lane (clamped into the run: a slot past its end re-reads the last window and stores nothing)
+    auto fetch = [&](long long itr, uint32_t (&a_)[NDW], uint32_t (&b_)[NDW], uint4& rec_) TPIV_LAMBDA_INLINE {
+        const unsigned itu = (unsigned)(itr < hi ? itr : hi - 1);        // (total < 2^31: 32-bit divisions)
+        const int pair = (int)(itu / (unsigned)N), win = (int)(itu - (unsigned)pair * (unsigned)N);
+        const size_t off = (size_t)pair * p.H * p.W + (size_t)((win / p.n_cols) * st + row) * p.W + (size_t)(win % p.n_cols) * st;
+        load_dwords<NDW>(p.A + off, a_);
+        load_dwords<NDW>(p.B + off, b_);
+        rec_ = p.cand[itu];
+    };
+    long long base = lo + (long long)slot * G::WINS;         // first window of the workgroup's step
+    if (base >= hi) return;
+    uint32_t a[NDW], b[NDW];
+    uint4 rec;
+    fetch(base + wslot, a, b, rec);
+    for (; base < hi; base += stride) {
+    const long long it_raw = base + wslot;
+    const bool valid = it_raw < hi;
+    const long long it = valid ? it_raw : hi - 1;
+    // ---- the next step's rows and record: in flight while this step is evaluated
+    uint32_t na[NDW], nb[NDW];
+    uint4 nrec;
+    fetch(base + stride + wslot, na, nb, nrec);
+    auto advance = [&]() TPIV_LAMBDA_INLINE {
+#pragma unroll
+        for (int i = 0; i < NDW; ++i) {
+            a[i] = na[i];
+            b[i] = nb[i];
+        }
+        rec = nrec;
+    };
     const int m = valid ? lo16(rec.x) : -3;
     double* const out = reinterpret_cast<double*>(p.peak_raw) + (size_t)it * 8;
     const bool writer = part == 0;                           // the wavefront of a window that stores its results
@@ -158,7 +179,10 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     if (m == -1) to_f64_kernel();
     if (m == -2 && r0 < 8 && writer) out[r0] = r0 == 6 ? 0.0 : 1.0;      // zero-mean window (B:513: NaN map): finalize_kernel looks at the flag [7] only
     const bool go = m >= 0;
-    if (__ballot(go) == 0ull) return;                        // (128x128: the same decision in both wavefronts of the window)
+    if (__ballot(go) == 0ull) {                              // (128x128: the same decision in both wavefronts of the window)
+        advance();
+        continue;
+    }
 
     // ---- the cells: lane j of the window holds flat index q_j (fftshift layout) or -1
     int q = -1;
@@ -276,6 +300,10 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     S = r0 < XCELLS ? S : 0u;
 
     decide_and_store(p, rec, r0, go, writer, q >= 0, m, S, sa, sb, (double)KD, out, it);
+    if constexpr (G::PARTS == 2) __syncthreads();       // (`joined` and the parked rows are free for the next step)
+    else wave_sync();
+    advance();
+    }
 }
 
 // ---- any even window size up to 128: lane = CELL.  Both windows sit in LDS (frame a's rows as zero-padded dwords,
@@ -433,12 +461,26 @@ __global__ __launch_bounds__(64) void xcorr_exact_refine_any_kernel(PassParams p
 
 // cand / fb_list / fb_count are set by the caller (launch_xcorr); the records go where the float64 kernel puts them
 template <int W>
-static hipError_t launch_refine(const PassParams& p, hipStream_t stream) {
+static hipError_t launch_refine(const PassParams& p, int n_cu, hipStream_t stream) {
     using G = XGeo<W>;
     const long long total = (long long)p.batch * p.n_rows * p.n_cols;
     const long long chunk = (total + 7) / 8;
     const long long slots = (chunk + G::WINS - 1) / G::WINS;
-    hipLaunchKernelGGL((xcorr_exact_refine_kernel<W>), dim3((unsigned)(slots * 8)), dim3(64 * G::WAVES), 0, stream, p);
+    // the resident set: LDS (parked rows) and wavefront slots per CU; TPIV_REFINE_PER_CU overrides for experiments
+    static const int per_cu_env = [] {
+        const char* e = getenv("TPIV_REFINE_PER_CU");
+        return e ? atoi(e) : 0;
+    }();
+    const size_t lds = sizeof(uint32_t) * G::WINS * W * G::XP + 128;
+    int per_cu = (int)((160 * 1024) / lds);
+    constexpr int WPS = W == 128 ? 2 : (W == 64 ? 4 : (W == 32 ? 5 : 8));    // wavefronts per SIMD by the VGPR count (188 / 107 / 82 / 61)
+    const int by_waves = 4 * WPS / G::WAVES;
+    per_cu = per_cu > by_waves ? by_waves : per_cu;
+    if (per_cu_env > 0) per_cu = per_cu_env;
+    long long blocks = (long long)(n_cu > 0 ? n_cu : 256) * per_cu / 8 * 8;
+    if (blocks > slots * 8) blocks = slots * 8;
+    if (blocks < 8) blocks = 8;
+    hipLaunchKernelGGL((xcorr_exact_refine_kernel<W>), dim3((unsigned)blocks), dim3(64 * G::WAVES), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -459,16 +501,16 @@ static hipError_t launch_refine_any(const PassParams& p, hipStream_t stream) {
 // B:255 -- not a plain circular correlation --, larger ones do not fit the refinement's LDS: both run the float64 kernels)
 bool exact_refine_size(int ws) { return ws >= 8 && ws <= 128 && (ws & 1) == 0; }
 
-hipError_t launch_exact_refine(const PassParams& p, hipStream_t stream) {
+hipError_t launch_exact_refine(const PassParams& p, int n_cu, hipStream_t stream) {
     const long long total = (long long)p.batch * p.n_rows * p.n_cols;
     if (total <= 0 || total >= (1ll << 31) || p.cand == nullptr || p.fb_list == nullptr || p.fb_count == nullptr ||
         !exact_refine_size(p.ws))
         return hipErrorInvalidValue;
     switch (p.ws) {
-        case 16: return launch_refine<16>(p, stream);
-        case 32: return launch_refine<32>(p, stream);
-        case 64: return launch_refine<64>(p, stream);
-        case 128: return launch_refine<128>(p, stream);
+        case 16: return launch_refine<16>(p, n_cu, stream);
+        case 32: return launch_refine<32>(p, n_cu, stream);
+        case 64: return launch_refine<64>(p, n_cu, stream);
+        case 128: return launch_refine<128>(p, n_cu, stream);
         default: return p.ws <= 32 ? launch_refine_any<4>(p, stream) : launch_refine_any<1>(p, stream);
     }
 }
