@@ -41,6 +41,13 @@ struct XGeo {
     static constexpr int WAVES = W == 128 ? 2 : 4;           // wavefronts per workgroup
     static constexpr int WINS = WAVES * WPW / PARTS;         // windows per workgroup: 8 / 4 / 1
     static constexpr int KD = W * W;
+    // rows are LOADED by the window's lanes together (W >= 32): 16-byte chunks, chunk ci = row * P16 + part, lane t of the
+    // window takes chunks t, t + LW, ... -- consecutive lanes read consecutive pieces of a row
+    static constexpr bool COOP = W >= 32;
+    static constexpr int P16 = W / 16;                       // 16-byte chunks per row = chunks per lane
+    static constexpr int LW = GROUP * PARTS;                 // lanes per window
+    static constexpr int AP = NDW + 4;                       // dwords per row of the frame-a hand-over tile (16-byte reads, all banks)
+    static_assert(!COOP || (W * AP <= W * XP && (LW * P16) == W * P16), "the hand-over tile lives in the parked rows' memory");
 };
 constexpr int XCELLS = 5 + EXACT_MAX_SECOND + EXACT_MAX_MIN;      // cells a window can ask for
 
@@ -117,7 +124,7 @@ template <int W>
 __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel(PassParams p) {
     using G = XGeo<W>;
     constexpr int NDW = G::NDW, XP = G::XP, KD = G::KD;
-    __shared__ uint32_t parked[G::WINS][W * XP];
+    __shared__ __attribute__((aligned(16))) uint32_t parked[G::WINS][W * XP];
     __shared__ unsigned joined[2][16];                       // 128x128: per wavefront the partial S of 12 cells + 4 window sums
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = (int)(threadIdx.x & 63);
@@ -128,48 +135,46 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     uint32_t* const rows_b = parked[wslot];
     const int N = p.n_rows * p.n_cols;
     const long long total = (long long)p.batch * N;
-    // PERSISTENT (round 5): the grid is the resident set; workgroups b, b+8, ... share an XCD (and its L2) and walk one
-    // contiguous run of windows together, G::WINS windows per step.  The rows and the candidate record of the NEXT step are
-    // requested before the current one is evaluated: with one window per wavefront LIFETIME (round 4) the kernel was a chain
-    // of memory latencies and workgroup launches -- 1.26 ms per 1 016 064 windows for 0.35 ms worth of instruction issue.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = (int)(gridDim.x >> 3);
+    // XCD-aware static order: workgroups b, b+8, ... share an XCD (and its L2) and cover one contiguous run of windows
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const long long chunk = (total + 7) / 8;
-    const long long lo = (long long)xcd * chunk;
-    const long long hi = lo + chunk < total ? lo + chunk : total;
-    const long long stride = (long long)per_xcd * G::WINS;
+    const long long in_chunk = (long long)slot * G::WINS + wslot;
+    const long long it_raw = (long long)xcd * chunk + in_chunk;
+    const bool valid = in_chunk < chunk && it_raw < total;
+    const long long it = valid ? it_raw : 0;
+
+    // ---- window rows.  Issued together with the candidate record, IN FRONT of the decisions that depend on it: the kernel
+    //      is a chain of memory latencies (one window per wavefront lifetime), and the addresses do not depend on the record.
+    //      (The 0.1 % of windows that do not go load their rows for nothing: in-bounds, unused.)
+    // Round 5: W >= 32 loads by CHUNKS.  With lane = row every load instruction touched 64 different cache lines -- 512 tag
+    // look-ups of the vector L1 per 64x64 window, one per CU cycle: 1.0 of the kernel's 1.26 ms per 1 016 064 windows was that
+    // (a persistent form with the next window's rows prefetched was SLOWER, 1.6 ms: latency was never the limit).  Now four
+    // consecutive lanes cover one 64-byte row (16 rows per instruction: a quarter of the look-ups); frame b's chunks go
+    // straight to their parked place, frame a's pass through a hand-over tile in the same LDS (before b is parked) and come
+    // back as the lane's row.
+    const unsigned itu = (unsigned)it;                       // (total < 2^31: 32-bit divisions)
+    const int pair = (int)(itu / (unsigned)N), win = (int)(itu - (unsigned)pair * (unsigned)N);
     const int st = p.ws - p.ov;
+    const size_t off0 = (size_t)pair * p.H * p.W + (size_t)((win / p.n_cols) * st) * p.W + (size_t)(win % p.n_cols) * st;
+    uint32_t a[NDW], b[NDW];
+    uint32_t ca[G::COOP ? G::P16 : 1][4], cb[G::COOP ? G::P16 : 1][4];
+    const int tw = r0 + 64 * part;                           // lane inside the window
+    if constexpr (G::COOP) {
+#pragma unroll
+        for (int k = 0; k < G::P16; ++k) {
+            const int ci = tw + G::LW * k, j = ci / G::P16, pt = ci % G::P16;
+            const size_t o_ = off0 + (size_t)j * p.W + 16 * pt;
+            load_dwords<4>(p.A + o_, ca[k]);
+            load_dwords<4>(p.B + o_, cb[k]);
+        }
+    } else {
+        const size_t off = off0 + (size_t)row * p.W;
+        load_dwords<NDW>(p.A + off, a);
+        load_dwords<NDW>(p.B + off, b);
+    }
+    const uint4 rec = p.cand[it];
     auto lo16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v & 0xffffu); };
     auto hi16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v >> 16); };
-    // window `itr` of this lane (clamped into the run: a slot past its end re-reads the last window and stores nothing)
-    auto fetch = [&](long long itr, uint32_t (&a_)[NDW], uint32_t (&b_)[NDW], uint4& rec_) TPIV_LAMBDA_INLINE {
-        const unsigned itu = (unsigned)(itr < hi ? itr : hi - 1);        // (total < 2^31: 32-bit divisions)
-        const int pair = (int)(itu / (unsigned)N), win = (int)(itu - (unsigned)pair * (unsigned)N);
-        const size_t off = (size_t)pair * p.H * p.W + (size_t)((win / p.n_cols) * st + row) * p.W + (size_t)(win % p.n_cols) * st;
-        load_dwords<NDW>(p.A + off, a_);
-        load_dwords<NDW>(p.B + off, b_);
-        rec_ = p.cand[itu];
-    };
-    long long base = lo + (long long)slot * G::WINS;         // first window of the workgroup's step
-    if (base >= hi) return;
-    uint32_t a[NDW], b[NDW];
-    uint4 rec;
-    fetch(base + wslot, a, b, rec);
-    for (; base < hi; base += stride) {
-    const long long it_raw = base + wslot;
-    const bool valid = it_raw < hi;
-    const long long it = valid ? it_raw : hi - 1;
-    // ---- the next step's rows and record: in flight while this step is evaluated
-    uint32_t na[NDW], nb[NDW];
-    uint4 nrec;
-    fetch(base + stride + wslot, na, nb, nrec);
-    auto advance = [&]() TPIV_LAMBDA_INLINE {
-#pragma unroll
-        for (int i = 0; i < NDW; ++i) {
-            a[i] = na[i];
-            b[i] = nb[i];
-        }
-        rec = nrec;
-    };
     const int m = valid ? lo16(rec.x) : -3;
     double* const out = reinterpret_cast<double*>(p.peak_raw) + (size_t)it * 8;
     const bool writer = part == 0;                           // the wavefront of a window that stores its results
@@ -179,10 +184,7 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     if (m == -1) to_f64_kernel();
     if (m == -2 && r0 < 8 && writer) out[r0] = r0 == 6 ? 0.0 : 1.0;      // zero-mean window (B:513: NaN map): finalize_kernel looks at the flag [7] only
     const bool go = m >= 0;
-    if (__ballot(go) == 0ull) {                              // (128x128: the same decision in both wavefronts of the window)
-        advance();
-        continue;
-    }
+    if (__ballot(go) == 0ull) return;                        // (128x128: the same decision in both wavefronts of the window)
 
     // ---- the cells: lane j of the window holds flat index q_j (fftshift layout) or -1
     int q = -1;
@@ -210,15 +212,48 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     unsigned P[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) P[k] = 0u;
+    auto lds_sync = [&]() TPIV_LAMBDA_INLINE {
+        if constexpr (G::PARTS == 2) __syncthreads();   // (128x128: both wavefronts of the window)
+        else wave_sync();
+    };
+    if constexpr (G::COOP) {
+        // frame a: chunks -> hand-over tile (pitch AP dwords: 16-byte reads of 16 lanes cover all banks) -> the lane's row
+        uint4* const ta = reinterpret_cast<uint4*>(rows_b);
 #pragma unroll
-    for (int i = 0; i < NDW; ++i) {
-        P[12] = __builtin_amdgcn_sad_u8(a[i], 0u, P[12]);
-        P[13] = __builtin_amdgcn_sad_u8(b[i], 0u, P[13]);
-        rows_b[row * XP + i] = b[i];
-        rows_b[row * XP + NDW + i] = b[i];
+        for (int k = 0; k < G::P16; ++k) {
+            const int ci = tw + G::LW * k, j = ci / G::P16, pt = ci % G::P16;
+            ta[j * (G::AP / 4) + pt] = make_uint4(ca[k][0], ca[k][1], ca[k][2], ca[k][3]);
+        }
+        lds_sync();
+#pragma unroll
+        for (int k = 0; k < NDW / 4; ++k) {
+            const uint4 t = ta[row * (G::AP / 4) + k];
+            a[4 * k] = t.x, a[4 * k + 1] = t.y, a[4 * k + 2] = t.z, a[4 * k + 3] = t.w;
+        }
+        lds_sync();
+        // frame b: every chunk twice into its parked row (odd pitch: single dwords)
+#pragma unroll
+        for (int k = 0; k < G::P16; ++k) {
+            const int ci = tw + G::LW * k, j = ci / G::P16, pt = ci % G::P16;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                P[13] = __builtin_amdgcn_sad_u8(cb[k][c], 0u, P[13]);
+                rows_b[j * XP + 4 * pt + c] = cb[k][c];
+                rows_b[j * XP + NDW + 4 * pt + c] = cb[k][c];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NDW; ++i) P[12] = __builtin_amdgcn_sad_u8(a[i], 0u, P[12]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NDW; ++i) {
+            P[12] = __builtin_amdgcn_sad_u8(a[i], 0u, P[12]);
+            P[13] = __builtin_amdgcn_sad_u8(b[i], 0u, P[13]);
+            rows_b[row * XP + i] = b[i];
+            rows_b[row * XP + NDW + i] = b[i];
+        }
     }
-    if constexpr (G::PARTS == 2) __syncthreads();       // the other wavefront's rows are parked
-    else wave_sync();
+    lds_sync();                                         // the rows are parked
 
     // ---- S at every requested cell
     static_for<0, XCELLS>([&](auto cc) TPIV_LAMBDA_INLINE {
@@ -300,9 +335,123 @@ __global__ __launch_bounds__(64 * XGeo<W>::WAVES) void xcorr_exact_refine_kernel
     S = r0 < XCELLS ? S : 0u;
 
     decide_and_store(p, rec, r0, go, writer, q >= 0, m, S, sa, sb, (double)KD, out, it);
-    if constexpr (G::PARTS == 2) __syncthreads();       // (`joined` and the parked rows are free for the next step)
-    else wave_sync();
-    advance();
+}
+
+// ---- 8x8 and 16x16 windows: lane = WINDOW (round 5).  A first pass of 8-pixel windows has a million windows per 4096^2
+// pair; with a wavefront per four windows the refinement was bound by workgroup launches (3.8 ms per 4.2 M windows against
+// 0.6 ms for the locating pass).  Here a lane owns a whole window: frame a's rows in registers (W x W / 4 dwords), frame b's
+// rows parked twice over in the lane's own LDS strip (odd strip pitch: the lanes' same-offset reads hit different banks), every
+// cell W x (W / 4) dot products with compile-time register indices, every decision per lane -- no cross-lane traffic at all.
+template <int W>
+struct SGeo {
+    static constexpr int NDW = W / 4, XP = 2 * NDW + 1, STRIP = (W * XP) | 1, KD = W * W;
+};
+template <int W>
+__global__ __launch_bounds__(64) void xcorr_exact_refine_small_kernel(PassParams p) {
+    using G = SGeo<W>;
+    constexpr int NDW = G::NDW, XP = G::XP, KD = G::KD;
+    __shared__ uint32_t strips[64 * G::STRIP];
+    const int lane = (int)threadIdx.x;
+    uint32_t* const mine = strips + lane * G::STRIP;
+    const int N = p.n_rows * p.n_cols;
+    const long long total = (long long)p.batch * N;
+    // XCD-aware static order: workgroups b, b+8, ... share an XCD and cover one contiguous run of windows, 64 per workgroup
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const long long chunk = (total + 7) / 8;
+    const long long in_chunk = (long long)slot * 64 + lane;
+    const long long it_raw = (long long)xcd * chunk + in_chunk;
+    const bool valid = in_chunk < chunk && it_raw < total;
+    const long long it = valid ? it_raw : 0;
+    const unsigned itu = (unsigned)it;
+    const int pair = (int)(itu / (unsigned)N), win = (int)(itu - (unsigned)pair * (unsigned)N);
+    const int st = p.ws - p.ov;
+    const size_t off = (size_t)pair * p.H * p.W + (size_t)((win / p.n_cols) * st) * p.W + (size_t)(win % p.n_cols) * st;
+    const uint4 rec = p.cand[it];
+    uint32_t a[W][NDW];
+    unsigned sa = 0u, sb = 0u;
+#pragma unroll
+    for (int y = 0; y < W; ++y) {
+        uint32_t b[NDW];
+        load_dwords<NDW>(p.A + off + (size_t)y * p.W, a[y]);
+        load_dwords<NDW>(p.B + off + (size_t)y * p.W, b);
+#pragma unroll
+        for (int i = 0; i < NDW; ++i) {
+            sa = __builtin_amdgcn_sad_u8(a[y][i], 0u, sa);
+            sb = __builtin_amdgcn_sad_u8(b[i], 0u, sb);
+            mine[y * XP + i] = b[i];
+            mine[y * XP + NDW + i] = b[i];
+        }
+    }
+    auto lo16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v & 0xffffu); };
+    auto hi16 = [](unsigned v) TPIV_LAMBDA_INLINE { return (int)(short)(v >> 16); };
+    const int m = valid ? lo16(rec.x) : -3;
+    double* const out = reinterpret_cast<double*>(p.peak_raw) + (size_t)it * 8;
+    if (m == -1) p.fb_list[atomicAdd(p.fb_count, 1u)] = (int)it;
+    if (m == -2) {                                           // zero-mean window (B:513): finalize_kernel looks at the flag [7] only
+#pragma unroll
+        for (int r = 0; r < 8; ++r) out[r] = r == 6 ? 0.0 : 1.0;
+    }
+    const bool go = m >= 0;
+    if (__ballot(go) == 0ull) return;
+    int q[XCELLS];
+    {
+        int left = m + 1, right = m - 1, top = m + W, bot = m - W;      // B:385-392
+        if (left >= KD - 1) left = m;
+        if (right <= 0) right = m;
+        if (top >= KD - 1) top = m;
+        if (bot <= 0) bot = m;
+        q[0] = m, q[1] = left, q[2] = right, q[3] = top, q[4] = bot;
+        q[5] = hi16(rec.x), q[6] = lo16(rec.y), q[7] = hi16(rec.y);
+        q[8] = lo16(rec.z), q[9] = hi16(rec.z), q[10] = lo16(rec.w), q[11] = hi16(rec.w);
+    }
+    wave_sync();                                             // (a lane reads its own strip only; program order)
+    unsigned S[XCELLS];
+    static_for<0, XCELLS>([&](auto cc) TPIV_LAMBDA_INLINE {
+        constexpr int c = decltype(cc)::value;
+        const bool on = go && q[c] >= 0;
+        unsigned acc = 0u;
+        if (__ballot(on) != 0ull) {
+            const int qq = on ? q[c] : 0;
+            const int dy = qq / W - W / 2, bx = (qq % W - W / 2) & (W - 1);
+            const unsigned sh = (unsigned)(bx & 3);
+            const uint32_t* const src = mine + (bx >> 2);
+#pragma unroll
+            for (int y = 0; y < W; ++y) {
+                const uint32_t* rowp = src + ((y + dy) & (W - 1)) * XP;
+                uint32_t w[NDW + 1];
+#pragma unroll
+                for (int i = 0; i <= NDW; ++i) w[i] = rowp[i];
+#pragma unroll
+                for (int i = 0; i < NDW; ++i) acc = __builtin_amdgcn_udot4(a[y][i], __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh), acc, false);
+            }
+        }
+        S[c] = on ? acc : 0u;
+    });
+    // ---- the decisions on the exact values (decide_and_store, per lane)
+    constexpr int S0 = 5, N0 = 5 + EXACT_MAX_SECOND;
+    unsigned s_min = 0xffffffffu, s_low = 0xffffffffu, s_top = 0u, s_second = 0u, n_second = 0u;
+#pragma unroll
+    for (int c = 0; c < XCELLS; ++c) {
+        const bool have = q[c] >= 0;
+        if (c >= N0) s_min = (have && S[c] < s_min) ? S[c] : s_min;
+        s_low = (have && S[c] < s_low) ? S[c] : s_low;
+        if (c < N0) s_top = (have && S[c] > s_top) ? S[c] : s_top;
+        if (c >= S0 && c < N0) {
+            s_second = (have && S[c] > s_second) ? S[c] : s_second;
+            n_second += have ? 1u : 0u;
+        }
+    }
+    const unsigned s_m = S[0];
+    const bool min_overflow = hi16(rec.w) == -2;
+    const bool redo = s_top > s_m || s_low < s_min || s_min == 0xffffffffu || sa == 0u || sb == 0u || (min_overflow && s_min != 0u);
+    if (go && redo) p.fb_list[atomicAdd(p.fb_count, 1u)] = (int)it;
+    if (go && !redo) {
+        const double scale = ((double)KD * (double)KD) / ((double)sa * (double)sb);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) out[r] = __fma_rn((double)(S[r] - s_min), scale, 1e-7);
+        out[5] = n_second == 0u ? 0.0 : __fma_rn((double)(s_second - s_min), scale, 1e-7);
+        out[6] = (double)m;
+        out[7] = 0.0;
     }
 }
 
@@ -461,26 +610,21 @@ __global__ __launch_bounds__(64) void xcorr_exact_refine_any_kernel(PassParams p
 
 // cand / fb_list / fb_count are set by the caller (launch_xcorr); the records go where the float64 kernel puts them
 template <int W>
-static hipError_t launch_refine(const PassParams& p, int n_cu, hipStream_t stream) {
+static hipError_t launch_refine(const PassParams& p, hipStream_t stream) {
     using G = XGeo<W>;
     const long long total = (long long)p.batch * p.n_rows * p.n_cols;
     const long long chunk = (total + 7) / 8;
     const long long slots = (chunk + G::WINS - 1) / G::WINS;
-    // the resident set: LDS (parked rows) and wavefront slots per CU; TPIV_REFINE_PER_CU overrides for experiments
-    static const int per_cu_env = [] {
-        const char* e = getenv("TPIV_REFINE_PER_CU");
-        return e ? atoi(e) : 0;
-    }();
-    const size_t lds = sizeof(uint32_t) * G::WINS * W * G::XP + 128;
-    int per_cu = (int)((160 * 1024) / lds);
-    constexpr int WPS = W == 128 ? 2 : (W == 64 ? 4 : (W == 32 ? 5 : 8));    // wavefronts per SIMD by the VGPR count (188 / 107 / 82 / 61)
-    const int by_waves = 4 * WPS / G::WAVES;
-    per_cu = per_cu > by_waves ? by_waves : per_cu;
-    if (per_cu_env > 0) per_cu = per_cu_env;
-    long long blocks = (long long)(n_cu > 0 ? n_cu : 256) * per_cu / 8 * 8;
-    if (blocks > slots * 8) blocks = slots * 8;
-    if (blocks < 8) blocks = 8;
-    hipLaunchKernelGGL((xcorr_exact_refine_kernel<W>), dim3((unsigned)blocks), dim3(64 * G::WAVES), 0, stream, p);
+    hipLaunchKernelGGL((xcorr_exact_refine_kernel<W>), dim3((unsigned)(slots * 8)), dim3(64 * G::WAVES), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <int W>
+static hipError_t launch_refine_small(const PassParams& p, hipStream_t stream) {
+    const long long total = (long long)p.batch * p.n_rows * p.n_cols;
+    const long long chunk = (total + 7) / 8;
+    const long long slots = (chunk + 63) / 64;
+    hipLaunchKernelGGL((xcorr_exact_refine_small_kernel<W>), dim3((unsigned)(slots * 8)), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -506,11 +650,16 @@ hipError_t launch_exact_refine(const PassParams& p, int n_cu, hipStream_t stream
     if (total <= 0 || total >= (1ll << 31) || p.cand == nullptr || p.fb_list == nullptr || p.fb_count == nullptr ||
         !exact_refine_size(p.ws))
         return hipErrorInvalidValue;
+    // (TPIV_REFINE_SMALL=0: the lane-per-row / lane-per-cell kernels for 16 / 8 as well -- A/B runs)
+    static const bool small_on = [] { const char* e = getenv("TPIV_REFINE_SMALL"); return !(e && e[0] == '0'); }();
     switch (p.ws) {
-        case 16: return launch_refine<16>(p, n_cu, stream);
-        case 32: return launch_refine<32>(p, n_cu, stream);
-        case 64: return launch_refine<64>(p, n_cu, stream);
-        case 128: return launch_refine<128>(p, n_cu, stream);
+        case 8:
+            if (small_on) return launch_refine_small<8>(p, stream);
+            return launch_refine_any<4>(p, stream);
+        case 16: return small_on ? launch_refine_small<16>(p, stream) : launch_refine<16>(p, stream);
+        case 32: return launch_refine<32>(p, stream);
+        case 64: return launch_refine<64>(p, stream);
+        case 128: return launch_refine<128>(p, stream);
         default: return p.ws <= 32 ? launch_refine_any<4>(p, stream) : launch_refine_any<1>(p, stream);
     }
 }
