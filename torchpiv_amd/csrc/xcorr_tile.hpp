@@ -476,6 +476,19 @@ struct ItemGeom {
     size_t fidx;
 };
 
+// first pass: rows loaded in 16-byte chunks by the window's lanes together (issue_rows / convert_rows, MODE_PASS1).
+// OFF: measured in round 5 (same box, A B A B): locating pass of configs[1] 6.86 / 6.90 ms without, 7.05 / 7.16 ms with; 32x32
+// (configs[3]) 1.58 against 1.61 ms -- the hand-over through the tile costs more than the address unit saves (the shifted
+// CWS passes, whose patches are (WS + 1)^2 and fetched twice per row otherwise, keep their chunk loads: CoopGeo).
+#ifndef TPIV_COOP1
+#define TPIV_COOP1 0
+#endif
+template <int WS>
+struct Coop1 {
+    static constexpr bool ON = TPIV_COOP1 && (WS == 64 || WS == 32);
+    static constexpr int P16 = WS / 16;                       // chunks per row = chunks per lane
+    static constexpr int PITCH4 = WS / 16 + 1;                // hand-over tile: 16-byte units per row (16-byte reads cover all banks)
+};
 template <int WS, int MODE>
 struct RawRows;
 template <int WS>
@@ -649,8 +662,25 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
     const uint8_t* __restrict__ fb = p.B + (size_t)g.pair * HW;
     const long long base = (long long)(g.y0 + r) * p.W + g.x0;
     if constexpr (MODE == MODE_PASS1) {
-        load_dwords<WS / 4>(fa + base, raw.a);
-        load_dwords<WS / 4>(fb + base, raw.b);
+        if constexpr (Coop1<WS>::ON) {
+            // rows LOADED by the window's lanes together (round 5): with lane = row every load instruction touches WS cache
+            // lines and the CU's address unit takes them one by one -- the stamps put 18 % of the 64x64 iteration on the issue
+            // of these eight loads.  Chunk ci = row * P16 + part of 16 bytes, lane r takes chunks r, r + WS, ...: consecutive
+            // lanes read consecutive pieces of a row (16 rows per instruction for 64-pixel rows); convert_rows hands the
+            // chunks over through the (idle) transposition tile and every lane gets its row back.
+            using C1 = Coop1<WS>;
+            const unsigned o0 = (unsigned)(g.y0 * p.W + g.x0);
+#pragma unroll
+            for (int k = 0; k < C1::P16; ++k) {
+                const int ci = r + WS * k, j = ci / C1::P16, part = ci % C1::P16;
+                const unsigned o_ = o0 + (unsigned)(j * p.W + 16 * part);
+                load_dwords<4>(fa + o_, *reinterpret_cast<uint32_t(*)[4]>(&raw.a[4 * k]));
+                load_dwords<4>(fb + o_, *reinterpret_cast<uint32_t(*)[4]>(&raw.b[4 * k]));
+            }
+        } else {
+            load_dwords<WS / 4>(fa + base, raw.a);
+            load_dwords<WS / 4>(fb + base, raw.b);
+        }
     } else if constexpr (MODE == MODE_DWS) {
         // integer shift on the FLAT index (B:213-215): a at idx - (vy*W + vx), b at idx + (...)
         const long long sh = (long long)vy * p.W + (long long)vx;
@@ -802,6 +832,28 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
     // needs about 60), so they are fully rolled there.
     static constexpr int UNR_DWS = WS <= 16 ? 1 : 4, UNR_CWS = WS <= 16 ? 1 : 2;
     if constexpr (MODE == MODE_PASS1) {
+        if constexpr (Coop1<WS>::ON) {
+            // chunks -> tile -> the lane's own row, one frame at a time (the tile is idle until the first transposition)
+            using C1 = Coop1<WS>;
+            uint4* const t4 = reinterpret_cast<uint4*>(lds) + (lane / WS) * (WS * C1::PITCH4);
+            auto hand_over = [&](uint32_t (&d)[WS / 4]) TPIV_LAMBDA_INLINE {
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < C1::P16; ++k) {
+                    const int ci = r + WS * k, j = ci / C1::P16, part = ci % C1::P16;
+                    t4[j * C1::PITCH4 + part] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+                }
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < C1::P16; ++k) {
+                    const uint4 v = t4[r * C1::PITCH4 + k];
+                    d[4 * k] = v.x, d[4 * k + 1] = v.y, d[4 * k + 2] = v.z, d[4 * k + 3] = v.w;
+                }
+            };
+            hand_over(raw.a);
+            hand_over(raw.b);
+            wave_sync();
+        }
         unsigned ia = 0, ib = 0;
 #pragma unroll
         for (int q = 0; q < WS / 4; ++q) {
@@ -1391,7 +1443,7 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
                   "slow-path row buffer (shifted passes) must fit the tile LDS");
     constexpr int LDSF = (MODE == MODE_CWS && CoopGeo<WS>::ON && CoopGeo<WS>::LDS_FLOATS > G::LDS_FLOATS)
                              ? CoopGeo<WS>::LDS_FLOATS : G::LDS_FLOATS;
-    __shared__ float tile[LDSF];
+    __shared__ __attribute__((aligned(16))) float tile[LDSF];
 
     // 16x16 has registers to spare: its twiddle constants live in VGPRs (plain 4-byte VOP2 multiplies
     // instead of 8-byte literal forms and half-rate SGPR operands): 169 -> 158 us/pair
