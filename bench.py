@@ -280,7 +280,7 @@ def e2e_cases(n, workers, files=True, budget_s=150.0):
 
 
 def e2e_block(r, log, n, workers):
-    return {"unit": "pairs/s", "pairs_per_case": r.get("pairs_streamed", n), "distinct_pairs": n, "batch": 32, "fill_workers": workers, "precision": r.get("precision", "exact"),
+    return {"unit": "pairs/s", "pairs_per_case": r.get("pairs_streamed", n), "distinct_pairs": n, "batch": {"resident": r.get("resident_batch", 32), "files": r.get("files_batch", 32)}, "fill_workers": workers, "precision": r.get("precision", "exact"),
             "what": "generator end to end at 4 MP, wind=64 ov=32 2-pass CWS: passes + device post-validation + counted host "
                     "fallbacks + flip/scale + yield (ResidentPIV / OfflinePIV.batched)",
             "resident_clean_all_dropped": r.get("clean"), "resident_straight_runs": r.get("runs"),

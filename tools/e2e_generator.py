@@ -64,20 +64,23 @@ def rate3(make_gen, n, trials=3):
     return sorted(rs)[len(rs) // 2], k, [round(r_) for r_ in rs], cpu
 
 
-def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True, budget_s=None, precision="exact", reps=8):
+def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True, budget_s=None, precision="exact", reps=8,
+         resident_batch=64):
     """Rates in pairs/s per case; `files` adds the BMP cases (skipped once `budget_s` seconds are spent).  Every case
     streams n * reps pairs (the n distinct pairs `reps` times over: 128 pairs alone last some 20 ms, which measures the
     pipeline's fill and drain, not its rate); the file cases hard-link the n pairs' files under n * reps names."""
-    out = {"precision": precision, "pairs_streamed": n * reps}
+    # (resident frames: 64 pairs per launch -- tools/dev/e2e_batch.py, round 5: isolated spots 13.7 k pairs/s at 32, 14.2 k at 64,
+    #  13.1 k at 128; the file path is bound by the PCIe link at any batch size and keeps 32, the staging buffers' size)
+    out = {"precision": precision, "pairs_streamed": n * reps, "resident_batch": resident_batch, "files_batch": batch}
     order = list(range(n)) * reps
     t_start = time.perf_counter()
     for kind in ("clean", "runs", "spots"):
         A, B = make_frames(n, H, W, kind)
         piv = T.ResidentPIV(A, B, 64, 32, multipass=2, multipass_mode="CWS", precision=precision)
         piv.fill_workers = workers
-        rate(piv.batched(batch), n)                      # warm-up: plan creation
+        rate(piv.batched(resident_batch), n)             # warm-up: plan creation
         piv.reset_stats()
-        r, k, rs, cpu = rate3(lambda: piv.batched(batch, indices=order), n * reps)
+        r, k, rs, cpu = rate3(lambda: piv.batched(resident_batch, indices=order), n * reps)
         out[kind] = r
         out.setdefault("trials", {})[kind] = rs
         out.setdefault("host_cpu_s_per_pair", {})[kind] = cpu

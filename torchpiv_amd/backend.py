@@ -398,7 +398,10 @@ class OfflinePIV:
         false vectors' (decided on the device), finished on the device alone, sent to the host
         triangulation (and dropped there because Qhull refused the ring)."""
         self.stats = {"pairs": 0, "dropped_no_invalid": 0, "dropped_too_many": 0, "device_complete": 0,
-                      "host_fallback": 0, "dropped_by_qhull": 0}
+                      "host_fallback": 0, "dropped_by_qhull": 0,
+                      # host_fallback by hole class (SURVEY 8 f-1): pairs whose only undetermined cells are co-circular
+                      # diamonds (isolated invalid vectors: Qhull's tie-break decides), and pairs that hold a wider hole
+                      "host_fallback_diamonds_only": 0, "host_fallback_wide_holes": 0}
 
     fill_workers = 0         # > 0: the host triangulations of a batch run in that many worker processes
     pipeline_depth = 2       # batched() over files: launches in flight before a batch's results are collected
@@ -509,6 +512,8 @@ class OfflinePIV:
         st["dropped_no_invalid"] += int(no_ring.sum())
         st["dropped_too_many"] += int(too_many.sum())
         st["device_complete"] += int((keep & ~need_host).sum())
+        st["host_fallback_diamonds_only"] += int((need_host & (cnt[:, 3] == 0)).sum())
+        st["host_fallback_wide_holes"] += int((need_host & (cnt[:, 3] > 0)).sum())
         for _ in range(2 * int(too_many.sum())):                  # once for u, once for v (B:306, B:889-890)
             print(TOO_MANY_MSG)
         state = {"keep": keep, "need": np.flatnonzero(need_host), "host": host, "dev": keep_alive[0]}
@@ -550,37 +555,38 @@ class OfflinePIV:
             fu, fv = host["fu"].numpy(), host["fv"].numpy()
             uk, vk = (host["u"].numpy(), host["v"].numpy()) if "u" in host else (None, None)
             nr = fu.shape[1]
+            st["host_fallback"] += len(state["sols"])
+            ii, cells_l, vals_l = [], [], []
             for k, vals_k in enumerate(state["sols"]):
-                i = int(need[k])
-                st["host_fallback"] += 1
                 if vals_k is None:
                     st["dropped_by_qhull"] += 1
-                    keep[i] = False
-                    continue
-                cells = state["holes"][k]
-                if uk is not None:
-                    uk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 0]
-                    vk[i][cells[:, 0], cells[:, 1]] = vals_k[:, 1]
-                fu[i][nr - 1 - cells[:, 0], cells[:, 1]] = vals_k[:, 0] * self._scale / self._dt * 1000
-                fv[i][nr - 1 - cells[:, 0], cells[:, 1]] = -vals_k[:, 1] * self._scale / self._dt * 1000
-        if self.device_out and need.size:
-            # the same patches into the device copies of the finished fields: ONE small upload + index_put per batch
-            ii, rr, cc, pu, pv = [], [], [], [], []
-            for k, vals_k in enumerate(state["sols"]):
-                if vals_k is None:
+                    keep[int(need[k])] = False
                     continue
                 cells = state["holes"][k]
                 ii.append(np.full(cells.shape[0], int(need[k]), dtype=np.int64))
-                rr.append(nr - 1 - cells[:, 0].astype(np.int64))
-                cc.append(cells[:, 1].astype(np.int64))
-                pu.append(vals_k[:, 0] * self._scale / self._dt * 1000)
-                pv.append(-vals_k[:, 1] * self._scale / self._dt * 1000)
+                cells_l.append(cells)
+                vals_l.append(vals_k)
             if ii:
-                dev = state["dev"]["fu"].device
-                idx = torch.from_numpy(np.stack([np.concatenate(ii), np.concatenate(rr), np.concatenate(cc)])).to(dev)
-                val = torch.from_numpy(np.stack([np.concatenate(pu), np.concatenate(pv)])).to(dev)
-                state["dev"]["fu"][idx[0], idx[1], idx[2]] = val[0]
-                state["dev"]["fv"][idx[0], idx[1], idx[2]] = val[1]
+                # ONE indexed assignment per field for the whole batch (round 5; per pair before: 4-6 fancy-index stores each)
+                ii = np.concatenate(ii)
+                cells = np.concatenate(cells_l).astype(np.int64, copy=False)
+                vals = np.concatenate(vals_l)
+                rr, cc = cells[:, 0], cells[:, 1]
+                if uk is not None:
+                    uk[ii, rr, cc] = vals[:, 0]
+                    vk[ii, rr, cc] = vals[:, 1]
+                pu = vals[:, 0] * self._scale / self._dt * 1000          # the reference's expression, cell by cell (B:896-898)
+                pv = -vals[:, 1] * self._scale / self._dt * 1000
+                fr = nr - 1 - rr
+                fu[ii, fr, cc] = pu
+                fv[ii, fr, cc] = pv
+                if self.device_out:
+                    # the same patches into the device copies of the finished fields: ONE small upload + index_put per batch
+                    dev = state["dev"]["fu"].device
+                    idx = torch.from_numpy(np.stack([ii, fr, cc])).to(dev)
+                    val = torch.from_numpy(np.stack([pu, pv])).to(dev)
+                    state["dev"]["fu"][idx[0], idx[1], idx[2]] = val[0]
+                    state["dev"]["fv"][idx[0], idx[1], idx[2]] = val[1]
         state["keep_final"] = keep
         return state
 
