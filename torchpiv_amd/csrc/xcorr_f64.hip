@@ -58,8 +58,17 @@ struct __attribute__((aligned(16))) F64SplitShared {
 // Seven workgroup barriers per window: T1 three (real plane written / read / imaginary plane written), T2 two (plane free /
 // written), peak analysis two.
 // LIST: the windows are those of PassParams::fb_list (precision "exact": the ones its float32 pass left undecided)
-template <int W, bool LIST>
-__device__ __forceinline__ void xcorr_f64_split_body(const PassParams& p) {
+// HALF (round 5): 0 / 1 = the whole window loop instantiated per line half (two straight-line loop bodies
+// behind ONE wave-uniform branch at the top of the kernel: no merge point for the register allocator anywhere inside);
+// -1 = one loop, the half a run-time (wave-uniform) value with branches around the parity-specific stages (round 4).
+// 64x64: 256 VGPRs + 58 spilled (220 B of scratch per lane, 10.7 x the algorithmic HBM traffic) -> 185 VGPRs, ScratchSize 0;
+// 16.1 -> 14.7 ms per 256 pairs (same box, A B A B).  128x128 (TPIV_F64_PER_HALF=2): 256 + 96 AGPRs, ScratchSize 0 on
+// paper -- and a memory fault on the GPU in its first test (golden g3, 128x128): left on the round-4 form.
+#ifndef TPIV_F64_PER_HALF
+#define TPIV_F64_PER_HALF 1
+#endif
+template <int W, bool LIST, int HALF = -1>
+__device__ __forceinline__ void xcorr_f64_split_body(const PassParams& p, F64SplitShared<W>& sm) {
     using S = f64s::Split<W>;
     using f64s::dmax2;
     using f64s::dmin2;
@@ -67,7 +76,6 @@ __device__ __forceinline__ void xcorr_f64_split_body(const PassParams& p) {
     constexpr int M = S::M, NDW = S::NDW, NWV = 2 * W / 64;                      // wavefronts per workgroup
     constexpr int LB = W == 64 ? 6 : 7;                                          // log2 W: line = t & (W - 1), half = t >> LB
     constexpr int NJ = W / 64;                                                   // map rows per lane in the row scans of the peak stage
-    __shared__ F64SplitShared<W> sm;
     double* const plane = sm.plane;
     const int tid = threadIdx.x;
     // The thread index at the point of use.  128x128: lane id (two VALU instructions) + the wavefront's base in an SGPR --
@@ -84,7 +92,7 @@ __device__ __forceinline__ void xcorr_f64_split_body(const PassParams& p) {
         }
     };
 #define TPIV_F64_TID() thread_index()
-    const int half = wave_base >> LB;            // wave-uniform: 0 = first halves of the lines, 1 = second halves
+    const int half = HALF >= 0 ? HALF : wave_base >> LB;      // wave-uniform: 0 = first halves of the lines, 1 = second halves
     const int g = 1 - half;                      // parity of the column bins this thread owns
 
     const int N = p.n_rows * p.n_cols;
@@ -354,13 +362,23 @@ __device__ __forceinline__ void xcorr_f64_split_body(const PassParams& p) {
     TPIV_STAMP_FLUSH(p);
 }
 
+template <int W, bool LIST>
+__device__ __forceinline__ void xcorr_f64_split_entry(const PassParams& p) {
+    __shared__ F64SplitShared<W> sm;
+    if constexpr (TPIV_F64_PER_HALF == 2 || (TPIV_F64_PER_HALF && W == 64)) {
+        if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= W) xcorr_f64_split_body<W, LIST, 1>(p, sm);
+        else xcorr_f64_split_body<W, LIST, 0>(p, sm);
+    } else {
+        xcorr_f64_split_body<W, LIST, -1>(p, sm);
+    }
+}
 template <int W>
 __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_split_kernel(PassParams p) {
-    xcorr_f64_split_body<W, false>(p);
+    xcorr_f64_split_entry<W, false>(p);
 }
 template <int W>
 __global__ __launch_bounds__(2 * W, W == 64 ? 2 : 1) void xcorr_f64_list_kernel(PassParams p) {
-    xcorr_f64_split_body<W, true>(p);
+    xcorr_f64_split_entry<W, true>(p);
 }
 
 template <int W>
