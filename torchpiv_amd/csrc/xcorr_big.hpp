@@ -276,14 +276,18 @@ __device__ __forceinline__ void big_peak_stage(const PassParams& p, float (&c)[B
     }
 }
 
-template <bool CAND>
-__device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
-    __shared__ BigShared sm;
+// PAR (round 5): 0 / 1 = the whole window loop instantiated per parity behind ONE wave-uniform branch at the top of the kernel
+// (the float64 kernels lost all their scratch that way, xcorr_f64.hip); -1 = the parity a run-time value (round 4)
+#ifndef TPIV_BIG_PER_PAR
+#define TPIV_BIG_PER_PAR 1
+#endif
+template <bool CAND, int PAR = -1>
+__device__ __forceinline__ void xcorr_big128_body(const PassParams& p, BigShared& sm) {
     float* const plane = sm.plane;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int line_c = t & 127;       // row y (stages 0-1, 6-7) or column k (stages 2-5)
-    const int par = t >> 7;           // sample / line parity handled by this thread (wave-uniform)
+    const int par = PAR >= 0 ? PAR : t >> 7;      // sample / line parity handled by this thread (wave-uniform)
     const float sgn = par ? -1.f : 1.f;
 
     const int N = p.n_rows * p.n_cols;
@@ -403,7 +407,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             wg_barrier();                                   // plane free (previous item's map)
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
                 static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int k1 = decltype(kc)::value;
                     plane[ln * BP + 64 * pr + k1] = x[FFT_POS<k1, BH>].x;
@@ -412,7 +416,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int k1r = tq & 63, pr = tq >> 7;
+                const int k1r = tq & 63, pr = PAR >= 0 ? PAR : tq >> 7;
 #pragma unroll
                 for (int i = 0; i < BH; ++i) {
                     const float E = plane[(2 * i + pr) * BP + k1r], O = plane[(2 * i + pr) * BP + 64 + k1r];
@@ -423,7 +427,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
                 static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int k1 = decltype(kc)::value;
                     plane[ln * BP + 64 * pr + k1] = x[FFT_POS<k1, BH>].y;
@@ -432,7 +436,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int k1r = tq & 63, pr = tq >> 7;
+                const int k1r = tq & 63, pr = PAR >= 0 ? PAR : tq >> 7;
 #pragma unroll
                 for (int i = 0; i < BH; ++i) {
                     const float E = plane[(2 * i + pr) * BP + k1r], O = plane[(2 * i + pr) * BP + 64 + k1r];
@@ -458,7 +462,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
                 static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int ky1 = decltype(kc)::value;
                     plane[(ky1 + 64 * pr) * BP + ln] = x[FFT_POS<ky1, BH>].x;
@@ -467,7 +471,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
                 const int mk = (BW - ln) & (BW - 1);           // mirrored column
                 static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int ky1 = decltype(kc)::value;
@@ -482,7 +486,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
                 static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int ky1 = decltype(kc)::value;
                     plane[(ky1 + 64 * pr) * BP + ln] = x[FFT_POS<ky1, BH>].y;
@@ -492,7 +496,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             // with Z(k) = a + ib, Z(-k) = c + id:  re = 2 (a d + b c),  im = (c^2 - a^2) + (d^2 - b^2)
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
                 const int mk = (BW - ln) & (BW - 1);
                 static_for<0, BH>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int ky1 = decltype(kc)::value;
@@ -512,28 +516,28 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
 #pragma unroll
                 for (int q = 0; q < BH; ++q) plane[(q + 64 * pr) * BP + ln] = x[q].x;
             }
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
 #pragma unroll
                 for (int q = 0; q < BH; ++q) x[q].x = fmaf(sgn, x[q].x, plane[(q + 64 * (1 - pr)) * BP + ln]);
             }
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
 #pragma unroll
                 for (int q = 0; q < BH; ++q) plane[(q + 64 * pr) * BP + ln] = x[q].y;
             }
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
 #pragma unroll
                 for (int q = 0; q < BH; ++q) x[q].y = fmaf(sgn, x[q].y, plane[(q + 64 * (1 - pr)) * BP + ln]);
             }
@@ -556,7 +560,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
                 static_for<0, BH>([&](auto ic) TPIV_LAMBDA_INLINE {
                     constexpr int i = decltype(ic)::value;
                     plane[(2 * i + pr) * BP + ln] = x[FFT_POS<i, BH>].x;
@@ -572,7 +576,7 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
             wg_barrier();
             {
                 const int tq = TPIV_OPQ_T();
-                const int ln = tq & 127, pr = tq >> 7;
+                const int ln = tq & 127, pr = PAR >= 0 ? PAR : tq >> 7;
                 static_for<0, BH>([&](auto ic) TPIV_LAMBDA_INLINE {
                     constexpr int i = decltype(ic)::value;
                     plane[(2 * i + pr) * BP + ln] = x[FFT_POS<i, BH>].y;
@@ -609,9 +613,21 @@ __device__ __forceinline__ void xcorr_big128_body(const PassParams& p) {
     }
 }
 
-__global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) { xcorr_big128_body<false>(p); }
+template <bool CAND>
+__device__ __forceinline__ void xcorr_big128_entry(const PassParams& p) {
+    __shared__ BigShared sm;
+    // (the candidate form only: its 6 spilled registers go down to 2 and the locating pass of configs[4] from 3.76 to 3.60 ms
+    //  per 64 pairs; the plain float32 kernel has no spills to lose and its doubled code ran 2 % slower -- same box, A B A B)
+    if constexpr (TPIV_BIG_PER_PAR && CAND) {
+        if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) >= 128) xcorr_big128_body<CAND, 1>(p, sm);
+        else xcorr_big128_body<CAND, 0>(p, sm);
+    } else {
+        xcorr_big128_body<CAND, -1>(p, sm);
+    }
+}
+__global__ __launch_bounds__(256, 2) void xcorr_big128_kernel(PassParams p) { xcorr_big128_entry<false>(p); }
 // float32 first pass of the exact scheme (xcorr_exact.hip): same transforms, candidate cells out
-__global__ __launch_bounds__(256, 2) void xcorr_big128_cand_kernel(PassParams p) { xcorr_big128_body<true>(p); }
+__global__ __launch_bounds__(256, 2) void xcorr_big128_cand_kernel(PassParams p) { xcorr_big128_entry<true>(p); }
 
 // test hook: hand-made maps [n_maps, 128, 128] float32 in fftshift layout through stage 7
 __global__ __launch_bounds__(256, 2) void peak_debug_big_kernel(PassParams p, const float* maps, int n_maps) {
