@@ -14,10 +14,14 @@
 #   bench_e2e_gloo2.json        the GENERATOR path sharded over 2 gloo ranks on the one GPU (bench.py --gpus 2 --e2e): launch,
 #                               per-rank host budget and the end-of-run gather from device-resident fields -- a rehearsal
 #   generic_chain.txt           64/32 -> 42/21 -> 28/14 (multipass_scale 1.5) with the three generations of the generic kernel
+#   other_configs/exact_sizes.txt   precision "exact" against "f64" / "fast" at the first-pass sizes other than 32 / 64 / 128
+#                               (quick_bench lines: 8, 16, 24 ... 96 and the chains 16/8 -> 8/4, 48/24 -> 32/16)
+#   stamps_cfg1_cws.txt         per-phase cycle shares of the locating pass and the 32x32 CWS kernel (stamped build)
+#   exact_adversarial.txt       tools/research/exact_adversarial.py: the float32 map's error against the proven bound
 # PART=a: the bench lines and the kernel statistics; PART=b: other configs, stamps, file path, rehearsals (two gpurun calls)
 # Outputs: gpurun_out/$1/ ; tools/collect_profile.py copies what is to be judged into profiles/<round>/.
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT/other_configs
 export TMPDIR=/tmp
@@ -52,6 +56,9 @@ cfg cfg4_128_64_fast --size 2048 --ws 128 --passes 2 --mode CWS --batch 64
 cfg cfg4_128_64_f64 --size 2048 --ws 128 --passes 2 --mode CWS --batch 64 --precision f64
 cfg cfg4_128_64_exact --size 2048 --ws 128 --passes 2 --mode CWS --batch 64 --precision exact
 TPIV_LIB=tools/diag/libtorchpiv_hip_stamps.so python3 tools/stamp_f64.py > $OUT/stamps_f64.txt 2> $OUT/stamps.err || tail -3 $OUT/stamps.err
+TPIV_LIB=tools/diag/libtorchpiv_hip_stamps.so python3 tools/stamp_profile.py CWS 2> /dev/null | grep -v amdgpu.ids > $OUT/stamps_cfg1_cws.txt
+bash tools/dev/exact_chains.sh $TAG/chains > /dev/null 2>&1; cp $OUT/chains/chains.log $OUT/other_configs/exact_sizes.txt
+python3 tools/research/exact_adversarial.py 2> /dev/null | grep -v amdgpu.ids > $OUT/exact_adversarial.txt
 python3 tools/dev/files_profile.py 8 8 8 spots 2 32 2> /dev/null | grep -v amdgpu.ids > $OUT/files_profile.txt
 TPIV_DIST_BACKEND=gloo python3 bench.py --gpus 2 --e2e --e2e-pairs 64 > $OUT/bench_e2e_gloo2.json 2> $OUT/e2e_g2.err || tail -3 $OUT/e2e_g2.err
 python3 bench.py --e2e --e2e-pairs 128 > $OUT/bench_e2e_n1.json 2> $OUT/e2e_n1.err || tail -3 $OUT/e2e_n1.err
