@@ -32,7 +32,7 @@ Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel: HIP-even
 launch stream during the timed steps, bound = "valu" (the path sits ~10x above the
 HBM ridge), frac = max(B_alg / 8 TB/s, F_alg / 157.3 TFLOP/s) / t, the HBM view beside it, and --
 at N = 1 -- PMC counters of THIS build collected live by rocprofv3 child runs of this script
-(FETCH_SIZE, WRITE_SIZE, SQ_* in separate passes; --pmc file reads profiles/r04/pmc_counters.json
+(FETCH_SIZE, WRITE_SIZE, SQ_* in separate passes; --pmc file reads profiles/r05/pmc_counters.json
 instead, --pmc off skips).  `cpu_baseline` (N = 1): the CPU oracle on the host cores.
 """
 import argparse
@@ -56,7 +56,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_VALU_PEAK_TFLOPS = 157.3   # vector fp32 peak, same guide
 FP64_VALU_PEAK_TFLOPS = 78.6    # vector fp64 peak (half rate)
 ISSUE_PEAK_G = 256 * 4 * 2.4 / 2.0      # wave-instructions/s: one per SIMD every 2 cycles at 2.4 GHz
-PMC_FILE = os.path.join(ROOT, "profiles", "r04", "pmc_counters.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05", "pmc_counters.json")
 
 
 def alg_bytes(H, W, n_windows, first_pass):
