@@ -67,9 +67,10 @@ enum tpiv_precision {
     TPIV_PREC_EXACT = 3      /* as TPIV_PREC_F64, with the map cells that reach the result of pass 1 (arg-max, its
                                 neighbours, second peak, minimum: B:383-411, B:518) evaluated as EXACT integer
                                 correlation sums of the uint8 windows instead of through a float64 FFT: a float32
-                                FFT pass locates the cells inside an error band, windows it cannot decide run the
-                                float64 transform (xcorr_exact.hip).  32x32, 64x64 and 128x128 first-pass windows;
-                                other sizes run as TPIV_PREC_F64.  Within ~1e-14 px of the reference's float64
+                                FFT pass locates the cells inside an error band (the proven bound on its rounding
+                                error), windows it cannot decide run the float64 transform
+                                (xcorr_exact.hip).  Every even first-pass window size from 8 to 128; other sizes run
+                                as TPIV_PREC_F64.  Within ~1e-14 px of the reference's float64
                                 pass 1 (whose own transform rounding is the difference).  The default of the Python
                                 drop-in (OfflinePIV). */
 };
@@ -254,7 +255,7 @@ int tpiv_plan_set_timing(tpiv_plan* plan, int enable);
  * the runs recorded since the last call into avg_ms[0..n_slots) and the number of runs into
  * n_runs, then clears the record.  n_slots must be 2*n_pass - 1. */
 int tpiv_plan_get_timing(tpiv_plan* plan, double* avg_ms, int n_slots, int* n_runs);
-/* TPIV_PREC_EXACT plans with 32x32 / 64x64 / 128x128 first-pass windows: the number of windows of the LAST tpiv_plan_run whose first pass
+/* TPIV_PREC_EXACT plans with an even first-pass window size from 8 to 128: the number of windows of the LAST tpiv_plan_run whose first pass
  * went through the float64 transform (undecided by the float32 locating pass).  Waits for the device.  TPIV_EINVAL for
  * other plans or before the first run.  (Diagnostics: bench.py reports the share.) */
 int tpiv_plan_exact_fallbacks(tpiv_plan* plan, long long* n_windows);
