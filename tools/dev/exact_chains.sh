@@ -16,4 +16,6 @@ for ws in 8 16 24 28 40 42 48 56 96; do
     qb --size $sz --ws $ws --passes 1 --batch $b --distinct 2 --precision $prec
   done
 done
+# 8/4 on frames with sensor noise (the default synthetic frames have a noise-free background: 8 % of their sparse 8x8 windows have flat maps)
+for prec in exact f64; do qb --size 4096 --ws 8 --passes 1 --batch 4 --distinct 2 --noise 2 --precision $prec; done
 grep "==\|pairs/s\|exact" $L
