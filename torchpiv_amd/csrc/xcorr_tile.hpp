@@ -144,6 +144,19 @@ __device__ __forceinline__ float byte_f(const uint32_t (&d)[N]) {
     return (float)((d[K >> 2] >> (8 * (K & 3))) & 0xffu);
 }
 
+// ... the same byte REINTERPRETED as a float32 (a denormal: b x 2^-149), for use as a multiplicand: the compiler folds
+// the byte extraction into the multiply (v_mul_f32_sdwa src_sel:BYTE_k) -- one instruction instead of v_cvt_f32_ubyte +
+// v_mul_f32.  The other factor carries 2^125, so the product is b x w x 2^-24: exact scaling, no rounding differs (the
+// kernels run with float32 denormals on: .amdhsa_float_denorm_mode_32 3).  gfx950 has no SDWA form of v_fmac / v_fma.
+#ifndef TPIV_SDWA_LERP
+#define TPIV_SDWA_LERP 1
+#endif
+constexpr float SDWA_UP = 0x1p125f, SDWA_DN = 0x1p-24f, SDWA_INV = 0x1p24f;      // 2^125 x 2^-149 = 2^-24
+template <int K, int N>
+__device__ __forceinline__ float byte_d(const uint32_t (&d)[N]) {
+    return __uint_as_float((d[K >> 2] >> (8 * (K & 3))) & 0xffu);
+}
+
 // N dwords from a byte address of any alignment (global memory takes unaligned dword loads)
 template <int N>
 __device__ __forceinline__ void load_dwords(const uint8_t* __restrict__ p, uint32_t (&d)[N]) {
@@ -1039,16 +1052,26 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                     pull(std::integral_constant<int, 0>{});
                     pull(std::integral_constant<int, 1>{});
                 }
-                float va = fmaf(byte_f<0, NB>(ra1), c.wya_dn, byte_f<0, NB>(ra0) * c.wya_up);
-                float vb = fmaf(byte_f<0, NB>(rb1), c.wyb_dn, byte_f<0, NB>(rb0) * c.wyb_up);
+                // (TPIV_SDWA_LERP: the upper row's byte enters its product as a float32 denormal -- see byte_d -- and every sample
+                //  of the wavefront carries the factor 2^-24 from here on: folded into end_scale by the kernel)
+                constexpr bool SD = TPIV_SDWA_LERP != 0;
+                const float wau = SD ? c.wya_up * SDWA_UP : c.wya_up, wad = SD ? c.wya_dn * SDWA_DN : c.wya_dn;
+                const float wbu = SD ? c.wyb_up * SDWA_UP : c.wyb_up, wbd = SD ? c.wyb_dn * SDWA_DN : c.wyb_dn;
+                auto row_lerp = [&](auto kc, const uint32_t (&r0_)[NB], const uint32_t (&r1_)[NB], float wu_, float wd_) TPIV_LAMBDA_INLINE {
+                    constexpr int k = decltype(kc)::value;
+                    if constexpr (SD) return fmaf(byte_f<k, NB>(r1_), wd_, byte_d<k, NB>(r0_) * wu_);
+                    else return fmaf(byte_f<k, NB>(r1_), wd_, byte_f<k, NB>(r0_) * wu_);
+                };
+                float va = row_lerp(std::integral_constant<int, 0>{}, ra0, ra1, wau, wad);
+                float vb = row_lerp(std::integral_constant<int, 0>{}, rb0, rb1, wbu, wbd);
                 static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
                     constexpr int k = decltype(kc)::value;
                     if constexpr (k % 8 == 0 && k > 0) __builtin_amdgcn_sched_barrier(0);
                     // dwords 4b .. 4b + 4 serve pixels 16b .. 16b + 15 (+1): unit b + 1 arrives at pixel 16b
                     if constexpr (LAZY && k % 16 == 0 && k > 0) pull(std::integral_constant<int, k / 16 + 1>{});
                     const float4 wx = wbuf[k];
-                    const float na = fmaf(byte_f<k + 1, NB>(ra1), c.wya_dn, byte_f<k + 1, NB>(ra0) * c.wya_up);
-                    const float nb = fmaf(byte_f<k + 1, NB>(rb1), c.wyb_dn, byte_f<k + 1, NB>(rb0) * c.wyb_up);
+                    const float na = row_lerp(std::integral_constant<int, k + 1>{}, ra0, ra1, wau, wad);
+                    const float nb = row_lerp(std::integral_constant<int, k + 1>{}, rb0, rb1, wbu, wbd);
 #ifdef TPIV_MUTANT_LERP
                     // tests only (tools/diag/libtorchpiv_hip_mutant.so, never shipped): one weight of the column
                     // lerp off by 1e-3 -- the parity gates must notice (tests/test_gpu_gates.py)
@@ -1092,7 +1115,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                                        nxa - dxa_f, c.wya_up, c.wya_dn, c.ydeg_a || (uxa == dxa));
             }
 #pragma unroll
-            for (int k = 0; k < RBL; ++k) x[k0 + k].x = rowbuf[k];
+            for (int k = 0; k < RBL; ++k) x[k0 + k].x = (FAST && TPIV_SDWA_LERP) ? rowbuf[k] * SDWA_DN : rowbuf[k];
 #pragma unroll UNR_CWS
             for (int k = 0; k < RBL; ++k) {
                 const float nxb = (gx0f + (float)(k0 + k)) + vx;
@@ -1105,7 +1128,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
                                        nxb - dxb_f, c.wyb_up, c.wyb_dn, c.ydeg_b || (uxb == dxb));
             }
 #pragma unroll
-            for (int k = 0; k < RBL; ++k) x[k0 + k].y = rowbuf[k];
+            for (int k = 0; k < RBL; ++k) x[k0 + k].y = (FAST && TPIV_SDWA_LERP) ? rowbuf[k] * SDWA_DN : rowbuf[k];
             });
             wave_sync();
         }
@@ -1591,10 +1614,12 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
             int rr = r;
             asm volatile("" : "+v"(rr));
             float* d = p.dbg_win + fidx * 2 * WS * WS + rr * WS;
+            // (fast-order CWS samples carry 2^-24, see byte_d)
+            constexpr float UNS = (MODE == MODE_CWS && FAST && TPIV_SDWA_LERP) ? SDWA_INV : 1.0f;
 #pragma unroll
             for (int k = 0; k < WS; ++k) {
-                d[k] = x[k].x;
-                d[WS * WS + k] = x[k].y;
+                d[k] = x[k].x * UNS;
+                d[WS * WS + k] = x[k].y * UNS;
             }
         }
 
@@ -1663,6 +1688,7 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
             x[P0].x -= ta * (1.0f / WS);
             x[P0].y -= tb * (1.0f / WS);
             end_scale = 0.25f / (float)(WS * WS);
+            if constexpr (MODE == MODE_CWS && TPIV_SDWA_LERP) end_scale *= SDWA_INV * SDWA_INV;     // both frames' samples carry 2^-24
         }
         TPIV_STAMP(3);      // forward row FFT
         transpose_tile<WS, true, PLANAR>(x, tile, fresh_lane());  // lane = kx, x[y] natural
