@@ -148,8 +148,12 @@ __device__ __forceinline__ float byte_f(const uint32_t (&d)[N]) {
 // the byte extraction into the multiply (v_mul_f32_sdwa src_sel:BYTE_k) -- one instruction instead of v_cvt_f32_ubyte +
 // v_mul_f32.  The other factor carries 2^125, so the product is b x w x 2^-24: exact scaling, no rounding differs (the
 // kernels run with float32 denormals on: .amdhsa_float_denorm_mode_32 3).  gfx950 has no SDWA form of v_fmac / v_fma.
+// OFF: measured in round 5 (same box, A B A B; results bit-identical, 82 parity tests green): the 66 v_mul_f32_sdwa per item
+// replace 66 conversions -- and the 32x32 CWS pass takes 7.27 / 7.33 ms with them against 7.19 / 7.26 without, the 64x64 CWS
+// pass 2.35 against 2.27, the 16x16 pass 1.93 against 1.91: the multiply with a denormal (or SDWA) operand is not a
+// full-rate instruction on this chip.
 #ifndef TPIV_SDWA_LERP
-#define TPIV_SDWA_LERP 1
+#define TPIV_SDWA_LERP 0
 #endif
 constexpr float SDWA_UP = 0x1p125f, SDWA_DN = 0x1p-24f, SDWA_INV = 0x1p24f;      // 2^125 x 2^-149 = 2^-24
 template <int K, int N>
