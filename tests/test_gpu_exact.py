@@ -240,3 +240,29 @@ def test_exact_on_adversarial_windows(eng):
         print(f"  {str(name):32s} err / E+ {ratio:.2e}  float64 path {n_fb}/{len(a)}  max |exact - f64| {d:.1e} px")
         assert d < TOL_F64 and torch.equal(ie, i_f), str(name)
     print(f"  worst err / E+ {worst:.2e} against Gamma {gamma:.2e}")
+
+
+@pytest.mark.parametrize("ws,scale,size,batch", [(16, 2.0, 1024, 4), (48, 1.5, 1024, 4), (24, 2.0, 1024, 4), (96, 2.0, 1024, 2)])
+def test_exact_chains_from_other_first_pass_sizes(eng, ws, scale, size, batch):
+    """multipass chains whose FIRST pass is not 32 / 64 / 128 pixels (16/8 -> 8/4, 48/24 -> 32/16 at
+    multipass_scale 1.5, 24/12 -> 12/6, 96/48 -> 48/24) at the default precision against the float64 first pass: the same first-pass
+    fields to 1e-9 px with identical flags, and final fields that differ in no more than a sliver of the cells."""
+    from torchpiv_amd import synth
+    A, B = synth.make_batch(batch, size, size, device="cuda", noise=2.0, first_index=200 + ws)
+    pe = eng.Plan(size, size, ws, ws // 2, n_pass=2, mode="CWS", pass_scale=scale, max_batch=batch, precision="exact")
+    pf = eng.Plan(size, size, ws, ws // 2, n_pass=2, mode="CWS", pass_scale=scale, max_batch=batch, precision="f64")
+    assert "cand" in pe.kernel_name(0), pe.kernel_name(0)
+    ue, ve, ie = (t.clone() for t in pe.run(A, B))
+    n_fb, n_win = pe.exact_fallbacks(), batch * pe.geometry[0][2] * pe.geometry[0][3]
+    u1e, v1e, i1e = pe.pass_fields(0, batch)
+    uf, vf, i_f = (t.clone() for t in pf.run(A, B))
+    u1f, v1f, i1f = pf.pass_fields(0, batch)
+    d1 = max(float((u1e - u1f).abs().max()), float((v1e - v1f).abs().max()))
+    print(f"  {ws}/{ws // 2} x{scale}: geometry {pe.geometry}, {n_fb} of {n_win} first-pass windows through the float64 transform, "
+          f"first pass max |exact - f64| {d1:.1e} px")
+    assert d1 < 1e-9 and torch.equal(i1e, i1f)
+    assert n_fb <= n_win // 10
+    far = ((ue - uf).abs() > 1e-6) | ((ve - vf).abs() > 1e-6) | (ie != i_f)
+    assert float(far.float().mean()) < 2e-3
+    pe.close()
+    pf.close()
