@@ -4,9 +4,10 @@ For families of 64x64 windows -- particle images at several noise levels, pure n
 transform look bad (nearly orthogonal patterns, one bright pixel on a pedestal, two grey levels, a saturated frame with a
 few dark pixels) -- the float32 correlation maps of the tile kernel (debug hook) are compared with the float64 maps:
 
-  err / R   largest cell error relative to the map range (the band of peak_candidates is EXACT_BAND = 1e-4 of the range)
-  err / E   ... relative to E = |a - mean a| |b - mean b| / (mean a mean b), the scale the transform's rounding follows
-  R / E     contrast of the map; the refinement sends windows below EXACT_MIN_CONTRAST to the float64 transform
+  err / R   largest cell error relative to the map range
+  err / E   ... relative to E = |a - mean a| |b - mean b| / (mean a mean b) <= E+, the scale the transform's rounding follows
+            (the band of the locating pass is 2 Gamma (1 + 1/16) E+ with the PROVEN Gamma = 247 u = 1.47e-5)
+  R / E     contrast of the map (round 4 sent windows below 0.028 to the float64 transform; the proven band needs no such guard)
 
 and the fields of precision="exact" with those of precision="f64" (any difference above 1e-9 px is a wrong decision that
 went unnoticed).
