@@ -90,6 +90,42 @@ __device__ __forceinline__ float cws_sample_patch(const uint8_t* __restrict__ pa
     return degenerate ? f11 : r;
 }
 
+// ---- the same sample through SEPARABLE TABLES (round 5): the column part of B:162-172 (floor / ceil of the x coordinate,
+// its two weights, the corner's offset inside the patch) depends on the column only, the row part on the row only -- n + n
+// table entries per frame instead of n x n evaluations of both.  The sample itself is B:187-193 operation by operation with
+// the same float32 numbers: bit-identical to cws_sample_patch (every staged-window test runs through it).
+struct CwsAxis {
+    int off;        // corner (floor) coordinate inside the patch: column index, or row index times the patch pitch
+    int step;       // distance to the ceil corner: 0 (integral coordinate: B:170, B:193 -- the "nearest sample" quirk), 1 column or 1 row
+    float w_up;     // ceil - coordinate: weight of the FLOOR corner
+    float w_dn;     // coordinate - floor
+};
+// entry of grid coordinate g (pixel index along the axis) shifted by v; base = first pixel of the patch along the axis, PD = its
+// extent, scale = 1 (columns) or the patch pitch (rows).  *inside: both corners lie inside the patch.
+__device__ __forceinline__ CwsAxis cws_axis(int g, float v, int base, int PD, int scale, bool& inside) {
+#pragma clang fp contract(off)
+    const float n_ = (float)g + v;
+    const float u_f = ceilf(n_), d_f = floorf(n_);
+    const int u = f2i_sat_g(u_f), d = f2i_sat_g(d_f);
+    inside = ((unsigned)(d - base) < (unsigned)PD) & ((unsigned)(u - base) < (unsigned)PD);
+    CwsAxis e;
+    e.off = (d - base) * scale;
+    e.step = (u - d) * scale;
+    e.w_up = u_f - n_;
+    e.w_dn = n_ - d_f;
+    return e;
+}
+__device__ __forceinline__ float cws_sample_tab(const uint8_t* __restrict__ patch, CwsAxis cx, CwsAxis cy) {
+#pragma clang fp contract(off)
+    const uint8_t* q0 = patch + cy.off + cx.off;
+    const float f11 = (float)q0[0], f21 = (float)q0[cx.step], f12 = (float)q0[cy.step], f22 = (float)q0[cy.step + cx.step];
+    float r = (f11 * cx.w_up) * cy.w_up;
+    r = r + (f21 * cx.w_dn) * cy.w_up;
+    r = r + (f12 * cx.w_up) * cy.w_dn;
+    r = r + (f22 * cx.w_dn) * cy.w_dn;
+    return (cx.step == 0) | (cy.step == 0) ? f11 : r;          // (ux - dx) * (uy - dy) == 0  (B:192-193)
+}
+
 // ---- piv_iteration_CWS_Fast (B:644-653): torch's affine_grid + grid_sample(mode="bicubic",
 // padding_mode="border", align_corners=False) of a window INSIDE ITSELF, in float32.
 // cubic convolution with A = -0.75 (ATen UpSample.h: cubic_convolution1/2, get_cubic_upsample_coefficients)
@@ -748,6 +784,8 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
     float* wmeta = reinterpret_cast<float*>(ct_smem + ct_register_meta_offset(n, WPW));
     // candidate lists of the exact scheme (map_candidates): 16 ints behind the reduction slots / the per-window data
     int* cscr = NC > 0 ? reinterpret_cast<int*>(wmeta + WPW * 8) : reinterpret_cast<int*>(red + 2 * CT_WAVES);
+    // CWS: the separable sampling tables (cws_axis): columns / rows of frame a, columns / rows of frame b, n entries each, + a flag
+    CwsAxis* const axes = reinterpret_cast<CwsAxis*>(cscr + 16);
     float band_abs = 0.f;
     const int PD = n + 4;                                   // CWS: source patch of a shifted window incl. the interpolation margin
     const int PDP = (PD + 3) & ~3;                          // its row pitch in LDS (rows start on dword boundaries)
@@ -831,8 +869,22 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
                     patch_b[py * PDP + px] = (uint8_t)fetch_clamped_g(fb, (long long)(byb + py) * p.W + (bxb + px), HW);
                 }
             }
+            // the separable tables of this window: thread t < n makes the entries of column t and of row t (both frames)
+            int* const tab_ok = reinterpret_cast<int*>(axes + 4 * n);
+            if (tid == 0) *tab_ok = 1;
+            __syncthreads();
+            if (tid < n) {
+                bool i0, i1, i2, i3;
+                axes[tid] = cws_axis(x0 + tid, -vx, bxa, PD, 1, i0);
+                axes[n + tid] = cws_axis(y0 + tid, -vy, bya, PD, PDP, i1);
+                axes[2 * n + tid] = cws_axis(x0 + tid, vx, bxb, PD, 1, i2);
+                axes[3 * n + tid] = cws_axis(y0 + tid, vy, byb, PD, PDP, i3);
+                if (!(i0 & i1 & i2 & i3)) *tab_ok = 0;          // (a corner outside the patch -- a wild predictor: the per-sample form below)
+            }
             __syncthreads();
         }
+        bool tabs = false;
+        if constexpr (MODE == MODE_CWS) tabs = *reinterpret_cast<int*>(axes + 4 * n) != 0;
         float sa = 0, sb = 0;
         unsigned iaa = 0u, ibb = 0u;      // first pass: sums of squares of the bytes (exact; the band of the exact scheme)
 #pragma unroll 4
@@ -851,8 +903,13 @@ __global__ __launch_bounds__(NC > 0 ? 64 : CT_T) void xcorr_generic_ct_kernel(Pa
                 a = fetch_clamped_g(fa, q - sh, HW);
                 b = fetch_clamped_g(fb, q + sh, HW);
             } else if constexpr (MODE == MODE_CWS) {
-                a = cws_sample_patch(patch_a, PD, PDP, bxa, bya, fa, HW, p.W, x0 + x, y0 + y, -vx, -vy);
-                b = cws_sample_patch(patch_b, PD, PDP, bxb, byb, fb, HW, p.W, x0 + x, y0 + y, vx, vy);
+                if (tabs) {       // (wave-uniform)
+                    a = cws_sample_tab(patch_a, axes[x], axes[n + y]);
+                    b = cws_sample_tab(patch_b, axes[2 * n + x], axes[3 * n + y]);
+                } else {
+                    a = cws_sample_patch(patch_a, PD, PDP, bxa, bya, fa, HW, p.W, x0 + x, y0 + y, -vx, -vy);
+                    b = cws_sample_patch(patch_b, PD, PDP, bxb, byb, fb, HW, p.W, x0 + x, y0 + y, vx, vy);
+                }
             } else {
                 a = bicubic_local(fa, p.W, y0, x0, n, x, y, -vx, -vy);
                 b = bicubic_local(fb, p.W, y0, x0, n, x, y, vx, vy);
@@ -1208,7 +1265,8 @@ static bool ct_register_size(int n) {
 }
 // (one tile per window of a wavefront, one pair of CWS patches, and eight floats of per-window data)
 static size_t ct_register_smem(int n, int mode) {
-    return ct_register_meta_offset(n, ct_register_wpw(n, mode)) + (size_t)ct_register_wpw(n, mode) * 8 * sizeof(float) + 16 * sizeof(int);
+    return ct_register_meta_offset(n, ct_register_wpw(n, mode)) + (size_t)ct_register_wpw(n, mode) * 8 * sizeof(float) + 16 * sizeof(int) +
+           (mode == MODE_CWS ? (size_t)(4 * n + 1) * 16 : 0);
 }
 constexpr int CT_MAX_RADIX = 8;
 // n = n1 n2 with 2 <= n1 <= n2 <= CT_MAX_RADIX, n1 as large as possible; false if there is no such split
@@ -1220,7 +1278,7 @@ bool ct_factors(int n, int& n1, int& n2) {
     n2 = n / n1;
     return n1 >= 2 && n2 <= CT_MAX_RADIX;
 }
-size_t ct_smem_bytes(int n) { return (size_t)(2 * n * (n | 1) + n) * sizeof(cff) + 2 * CT_WAVES * sizeof(float) + 16 * sizeof(int); }     // (the two (n + 4) x pitch patches fit the second tile, n >= 4)
+size_t ct_smem_bytes(int n) { return (size_t)(2 * n * (n | 1) + n) * sizeof(cff) + 2 * CT_WAVES * sizeof(float) + 16 * sizeof(int) + (size_t)(4 * n + 1) * 16; }     // (the two (n + 4) x pitch patches fit the second tile, n >= 4)
 bool ct_usable(int n, int precision) {
     int a, b;
     return precision == 0 && (n & 1) == 0 && n >= 4 && n <= 96 && ct_factors(n, a, b) && ct_smem_bytes(n) <= 160 * 1024;
