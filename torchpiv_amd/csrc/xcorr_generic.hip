@@ -765,7 +765,12 @@ __host__ __device__ constexpr size_t ct_register_meta_offset(int n, int wpw) {
 // CWS: its staging (patch fetch + reference-order bilinear samples, all 64 lanes, window after window) is most of the pass,
 // and the packed form's registers (161 -> 208 at 28) cost it the third wavefront per SIMD: 28x28 CWS 155 -> 180 us per pair
 // packed, while DWS goes 124 -> 83
-__host__ __device__ constexpr int ct_register_wpw(int n, int mode) { return (n > 0 && n <= 64 && mode != MODE_CWS) ? 64 / n : 1; }
+// (TPIV_CT_PACK_CWS=1: several windows per wavefront for CWS too -- measured again in round 5 with the sampling tables: 28 x 28 CWS
+//  148 -> 156 us per pair, same registers (244); stays off)
+#ifndef TPIV_CT_PACK_CWS
+#define TPIV_CT_PACK_CWS 0
+#endif
+__host__ __device__ constexpr int ct_register_wpw(int n, int mode) { return (n > 0 && n <= 64 && (mode != MODE_CWS || TPIV_CT_PACK_CWS)) ? 64 / n : 1; }
 // NC > 0: the window size as a compile-time constant -- ONE wavefront per window, lane = line, the four transforms as
 // in-register mixed-radix codelets (fft_mixed.hpp) with LDS only for the two transpositions; staging and peak analysis are
 // the loops of the run-time form with n known to the compiler.  NC = 0: the run-time form (any even n whose factors fit).
