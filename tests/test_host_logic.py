@@ -432,6 +432,51 @@ def test_fast_hole_fill_is_the_reference_interpolator_bit_for_bit():
     assert n_masks > 500 and n_nan > 0 and n_refused > 0
 
 
+def test_diamond_short_cut_of_the_hole_fill_is_bit_identical():
+    """Fields whose holes are all ISOLATED invalid vectors (the common case): qhull_fill reads Qhull's diagonal of
+    every co-circular diamond off the triangulation instead of computing barycentric transforms and walking simplices
+    (_qhull._diamond_fill).  Against the reference's literal LinearNDInterpolator call and against the general path: every
+    value bit-identical -- holes next to each other diagonally, at the field border (then the short cut must step aside), values
+    over nine decades -- and the short cut really is the path taken."""
+    from torchpiv_amd import _qhull
+    rng = np.random.default_rng(77)
+    taken = general = n_vals = 0
+    for trial in range(300):
+        nr, nc = (int(t) for t in rng.integers(8, 130, 2))
+        hole = np.zeros((nr, nc), bool)
+        border = rng.random() < 0.15                      # holes ON the border have fewer than four neighbours: general path
+        for _ in range(int(rng.integers(1, 80))):
+            lo = 0 if border else 1
+            r, c = int(rng.integers(lo, nr - lo)), int(rng.integers(lo, nc - lo))
+            nb = [(r + dr, c + dc) for dr, dc in ((1, 0), (-1, 0), (0, 1), (0, -1)) if 0 <= r + dr < nr and 0 <= c + dc < nc]
+            if hole[r, c] or any(hole[q] for q in nb):
+                continue
+            hole[r, c] = True
+        d = hole.copy()
+        d[1:] |= hole[:-1]
+        d[:-1] |= hole[1:]
+        d[:, 1:] |= hole[:, :-1]
+        d[:, :-1] |= hole[:, 1:]
+        pts, tg = np.argwhere(d & ~hole), np.argwhere(hole)
+        vals = rng.standard_normal((len(pts), 2)) * float(rng.choice([1e-6, 1e-2, 1.0, 1e3]))
+        ref = _qhull.qhull_fill_reference(pts, vals, tg)
+        got = _qhull.qhull_fill(pts, vals, tg)
+        slow = _qhull.qhull_fill(pts, vals, tg, diamonds=False)
+        assert (ref is None) == (got is None) == (slow is None), trial
+        if ref is None:
+            continue
+        assert np.array_equal(ref, got, equal_nan=True) and np.array_equal(ref, slow, equal_nan=True), trial
+        from scipy.spatial import Delaunay
+        short = _qhull._diamond_fill(Delaunay(pts), pts, vals, tg)
+        taken += short is not None
+        general += short is None
+        n_vals += ref.size
+        on_border = bool(hole[0].any() or hole[-1].any() or hole[:, 0].any() or hole[:, -1].any())
+        assert (short is None) == on_border, (trial, on_border)
+    print(f"  {taken} fields through the short cut, {general} with a border hole through the general path, {n_vals} values bit-identical")
+    assert taken > 200 and general > 10
+
+
 def test_batch_reader_agrees_with_the_per_file_path(tmp_path):
     """tpiv_read_files + the vectorised header sweep (io.stage_batch) against io.stage_raw file by file: same bytes
     in the slot, same layout and grey table for the plain BMPs; everything else is handed back (None)."""
