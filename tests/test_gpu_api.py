@@ -141,6 +141,8 @@ def test_offline_piv_generator(folder, golden, run, precision):
         assert u.shape == g[f"{run}_{j}_u"].shape
         unit = 1000 * scale / dt
         if (run, yielded[j]) in DEGENERATE:
+            print(f"{run} {precision} pair {yielded[j]}: frame b == frame a -- NOT compared with the reference's chain (its output for this "
+                  "pair is a function of +-1e-17 of transform noise, README 'Tolerance'); isolation gate of every pass only")
             strict_chain(g["frames_a"][yielded[j]], g["frames_b"][yielded[j]], ws, ov, mp_, ("DWS", "CWS")[mode],
                          precision, unit, u, v, f"{run}p{yielded[j]}", reference_chain=False)
             continue
