@@ -43,6 +43,11 @@ struct PassParams {
     // (float64 pass 1: 8 doubles per window, m and dead stored as values)
     float* peak_raw;
     unsigned* work_ctr;      // 8 x 16 dwords: per-XCD item counters of the tile kernel (set by launch_xcorr)
+    // 64x64 CWS pass in two launches (round 5): the fast-path-only kernel appends the items that need the per-pixel staging
+    // path to slow_list (count: slow_count); the full kernel then runs with list_mode = 1 over exactly those items
+    int* slow_list;
+    unsigned* slow_count;
+    int list_mode;
     // precision "exact" (64x64 pass 1, xcorr_exact.hip; all set by launch_xcorr): the float32 kernel's candidate cells
     // per window (8 x int16: arg-max, 3 second-peak cells, 4 minimum cells; -1 = none, arg-max -1 = undecided, -2 = dead),
     // and the windows that go to the float64 kernel instead (undecided ones)
@@ -160,6 +165,14 @@ hipError_t launch_bmp_unpack(const uint8_t* raw, const long long* desc, const ui
                              uint8_t* out, hipStream_t stream);
 
 hipError_t launch_xcorr(const PassParams& p, int mode, int n_cu, hipStream_t stream);
+// bytes of the tile kernels' work-queue counters (8 x one 64-byte line), and of the slow-item list header behind them
+constexpr size_t TILE_CTR_BYTES = 8 * 16 * sizeof(unsigned), TILE_SLOW_HDR_BYTES = 256;
+// 64x64 CWS pass at the fast operation order: fast-path-only kernel at three wavefronts per SIMD + a second launch of the full
+// kernel over the items it set aside (TPIV_SPLIT64=0: the single launch of rounds 1-4)
+#ifndef TPIV_SPLIT64
+#define TPIV_SPLIT64 1
+#endif
+constexpr bool tile_split64(int ws, int mode) { return TPIV_SPLIT64 && ws == 64 && mode == MODE_CWS; }
 // wavefronts per SIMD the tile kernel of (ws, mode) is built for (the OCC template argument of
 // xcorr_tile_kernel); 0 for sizes that run another kernel
 #ifndef TPIV_OCC64C

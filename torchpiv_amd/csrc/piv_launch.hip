@@ -176,7 +176,7 @@ hipError_t launch_peaks_from_maps(const PassParams& p, const float* maps, int n_
     return hipGetLastError();
 }
 
-static constexpr size_t WORK_CTR_BYTES = 8 * 16 * sizeof(unsigned);
+static constexpr size_t WORK_CTR_BYTES = TILE_CTR_BYTES;
 static size_t work_ctr_offset(int batch, int n_windows) { return (peak_bytes(batch, n_windows) + 127) / 128 * 128; }
 
 // precision "exact": float64 records | candidate cells (16 B per window) | float64 list | its counter | tile work counters
@@ -208,7 +208,9 @@ size_t peak_raw_bytes(int ws, int batch, int n_windows, int precision, bool forc
     }
     if (tile_size(ws) && !force_generic) {
         if (precision) return peak_bytes(batch, n_windows, 1);                      // float64 records only
-        return work_ctr_offset(batch, n_windows) + WORK_CTR_BYTES;                  // records + item counters
+        // records + item counters (+ 64x64: the list of the items the fast-path-only CWS kernel sets aside)
+        return work_ctr_offset(batch, n_windows) + WORK_CTR_BYTES +
+               (ws == 64 ? TILE_SLOW_HDR_BYTES + (size_t)batch * n_windows * sizeof(int) : 0);
     }
     // generic sizes (and shifted 128x128 passes): records + the DFT scratch tiles of the resident workgroups
     const int eb = precision ? 8 : 4;
@@ -328,7 +330,15 @@ hipError_t launch_xcorr(const PassParams& p_in, int mode, int n_cu, hipStream_t 
     } else if (tile_size(p.ws)) {       // per-XCD work queue of the tile kernel: counters behind the peak records
         p.work_ctr = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.peak_raw) +
                                                  work_ctr_offset(p.batch, p.n_rows * p.n_cols));
-        e = hipMemsetAsync(p.work_ctr, 0, WORK_CTR_BYTES, stream);
+        p.list_mode = 0;
+        p.slow_list = nullptr;
+        p.slow_count = nullptr;
+        const bool split = tile_split64(p.ws, mode) && p.precision == 0;
+        if (split) {        // (the list lives behind the counters: peak_raw_bytes)
+            p.slow_count = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.work_ctr) + WORK_CTR_BYTES);
+            p.slow_list = reinterpret_cast<int*>(reinterpret_cast<char*>(p.slow_count) + TILE_SLOW_HDR_BYTES);
+        }
+        e = hipMemsetAsync(p.work_ctr, 0, WORK_CTR_BYTES + (split ? TILE_SLOW_HDR_BYTES : 0), stream);
         if (e != hipSuccess) return e;
         // 8x8: one window per lane (xcorr_w8.hip); TPIV_W8=0 selects the lane-per-row tile kernel for A/B runs
         static const bool w8 = [] {

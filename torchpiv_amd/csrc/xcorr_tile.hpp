@@ -835,7 +835,9 @@ __device__ __forceinline__ uint32_t read_unit_x(const uint4* src) {
 struct RowSquares {
     unsigned aa, bb;
 };
-template <int WS, int MODE, int RBH = 1, bool FAST = false, bool SQ = false>
+// PATH: 0 = the staging path of the item is a run-time (wave-uniform) choice, 1 = the wide-load path only (the per-pixel
+// path is not compiled: the caller has sent those items elsewhere)
+template <int WS, int MODE, int RBH = 1, bool FAST = false, bool SQ = false, int PATH = 0>
 __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom& g, int r, int lane, float vx,
                                              float vy, RawRows<WS, MODE>& raw, cf (&x)[WS], float& sa,
                                              float& sb, float* lds, RowSquares* sq = nullptr) {
@@ -935,7 +937,7 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
         const CwsRow c = cws_row(g.y0 + r, vy);
         const float gx0f = (float)g.x0;
         using CG = CoopGeo<WS>;
-        if (raw.reg) {
+        if (PATH == 1 || raw.reg) {
             uint32_t ra0[NB], ra1[NB], rb0[NB], rb1[NB];
             const uint4 *lz0 = nullptr, *lz1 = nullptr, *lz2 = nullptr, *lz3 = nullptr;
             if constexpr (CG::ON) {
@@ -1460,7 +1462,11 @@ __device__ __forceinline__ void peak_candidates(const PassParams& p, const float
 // FAST (PassParams::precision == 0): cheaper arithmetic that differs from the !FAST form by float32
 // rounding only -- see convert_rows, the mean handling after the row transform and peak_analysis<.., SCALED>.
 // CAND: the peak stage writes candidate cells for the exact refinement (peak_candidates) instead of the 8-float record
-template <int WS, int MODE, int OCC, bool FAST, bool CAND>
+// ROLE 1 (64x64 CWS, round 5): the per-pixel staging path is NOT part of this instance -- with it the kernel needs 100 spilled
+// registers at the 168 three wavefronts per SIMD allow, without it 7 -- and the items that need it (frame borders, integral
+// row coordinates: ~0.3 %) are appended to PassParams::slow_list instead of being processed; a second launch of the full
+// kernel (ROLE 0, PassParams::list_mode = 1) runs exactly those.
+template <int WS, int MODE, int OCC, bool FAST, bool CAND, int ROLE = 0>
 __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
     constexpr bool PLANAR = OCC > 2;
     using G = TileGeo<WS, PLANAR>;
@@ -1485,8 +1491,11 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
 
     const int N = p.n_rows * p.n_cols;
     const int groups = (N + G::WPW - 1) / G::WPW;
-    const int items = p.batch * groups;               // < 2^31 (checked by the launcher)
+    // list mode: the items are the entries of slow_list, their number is on the device
+    const bool listed = ROLE == 0 && MODE != MODE_PASS1 && p.list_mode != 0;
+    const int items = listed ? __builtin_amdgcn_readfirstlane((int)*p.slow_count) : p.batch * groups;   // < 2^31 (checked by the launcher)
     const int st = p.ws - p.ov;
+    auto real_item = [&](int pos) TPIV_LAMBDA_INLINE { return listed ? __builtin_amdgcn_readfirstlane(p.slow_list[pos]) : pos; };
 
     // XCD-aware item order: workgroups b, b+8, ... share an XCD (and its L2); every XCD owns one
     // contiguous run of windows and its wavefronts pull the next item(s) from a per-XCD counter
@@ -1524,8 +1533,9 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
     };
 
     // per-lane geometry of an item; `w` = the lane's window slot (a fresh copy at every call site)
-    auto geom_of = [&](int item, int w) TPIV_LAMBDA_INLINE {
+    auto geom_of = [&](int pos, int w) TPIV_LAMBDA_INLINE {
         ItemGeom g;
+        const int item = real_item(pos);
         g.pair = fast_div(item, p.groups_magic, p.groups_shift);
         const int gi = item - g.pair * groups;
         const int win_raw = gi * G::WPW + w;
@@ -1593,6 +1603,17 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
         float nvx, nvy;
         shift_of(gnext, nvx, nvy);
 
+        if constexpr (ROLE == 1) {
+            if (!raw.reg) {                // (wave-uniform) an item for the full kernel: note it, fetch the next one's rows, go on
+                if (lane == 0) p.slow_list[atomicAdd(p.slow_count, 1u)] = item;
+                nnitem = q_take(q_raw);
+                issue_rows<WS, MODE, FAST>(p, gnext, r, nvx, nvy, raw, coff);
+                vx = nvx;
+                vy = nvy;
+                if constexpr (!RECOMPUTE) gcur = gnext;
+                continue;
+            }
+        }
         cf x[WS];
         float sa, sb;                      // window sums (for the mean)
         // CAND: the decision band of the lane's window (float bits).  Register-bound tiles keep it in scalar registers, one
@@ -1601,7 +1622,7 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
         int band_s[NBS];
         TPIV_STAMP(0);      // loop head: geometry, next shifts, combine loads
         RowSquares sq;
-        convert_rows<WS, MODE, RBH, FAST, CAND>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile, &sq);
+        convert_rows<WS, MODE, RBH, FAST, CAND, ROLE == 1 ? 1 : 0>(p, g, r, lane, vx, vy, raw, x, sa, sb, tile, &sq);
         TPIV_STAMP(1);      // wait for the rows + conversion / bilinear sampling
         // 64x64 (register-bound): the dequeue issued at the loop head has landed by now; move it to a
         // scalar register (kept in a VGPR to the loop end it would be spilled, and the reload would
@@ -1802,8 +1823,9 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
             // the window index is re-derived from the (wave-uniform) item position, see above
             const int lane_e = fresh_lane();
             const int w_e = lane_e / WS, r_e = lane_e % WS;
-            const int pair_e = fast_div(item, p.groups_magic, p.groups_shift);
-            const int win_raw_e = (item - pair_e * groups) * G::WPW + w_e;
+            const int item_e = real_item(item);
+            const int pair_e = fast_div(item_e, p.groups_magic, p.groups_shift);
+            const int win_raw_e = (item_e - pair_e * groups) * G::WPW + w_e;
             const bool active_e = win_raw_e < N;
             const int win_e = active_e ? win_raw_e : N - 1;
             const size_t fidx_e = (size_t)pair_e * N + win_e;
@@ -1823,6 +1845,11 @@ __device__ __forceinline__ void xcorr_tile_body(const PassParams& p) {
 template <int WS, int MODE, int OCC, bool FAST>
 __global__ __launch_bounds__(64, OCC) void xcorr_tile_kernel(PassParams p) {
     xcorr_tile_body<WS, MODE, OCC, FAST, false>(p);
+}
+// 64x64 CWS, fast-order arithmetic: the instance without the per-pixel staging path, three wavefronts per SIMD (ROLE 1)
+template <int WS, int MODE>
+__global__ __launch_bounds__(64, 3) void xcorr_tile_fastpath_kernel(PassParams p) {
+    xcorr_tile_body<WS, MODE, 3, true, false, 1>(p);
 }
 // float32 first pass of the exact scheme: same transforms, candidate cells out
 template <int WS>
@@ -1928,6 +1955,25 @@ static hipError_t launch_tile(const PassParams& p_in, int n_cu, hipStream_t stre
         }
     }
 #endif
+    if constexpr (tile_split64(WS, MODE)) {
+        // two launches: everything that takes the wide-load path at three wavefronts per SIMD (no per-pixel code in that
+        // instance), then the full kernel over the items it set aside (their number is on the device: the grid is a
+        // resident set, wavefronts without an item leave at once)
+        if (p.slow_list != nullptr && p.slow_count != nullptr) {
+            hipLaunchKernelGGL((xcorr_tile_fastpath_kernel<WS, MODE>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
+            hipError_t e_ = hipGetLastError();
+            if (e_ != hipSuccess) return e_;
+            e_ = hipMemsetAsync(p.work_ctr, 0, TILE_CTR_BYTES, stream);
+            if (e_ != hipSuccess) return e_;
+            PassParams q = p;
+            q.list_mode = 1;
+            long long blocks2 = (long long)n_cu * 8;
+            if (blocks2 > blocks) blocks2 = blocks;
+            blocks2 = (blocks2 + 7) / 8 * 8;
+            hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, OCC, true>), dim3((unsigned)blocks2), dim3(64), 0, stream, q);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((xcorr_tile_kernel<WS, MODE, OCC, true>), dim3((unsigned)blocks), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
