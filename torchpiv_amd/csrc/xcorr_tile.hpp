@@ -695,8 +695,18 @@ __device__ __forceinline__ void issue_rows(const PassParams& p, const ItemGeom& 
                 load_dwords<4>(fb + o_, *reinterpret_cast<uint32_t(*)[4]>(&raw.b[4 * k]));
             }
         } else {
+#ifdef TPIV_EXP_P1LOADS      // timing experiment only (wrong results): TPIV_EXP_P1LOADS 16-byte loads per row and frame
+            load_dwords<4 * TPIV_EXP_P1LOADS>(fa + base, *reinterpret_cast<uint32_t(*)[4 * TPIV_EXP_P1LOADS]>(&raw.a[0]));
+            load_dwords<4 * TPIV_EXP_P1LOADS>(fb + base, *reinterpret_cast<uint32_t(*)[4 * TPIV_EXP_P1LOADS]>(&raw.b[0]));
+#pragma unroll
+            for (int k = 4 * TPIV_EXP_P1LOADS; k < WS / 4; ++k) {
+                raw.a[k] = 0x11213141u * (unsigned)(r + 1 + k);
+                raw.b[k] = 0x31112141u * (unsigned)(r + 3 + k);
+            }
+#else
             load_dwords<WS / 4>(fa + base, raw.a);
             load_dwords<WS / 4>(fb + base, raw.b);
+#endif
         }
     } else if constexpr (MODE == MODE_DWS) {
         // integer shift on the FLAT index (B:213-215): a at idx - (vy*W + vx), b at idx + (...)
@@ -1150,6 +1160,43 @@ __device__ __forceinline__ void convert_rows(const PassParams& p, const ItemGeom
     }
 }
 
+// columns of map row ys (fftshift layout) that B:346-358 zeroes around the first peak m: q = clamp(m + i + WS j),
+// |i|, |j| <= wv -- in row y' the columns mx+i (j = y'-my), mx+i+WS (j = y'-my+1), mx+i-WS (j = y'-my-1), plus the clamps
+template <int WS>
+__device__ __forceinline__ unsigned long long exclusion_row_mask(int m, int ys, int wv) {
+    static_assert(WS <= 64, "one 64-bit mask per row");
+    const int my_ = m / WS, mx_ = m % WS, KD = WS * WS;
+    const int dj = ys - my_;
+    unsigned long long ex = 0ull;
+    auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
+        lo_ = lo_ < 0 ? 0 : lo_;
+        hi_ = hi_ > WS - 1 ? WS - 1 : hi_;
+        if (lo_ > hi_) return 0ull;
+        const unsigned long long ones = (hi_ - lo_ + 1) >= 64 ? ~0ull : ((1ull << (hi_ - lo_ + 1)) - 1ull);
+        return ones << lo_;
+    };
+    if (dj >= -wv && dj <= wv) ex |= span(mx_ - wv, mx_ + wv);
+    if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(mx_ - wv + WS, mx_ + wv + WS);
+    if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx_ - wv - WS, mx_ + wv - WS);
+    if (ys == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;
+    if (ys == WS - 1 && (m + wv + wv * WS) >= KD - 1) ex |= 1ull << (WS - 1);
+    return ex;
+}
+
+// maxima that pass over quiet NaNs (IEEE mode, the default of compute kernels: the maximum of a number and a quiet NaN is the
+// number; all NaN in, NaN out).  Inline assembly: for fmaxf() of a value of unknown origin the compiler adds a canonicalising
+// v_max_f32 x, x per operand.
+__device__ __forceinline__ float max3_skip_nan(float a, float b, float c) {
+    float o;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+    return o;
+}
+__device__ __forceinline__ float max_skip_nan(float a, float b) {
+    float o;
+    asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+
 // ---- peak analysis of one correlation row per lane (B:346-358, B:381-392, B:518) -----------------
 // in: lane (w, r) holds row y = r of its window's circular correlation, value at column x in row[x]
 // (un-shifted coordinates; the callers' copies into `row` are register renames).  Writes the window's 8-float record for finalize_kernel.
@@ -1187,15 +1234,18 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
         if constexpr (SCALED) return __fadd_rn(fmaf(c_, scale, ncs), 1e-7f);
         else return __fadd_rn(__fsub_rn(c_, cmin), 1e-7f);
     };
-    float c[WS];                                      // shifted row: c[x'] = corr - min + eps
-    static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-        constexpr int xsft = decltype(kc)::value;     // ascending shifted column
-        constexpr int xo = (xsft + WS / 2) % WS;
-        const float v = shifted(row[xo]);
-        c[xsft] = v;
-        if constexpr (!SMALLMAP) my_map[ys * G::MAP_PITCH + xsft] = v;
-    });
-    const float rmax = shifted(rraw);                 // = max of the row's c[] (monotonic); every c is >= 1e-7 > 0
+    // The map goes to LDS and through the second-peak scan as RAW values (fftshift column order): `shifted` is monotonic, so
+    // every maximum below is taken over raw values and shifted afterwards, and only the handful of cells that reach the
+    // record are shifted at all (round 5: 2 x WS instructions per lane less; same bits -- max(shifted) = shifted(max), and the
+    // arg-max compares SHIFTED values, so two raw values that round to the same shifted maximum still tie as they do in the
+    // reference's float32 map).
+    if constexpr (!SMALLMAP) {
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int xsft = decltype(kc)::value;     // ascending shifted column
+            my_map[ys * G::MAP_PITCH + xsft] = row[(xsft + WS / 2) % WS];
+        });
+    }
+    const float rmax = shifted(rraw);                 // = max of the row's shifted values (monotonic); every one is >= 1e-7 > 0
     const float gmax = grp_reduce<WS>(rmax, [](float a, float b) TPIV_LAMBDA_INLINE { return fmaxf(a, b); });
     auto imin = [](int a, int b) TPIV_LAMBDA_INLINE { return a < b ? a : b; };
     // arg-max = FIRST flat index holding the maximum (torch.argmax, B:383): the smallest row y' whose
@@ -1206,8 +1256,10 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
         wave_sync();
         const int slot = ys - row0;
         if (slot >= 0 && slot <= 2) {
-#pragma unroll
-            for (int k = 0; k < WS; ++k) my_map[slot * G::MAP_PITCH + k] = c[k];
+            static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+                constexpr int xsft = decltype(kc)::value;
+                my_map[slot * G::MAP_PITCH + xsft] = row[(xsft + WS / 2) % WS];
+            });
         }
     }
     wave_sync();                                  // map complete
@@ -1216,10 +1268,12 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
         int yy = ys;                 // opaque: keeps the WS store addresses out of the item loop's registers
         asm volatile("" : "+v"(yy));
         float* d = p.dbg_corr + fidx * WS * WS + yy * WS;
-#pragma unroll
-        for (int k = 0; k < WS; ++k) d[k] = c[k];
+        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int xsft = decltype(kc)::value;
+            d[xsft] = shifted(row[(xsft + WS / 2) % WS]);
+        });
     }
-    const int xwin = grp_reduce<WS>(my_map[(ywin - row0) * G::MAP_PITCH + r] == gmax ? r : WS - 1, imin);   // lane r = column r
+    const int xwin = grp_reduce<WS>(shifted(my_map[(ywin - row0) * G::MAP_PITCH + r]) == gmax ? r : WS - 1, imin);   // lane r = column r
 
     // ---- second peak: maximum outside the (2*wv+1)^2 FLAT-index neighbourhood (B:346-358):
     //      excluded q = clamp(m + i + WS*j), |i|,|j| <= wv, i.e. in row y' the columns
@@ -1228,34 +1282,26 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
     const int m = ywin * WS + xwin;
     const int KD = WS * WS;
     const int wv = p.val_win;
-    const int my_ = ywin, mx_ = xwin;
-    int smax = 0;                                     // float bits; positive floats order like ints
+    float sraw;                                       // maximum of the raw values outside the neighbourhood; NaN = none left
     {
-        const int dj = ys - my_;
-        unsigned long long ex = 0ull;                 // bit x' set = excluded in this lane's row
-        auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {     // bits lo_..hi_ clipped to the row
-            lo_ = lo_ < 0 ? 0 : lo_;
-            hi_ = hi_ > WS - 1 ? WS - 1 : hi_;
-            if (lo_ > hi_) return 0ull;
-            const unsigned long long ones = (hi_ - lo_ + 1) >= 64 ? ~0ull : ((1ull << (hi_ - lo_ + 1)) - 1ull);
-            return ones << lo_;
-        };
-        if (dj >= -wv && dj <= wv) ex |= span(mx_ - wv, mx_ + wv);
-        if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(mx_ - wv + WS, mx_ + wv + WS);
-        if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx_ - wv - WS, mx_ + wv - WS);
-        if (ys == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;                       // clamp to 0
-        if (ys == WS - 1 && (m + wv + wv * WS) >= KD - 1) ex |= 1ull << (WS - 1);  // clamp to KD-1
+        const unsigned long long ex = exclusion_row_mask<WS>(m, ys, wv);      // bit x' set = excluded in this lane's row
         const int exl = (int)(unsigned)ex, exh = (int)(unsigned)(ex >> 32);
-        static_for<0, WS>([&](auto kc) TPIV_LAMBDA_INLINE {
-            constexpr int xsft = decltype(kc)::value;
-            // sign-extended exclusion bit: 0 keeps the value, -1 turns it into a negative integer
-            const int kill = __builtin_amdgcn_sbfe(xsft < 32 ? exl : exh, xsft & 31, 1);
-            const int cand = __float_as_int(c[xsft]) | kill;
-            smax = cand > smax ? cand : smax;
+        // an excluded value becomes the quiet NaN 0xffffffff (OR with the sign-extended exclusion bit), which v_max3_f32 passes
+        // over (IEEE mode: the maximum of a number and a quiet NaN is the number).  Issued as inline assembly: for fmaxf() of a
+        // value of unknown origin the compiler adds a canonicalising v_max_f32 x, x per element.
+        float acc = __int_as_float(-1);
+        static_for<0, WS / 2>([&](auto kc) TPIV_LAMBDA_INLINE {
+            constexpr int x0 = 2 * decltype(kc)::value, x1 = x0 + 1;
+            const int k0 = __builtin_amdgcn_sbfe(x0 < 32 ? exl : exh, x0 & 31, 1);
+            const int k1 = __builtin_amdgcn_sbfe(x1 < 32 ? exl : exh, x1 & 31, 1);
+            const float v0 = __int_as_float(__float_as_int(row[(x0 + WS / 2) % WS]) | k0);
+            const float v1 = __int_as_float(__float_as_int(row[(x1 + WS / 2) % WS]) | k1);
+            acc = max3_skip_nan(acc, v0, v1);
         });
+        sraw = acc;
     }
-    smax = grp_reduce<WS>(smax, [](int a, int b) TPIV_LAMBDA_INLINE { return a > b ? a : b; });
-    const float second_v = smax > 0 ? __int_as_float(smax) : gmax;
+    sraw = grp_reduce<WS>(sraw, [](float a, float b) TPIV_LAMBDA_INLINE { return max_skip_nan(a, b); });
+    const float second_v = sraw != sraw ? gmax : shifted(sraw);
 
     // ---- hand-off to finalize_kernel (piv_launch.hip): the float64 logarithms, divisions and the
     //      multipass combine of B:385-422 / B:728-738 need ONE lane per window, so they run in a
@@ -1271,7 +1317,7 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
         q = (r == 2) ? right : q;
         q = (r == 3) ? top : q;
         q = (r == 4) ? bot : q;
-        float outv = my_map[(q / WS - row0) * G::MAP_PITCH + (q % WS)];     // rows ywin-1..ywin+1 only
+        float outv = shifted(my_map[(q / WS - row0) * G::MAP_PITCH + (q % WS)]);     // rows ywin-1..ywin+1 only
         outv = (r == 5) ? second_v : outv;
         outv = (r == 6) ? __int_as_float(m) : outv;
         outv = (r == 7) ? __int_as_float(dead ? 1 : 0) : outv;
@@ -1291,29 +1337,6 @@ __device__ __forceinline__ void peak_analysis(const PassParams& p, const float (
 // through the float64 transform (xcorr_f64_split_kernel<64, true>).  Dead windows (B:513: zero mean) are marked -2.
 // One window per wavefront (WS = 64): every ballot below spans exactly the window.
 // (EXACT_BAND, EXACT_MIN_CONTRAST, EXACT_MAX_SECOND / _MIN: piv_kernels.h)
-
-// columns of map row ys (fftshift layout) that B:346-358 zeroes around the first peak m: q = clamp(m + i + WS j),
-// |i|, |j| <= wv -- in row y' the columns mx+i (j = y'-my), mx+i+WS (j = y'-my+1), mx+i-WS (j = y'-my-1), plus the clamps
-template <int WS>
-__device__ __forceinline__ unsigned long long exclusion_row_mask(int m, int ys, int wv) {
-    static_assert(WS <= 64, "one 64-bit mask per row");
-    const int my_ = m / WS, mx_ = m % WS, KD = WS * WS;
-    const int dj = ys - my_;
-    unsigned long long ex = 0ull;
-    auto span = [&](int lo_, int hi_) TPIV_LAMBDA_INLINE {
-        lo_ = lo_ < 0 ? 0 : lo_;
-        hi_ = hi_ > WS - 1 ? WS - 1 : hi_;
-        if (lo_ > hi_) return 0ull;
-        const unsigned long long ones = (hi_ - lo_ + 1) >= 64 ? ~0ull : ((1ull << (hi_ - lo_ + 1)) - 1ull);
-        return ones << lo_;
-    };
-    if (dj >= -wv && dj <= wv) ex |= span(mx_ - wv, mx_ + wv);
-    if (dj + 1 >= -wv && dj + 1 <= wv) ex |= span(mx_ - wv + WS, mx_ + wv + WS);
-    if (dj - 1 >= -wv && dj - 1 <= wv) ex |= span(mx_ - wv - WS, mx_ + wv - WS);
-    if (ys == 0 && (m - wv - wv * WS) <= 0) ex |= 1ull;
-    if (ys == WS - 1 && (m + wv + wv * WS) >= KD - 1) ex |= 1ull << (WS - 1);
-    return ex;
-}
 
 // band_abs: the proven part of the decision band, 2 Gamma(WS) (1 + 1/16) E+ of this lane's window (piv_kernels.h, "The band")
 template <int WS>
