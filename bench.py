@@ -280,7 +280,7 @@ def e2e_cases(n, workers, files=True, budget_s=150.0):
 
 
 def e2e_block(r, log, n, workers):
-    return {"unit": "pairs/s", "pairs_per_case": r.get("pairs_streamed", n), "distinct_pairs": n, "batch": {"resident": r.get("resident_batch", 32), "files": r.get("files_batch", 32)}, "fill_workers": workers, "precision": r.get("precision", "exact"),
+    return {"unit": "pairs/s", "pairs_per_case": r.get("pairs_streamed", n), "pairs_per_resident_case": r.get("resident_pairs_streamed", n), "distinct_pairs": n, "batch": {"resident": r.get("resident_batch", 32), "files": r.get("files_batch", 32)}, "fill_workers": workers, "precision": r.get("precision", "exact"),
             "what": "generator end to end at 4 MP, wind=64 ov=32 2-pass CWS: passes + device post-validation + counted host "
                     "fallbacks + flip/scale + yield (ResidentPIV / OfflinePIV.batched)",
             "resident_clean_all_dropped": r.get("clean"), "resident_straight_runs": r.get("runs"),
@@ -288,7 +288,7 @@ def e2e_block(r, log, n, workers):
             "bmp_files_generator_call": r.get("files_call"), "trials": r.get("trials"),
             "host_cpu_s_per_pair": r.get("host_cpu_s_per_pair"),
             "host": host_block(workers),
-            "note": "every figure is the median of three runs of pairs_per_case pairs behind one untimed run (the distinct pairs "
+            "note": "every figure is the median of three runs of pairs_per_case (files) / pairs_per_resident_case pairs behind one untimed run (the distinct pairs "
                     "streamed repeatedly); host_cpu_s_per_pair = user + system CPU seconds of the process, its threads and "
                     "its fill-worker processes per pair over the timed runs",
             "post_validation": r.get("stats"), "log": log}

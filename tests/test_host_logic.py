@@ -477,6 +477,37 @@ def test_diamond_short_cut_of_the_hole_fill_is_bit_identical():
     assert taken > 200 and general > 10
 
 
+def test_fill_workers_keep_the_order_of_the_jobs(monkeypatch):
+    """The fill-worker processes of the generator (torchpiv_amd._qhull.FillWorkers): tickets collected in any order, light
+    batches left in flight while a heavy one (exchanged on the spot, job by job) passes, answers equal to the in-process fill."""
+    from torchpiv_amd._qhull import FillWorkers, qhull_fill
+    rng = np.random.default_rng(0)
+
+    def job(nh):
+        hole = np.zeros((12, 12), bool)
+        idx = rng.choice(100, nh, replace=False)
+        hole[1 + idx // 10, 1 + idx % 10] = True
+        pts = np.argwhere(~hole)
+        return pts, rng.normal(size=(pts.shape[0], 2)), np.argwhere(hole)
+
+    monkeypatch.setattr(FillWorkers, "LIGHT", 16000)
+    fw = FillWorkers(3)
+    try:
+        light_a, light_b, heavy = [job(3) for _ in range(10)], [job(5) for _ in range(7)], [job(40) for _ in range(5)] * 3
+        batches = [light_a, light_b, heavy, light_a[:2], []]
+        tickets = [fw.submit(b) for b in batches]
+        assert fw._order and tickets[2] in fw._ready                 # two kinds of ticket really were in play
+        for k in (3, 0, 4, 2, 1):
+            got = fw.collect(tickets[k])
+            assert len(got) == len(batches[k])
+            for g_, j in zip(got, batches[k]):
+                assert np.array_equal(g_, qhull_fill(*j), equal_nan=True)
+        assert not fw._order and not fw._ready and not fw._parts
+    finally:
+        fw.terminate()
+    assert all(not p.is_alive() for p in fw.procs) and not fw.conns
+
+
 def test_batch_reader_agrees_with_the_per_file_path(tmp_path):
     """tpiv_read_files + the vectorised header sweep (io.stage_batch) against io.stage_raw file by file: same bytes
     in the slot, same layout and grey table for the plain BMPs; everything else is handed back (None)."""

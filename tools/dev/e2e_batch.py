@@ -6,14 +6,15 @@ import torchpiv_amd as T
 import e2e_generator as E
 
 if __name__ == "__main__":
-    n, reps = 128, 8
+    n, reps = 128, 32
     for kind in ("spots", "clean"):
         A, B = E.make_frames(n, 2048, 2048, kind)
-        for batch in (32, 64, 128):
+        for batch, depth in ((32, 1), (64, 1), (64, 2), (128, 1), (128, 2)):
             for workers in (8,):
                 piv = T.ResidentPIV(A, B, 64, 32, multipass=2, multipass_mode="CWS")
                 piv.fill_workers = workers
+                piv.resident_depth = depth
                 E.rate(piv.batched(batch), n)
                 r, k, rs, _cpu = E.rate3(lambda: piv.batched(batch, indices=list(range(n)) * reps), n * reps)
-                print(f"{kind} batch {batch:3d} workers {workers:2d}: {r:8.1f} pairs/s  {rs}", flush=True)
+                print(f"{kind} batch {batch:3d} depth {depth} workers {workers:2d}: {r:8.1f} pairs/s  {rs}", flush=True)
                 piv.close()

@@ -26,18 +26,28 @@ def timed(obj, name, label=None):
 
 if __name__ == "__main__":
     n, workers = int(sys.argv[1]) if len(sys.argv) > 1 else 256, int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    A, Bf = E.make_frames(n, 2048, 2048, "spots")
+    BATCH = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+    KIND = sys.argv[4] if len(sys.argv) > 4 else "spots"
+    DISTINCT = min(n, 128)
+    A, Bf = E.make_frames(DISTINCT, 2048, 2048, KIND)
+    order = [i % DISTINCT for i in range(n)]
     piv = T.ResidentPIV(A, Bf, 64, 32, multipass=2, multipass_mode="CWS")
     piv.fill_workers = workers
-    sum(1 for _ in piv.batched(32))
+    if len(sys.argv) > 5:
+        piv.resident_depth = int(sys.argv[5])
+    sum(1 for _ in piv.batched(BATCH, indices=order))
     timed(piv, "_post_submit")
-    timed(piv, "_post_collect")
+    if getattr(piv, "_plan", None) is not None:
+        timed(piv._plan, "run", "plan.run (launch)")
+    timed(piv, "_post_extract")
+    timed(piv, "_post_complete")
     timed(piv, "_finish_batch")
     timed(engine, "postval")
     real_fill = B.qhull_fill_many
     pool = piv._fill_pool()
     if pool is not None:
-        timed(pool, "map", "pool.map")
+        timed(pool, "submit", "workers.submit")
+        timed(pool, "collect", "workers.collect")
     ev_sync = torch.cuda.Event.synchronize
 
     def sync(self):
@@ -47,10 +57,10 @@ if __name__ == "__main__":
     torch.cuda.Event.synchronize = sync
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    k = sum(1 for _ in piv.batched(32))
+    k = sum(1 for _ in piv.batched(BATCH, indices=order))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"{n / dt:.0f} pairs/s, {dt * 1e3 / (n / 32):.2f} ms per batch of 32, yielded {k}")
+    print(f"{n / dt:.0f} pairs/s, {dt * 1e3 / (n / BATCH):.2f} ms per batch of {BATCH}, yielded {k}")
     for key in T_:
-        print(f"  {key:20s} {T_[key] * 1e3 / (n / 32):7.2f} ms per batch  ({N_[key]} calls)")
+        print(f"  {key:20s} {T_[key] * 1e3 / (n / BATCH):7.2f} ms per batch  ({N_[key]} calls)")
     piv.close()

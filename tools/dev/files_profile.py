@@ -57,7 +57,8 @@ if __name__ == "__main__":
     timed(engine, "bmp_unpack")
     pool = piv._fill_pool()
     if pool is not None:
-        timed(pool, "map", "pool.map")
+        timed(pool, "submit", "workers.submit")
+        timed(pool, "collect", "workers.collect")
     ev_sync = torch.cuda.Event.synchronize
 
     def sync(self):

@@ -65,14 +65,18 @@ def rate3(make_gen, n, trials=3):
 
 
 def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True, budget_s=None, precision="exact", reps=8,
-         resident_batch=64):
+         resident_batch=64, resident_reps=32):
     """Rates in pairs/s per case; `files` adds the BMP cases (skipped once `budget_s` seconds are spent).  Every case
     streams n * reps pairs (the n distinct pairs `reps` times over: 128 pairs alone last some 20 ms, which measures the
-    pipeline's fill and drain, not its rate); the file cases hard-link the n pairs' files under n * reps names."""
+    pipeline's fill and drain, not its rate); the file cases hard-link the n pairs' files under n * reps names.  The resident
+    cases stream n * resident_reps pairs: the host side is a three-stage pipeline (launch, census + triangulations handed to the
+    workers, patch + hand-out), and with 64 pairs per launch 1024 pairs are 16 launches, two of them fill and drain -- round 5
+    measured 13.6 k pairs/s over 1024 pairs and 15.3 k over 2048 with the same code."""
     # (resident frames: 64 pairs per launch -- tools/dev/e2e_batch.py, round 5: isolated spots 13.7 k pairs/s at 32, 14.2 k at 64,
     #  13.1 k at 128; the file path is bound by the PCIe link at any batch size and keeps 32, the staging buffers' size)
-    out = {"precision": precision, "pairs_streamed": n * reps, "resident_batch": resident_batch, "files_batch": batch}
-    order = list(range(n)) * reps
+    out = {"precision": precision, "pairs_streamed": n * reps, "resident_pairs_streamed": n * resident_reps,
+           "resident_batch": resident_batch, "files_batch": batch}
+    order = list(range(n)) * resident_reps
     t_start = time.perf_counter()
     for kind in ("clean", "runs", "spots"):
         A, B = make_frames(n, H, W, kind)
@@ -80,13 +84,13 @@ def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True,
         piv.fill_workers = workers
         rate(piv.batched(resident_batch), n)             # warm-up: plan creation
         piv.reset_stats()
-        r, k, rs, cpu = rate3(lambda: piv.batched(resident_batch, indices=order), n * reps)
+        r, k, rs, cpu = rate3(lambda: piv.batched(resident_batch, indices=order), n * resident_reps)
         out[kind] = r
         out.setdefault("trials", {})[kind] = rs
         out.setdefault("host_cpu_s_per_pair", {})[kind] = cpu
         st_ = {k_: v_ // 4 for k_, v_ in piv.stats.items()}
         out.setdefault("stats", {})[kind] = dict(st_, yielded=k)
-        print(f"resident {kind:6s}: {r:8.1f} pairs/s, median of {rs} ({k} of {n * reps} yielded), host CPU {cpu * 1e6:.0f} us/pair  {st_}")
+        print(f"resident {kind:6s}: {r:8.1f} pairs/s, median of {rs} ({k} of {n * resident_reps} yielded), host CPU {cpu * 1e6:.0f} us/pair  {st_}")
         over = budget_s is not None and time.perf_counter() - t_start > budget_s
         if kind == "spots" and files and not over:
             from PIL import Image

@@ -133,3 +133,100 @@ def blas_one_thread():
 def qhull_fill_many(jobs):
     """[qhull_fill(*job) for job in jobs] -- one task of the worker pool carries several pairs (IPC per task, not per pair)."""
     return [qhull_fill(*job) for job in jobs]
+
+
+def worker_loop(conn):
+    """Body of a fill-worker process (FillWorkers below): lists of jobs in, lists of qhull_fill results out, one message at a
+    time, until the pipe closes or a None arrives."""
+    single_thread_blas()
+    while True:
+        try:
+            jobs = conn.recv()
+        except (EOFError, OSError):
+            break
+        if jobs is None:
+            break
+        conn.send(qhull_fill_many(jobs))
+    conn.close()
+
+
+def _job_bytes(part):
+    return sum(a.nbytes for job in part for a in job)
+
+
+class FillWorkers:
+    """`n` worker processes behind one duplex pipe each.  Unlike multiprocessing.Pool there are no handler threads in the
+    calling process (they compete with it for the GIL: an asynchronous Pool.map made the whole generator slower) and the
+    exchange is split: submit(jobs) hands the jobs of a batch out and returns at once, collect(ticket) reads the answers --
+    the caller launches the next batch and finishes the previous one in between (backend.OfflinePIV._post_pipeline).
+    Messages beyond LIGHT bytes could fill a pipe while its reader is itself blocked writing, so a batch that holds one is
+    exchanged on the spot, one message per worker at a time (send to all, then read from all: no cycle of blocked writers)."""
+    LIGHT = 24 * 1024            # bytes per message that may stay in flight (two batches outstanding: well inside a socket buffer)
+
+    def __init__(self, n):
+        import multiprocessing as mp
+        ctx = mp.get_context("spawn")   # the workers never see the caller's HIP state
+        self.conns, self.procs = [], []
+        for _ in range(n):
+            mine, theirs = ctx.Pipe(duplex=True)
+            p = ctx.Process(target=worker_loop, args=(theirs,), daemon=True)
+            p.start()
+            theirs.close()
+            self.conns.append(mine)
+            self.procs.append(p)
+        self.n = n
+        self._order, self._parts, self._ready = [], {}, {}      # tickets in flight (oldest first), their message counts, answers read early
+
+    def _recv(self, w):
+        try:
+            return self.conns[w].recv()
+        except (EOFError, OSError) as e:
+            raise RuntimeError(f"fill worker {w} died (exit code {self.procs[w].exitcode})") from e
+
+    def _drain(self, upto=None):
+        """Read the answers of the outstanding tickets, oldest first (every pipe is first in, first out), up to ticket `upto`."""
+        while self._order and (upto is None or upto in self._order):
+            t = self._order.pop(0)
+            self._ready[t] = [s for w in range(self._parts.pop(t)) for s in self._recv(w)]
+
+    def submit(self, jobs):
+        """Ticket for collect(): the jobs cut into one run per worker (the order of the jobs is the order of the answers)."""
+        t = self._next = getattr(self, "_next", 0) + 1
+        per = max(1, -(-len(jobs) // self.n))
+        parts = [jobs[k:k + per] for k in range(0, len(jobs), per)]
+        if all(_job_bytes(p_) <= self.LIGHT for p_ in parts):
+            for w, p_ in enumerate(parts):
+                self.conns[w].send(p_)
+            self._order.append(t)
+            self._parts[t] = len(parts)
+            return t
+        # a heavy batch: what is still in flight is read first (its answers sit in front in every pipe), then single jobs are
+        # exchanged now, one message per worker and round
+        self._drain()
+        out = []
+        for k in range(0, len(jobs), self.n):
+            rnd = jobs[k:k + self.n]
+            for w, j in enumerate(rnd):
+                self.conns[w].send([j])
+            for w in range(len(rnd)):
+                out += self._recv(w)
+        self._ready[t] = out
+        return t
+
+    def collect(self, ticket):
+        if ticket not in self._ready:
+            self._drain(ticket)
+        return self._ready.pop(ticket)
+
+    def terminate(self):
+        for c in self.conns:
+            try:
+                c.send(None)
+                c.close()
+            except (OSError, ValueError, BrokenPipeError):
+                pass
+        for p in self.procs:
+            p.join(timeout=1.0)
+            if p.is_alive():
+                p.terminate()
+        self.conns, self.procs = [], []

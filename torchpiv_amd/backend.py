@@ -420,17 +420,17 @@ class OfflinePIV:
         return b
 
     def _fill_pool(self):
+        """The fill-worker processes (_qhull.FillWorkers), started on first use and again when fill_workers changes."""
         if self.fill_workers <= 0:
             return None
         pool = getattr(self, "_pool", None)
         if pool is None or getattr(self, "_pool_size", 0) != self.fill_workers:
-            import multiprocessing as mp
             if pool is not None:
                 pool.terminate()
-            # spawn: the workers never see this process's HIP state; they only run scipy on small arrays (with ONE BLAS
+            # spawned: the workers never see this process's HIP state; they only run scipy on small arrays (with ONE BLAS
             # thread each: _qhull.single_thread_blas)
-            from ._qhull import single_thread_blas
-            self._pool = pool = mp.get_context("spawn").Pool(self.fill_workers, initializer=single_thread_blas)
+            from ._qhull import FillWorkers
+            self._pool = pool = FillWorkers(self.fill_workers)
             self._pool_size = self.fill_workers
         return pool
 
@@ -496,7 +496,9 @@ class OfflinePIV:
     def _post_extract(self, ticket):
         """Host half, first stage: drop decisions from the census; the pairs that hold an ambiguous or wide hole
         (counted) arrive with their ring points, values and hole cells already cut out (tpiv_postval_compact) and go to
-        the triangulation -- in worker processes when fill_workers > 0.  Returns the state _post_complete takes."""
+        the triangulation -- in worker processes when fill_workers > 0: the jobs are handed out here and the answers read
+        by _post_complete, so whatever the caller does in between (the next launch, the batch before) overlaps them.
+        Returns the state _post_complete takes."""
         done, host, keep_alive = ticket
         done.synchronize()
         cnt = host["counts"].numpy().astype(np.int64)                # [n, 4] holes, ring, ambiguous, general
@@ -531,11 +533,10 @@ class OfflinePIV:
             state["holes"] = [j[2] for j in jobs]
             pool = self._fill_pool()
             if pool is not None:
-                per = max(1, -(-len(jobs) // (2 * self.fill_workers)))          # two tasks per worker and batch
-                # (synchronous: with map_async the pool's handler threads compete with this thread for the GIL and
-                #  the whole host side got slower -- 6.5 k -> 4.8 k pairs/s)
-                state["sols"] = [s_ for part in pool.map(qhull_fill_many, [jobs[k:k + per] for k in range(0, len(jobs), per)])
-                                 for s_ in part]
+                # (round 5: own worker processes behind pipes.  multiprocessing.Pool.map was synchronous here -- with map_async
+                #  the pool's handler threads compete with this thread for the GIL and the whole host side got slower,
+                #  6.5 k -> 4.8 k pairs/s -- and a batch of 64 pairs waited 2-4 ms for its triangulations)
+                state["pending"] = (pool, pool.submit(jobs))
             else:
                 if not getattr(OfflinePIV, "_blas_limited", False):
                     from ._qhull import blas_one_thread
@@ -550,6 +551,9 @@ class OfflinePIV:
         cell -- into the finished fields (and into the raw ones when they were asked for).  Returns the state with the
         per-pair keep flags (False: dropped)."""
         keep, need, host = state["keep"].copy(), state["need"], state["host"]
+        if "pending" in state:
+            pool, t_ = state.pop("pending")
+            state["sols"] = pool.collect(t_)
         if need.size:
             st = self.stats
             fu, fv = host["fu"].numpy(), host["fv"].numpy()
@@ -602,18 +606,24 @@ class OfflinePIV:
 
     def _post_pipeline(self, x, y, depth=1):
         """The host side of batched() as a pipeline: push(meta, ticket) after every launch returns the finished
-        entries [(meta, per-pair results)] of the batch pushed `depth` launches before -- while the GPU works on batch k,
-        the census, the triangulations (worker pool) and the patching of batch k - depth run here.  The file path uses
+        entries [(meta, per-pair results)] of the batch pushed `depth` + 1 launches before -- while the GPU works on batch k,
+        the census of batch k - depth is taken and its triangulations go to the worker processes; their answers are read,
+        patched in and handed out one push later.  The file path uses
         depth 2: a batch's upload (longer than its passes) then overlaps the passes of the batch before instead of being
         waited for.  flush() drains."""
-        waiting = []
+        waiting, extracted = [], []
 
-        def step():
+        def step(drain=False):
+            # the census of the next batch first: it waits for the GPU, and behind that wait its triangulations go to the
+            # workers; then the batch before it, whose triangulations were handed out one step ago and have had that whole
+            # step (the wait included) to finish, is patched and handed out
             out = []
             if waiting:
                 meta, ticket = waiting.pop(0)
-                res = self._finish_batch(self._post_complete(self._post_extract(ticket)), x, y) if ticket is not None else []
-                out.append((meta, res))
+                extracted.append((meta, self._post_extract(ticket) if ticket is not None else None))
+            if extracted and (len(extracted) > 1 or (drain and not waiting)):
+                meta, state = extracted.pop(0)
+                out.append((meta, self._finish_batch(self._post_complete(state), x, y) if state is not None else []))
             return out
 
         class Pipe:
@@ -624,8 +634,8 @@ class OfflinePIV:
 
             def flush(_):
                 out = []
-                while waiting:
-                    out += step()
+                while waiting or extracted:
+                    out += step(drain=True)
                 return out
         return Pipe()
 
@@ -886,6 +896,12 @@ class ResidentPIV(OfflinePIV):
     def frame_shape(self):
         return tuple(self._A.shape[1:]) if len(self) else None
 
+    # launches in flight before a batch's census is read.  Two: the copies of a batch's results run on a stream of their own,
+    # as kernels (rocprofv3 shows __amd_rocclr_copyBuffer), and the passes of the NEXT batch leave them no registers on any CU
+    # until they end -- with one launch in flight the host got a batch's census when the GPU had just run dry (round 5: GPU
+    # timeline of the 'isolated spots' case, 0.8 ms idle per 64 pairs)
+    resident_depth = 2
+
     def batched(self, batch_size: int = 32, indices=None) -> Generator:
         idx = list(range(len(self))) if indices is None else list(indices)
         if not idx:
@@ -894,8 +910,7 @@ class ResidentPIV(OfflinePIV):
         plan = self._get_plan(H, W, max_batch=batch_size)
         w, o, _, _ = plan.geometry[-1]
         x, y = get_coordinates((H, W), w, o)
-        contiguous = idx == list(range(idx[0], idx[0] + len(idx)))
-        pipe = self._post_pipeline(x, y)
+        pipe = self._post_pipeline(x, y, depth=self.resident_depth)
 
         def emit(finished):
             for chunk_ids, res in finished:
@@ -905,7 +920,9 @@ class ResidentPIV(OfflinePIV):
 
         for s in range(0, len(idx), batch_size):
             chunk = idx[s:s + batch_size]
-            if contiguous:
+            # a run of consecutive pairs is a view of the resident frames; anything else is gathered (a copy of 2 x 4 MB per pair:
+            # 0.36 ms per 64 pairs at 4 MP -- the check is per launch, so a stream that repeats or skips stays copy-free per run)
+            if chunk[-1] - chunk[0] == len(chunk) - 1 and chunk == list(range(chunk[0], chunk[0] + len(chunk))):
                 A, B = self._A[chunk[0]:chunk[0] + len(chunk)], self._B[chunk[0]:chunk[0] + len(chunk)]
             else:
                 sel = torch.tensor(chunk, device=self._device)
