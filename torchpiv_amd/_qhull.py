@@ -34,32 +34,28 @@ def _diamond_fill(tri, points, values, targets):
     cannot be read (the caller then takes the general path)."""
     pts = np.asarray(points, dtype=np.int64)
     tg = np.asarray(targets, dtype=np.int64)
-    if pts.ndim != 2 or pts.shape[1] != 2 or tg.shape[0] == 0:
-        return None
-    K = int(max(pts[:, 1].max(), tg[:, 1].max())) + 3
-    key = pts[:, 0] * K + pts[:, 1]
-    order = np.argsort(key, kind="stable")
-    skey = key[order]
-
-    def index_of(rc):
-        k_ = rc[:, 0] * K + rc[:, 1]
-        pos = np.searchsorted(skey, k_)
-        pos = np.minimum(pos, skey.size - 1)
-        ok = skey[pos] == k_
-        return order[pos], ok
-
-    iN, okN = index_of(tg + (-1, 0))
-    iS, okS = index_of(tg + (1, 0))
-    iW, okW = index_of(tg + (0, -1))
-    iE, okE = index_of(tg + (0, 1))
-    if not (okN & okS & okW & okE).all():
-        return None
     n = pts.shape[0]
-    sp = tri.simplices.astype(np.int64)
-    e = np.concatenate([sp[:, [0, 1]], sp[:, [1, 2]], sp[:, [0, 2]]])
-    ekeys = np.unique(np.minimum(e[:, 0], e[:, 1]) * n + np.maximum(e[:, 0], e[:, 1]))
-    ns = np.isin(np.minimum(iN, iS) * n + np.maximum(iN, iS), ekeys)
-    ew = np.isin(np.minimum(iW, iE) * n + np.maximum(iW, iE), ekeys)
+    if pts.ndim != 2 or pts.shape[1] != 2 or tg.shape[0] == 0 or n > 2048:
+        return None               # (thousands of ring points: wide holes are among them anyway -- the general path)
+    # point index by lattice cell (dense table with a one-cell margin: the neighbour look-ups below need no range checks),
+    # edges of the triangulation as a dense n x n table: on two dozen points numpy's set routines (isin, unique, searchsorted)
+    # cost more than the triangulation itself
+    r0, c0 = int(min(pts[:, 0].min(), tg[:, 0].min())) - 1, int(min(pts[:, 1].min(), tg[:, 1].min())) - 1
+    R, K = int(max(pts[:, 0].max(), tg[:, 0].max())) - r0 + 2, int(max(pts[:, 1].max(), tg[:, 1].max())) - c0 + 2
+    if R * K > (1 << 22):
+        return None
+    lut = np.full((R, K), -1, dtype=np.int64)
+    lut[pts[:, 0] - r0, pts[:, 1] - c0] = np.arange(n)
+    tr, tc = tg[:, 0] - r0, tg[:, 1] - c0
+    iN, iS, iW, iE = lut[tr - 1, tc], lut[tr + 1, tc], lut[tr, tc - 1], lut[tr, tc + 1]
+    if min(iN.min(), iS.min(), iW.min(), iE.min()) < 0:
+        return None
+    sp = tri.simplices
+    adj = np.zeros((n, n), dtype=bool)
+    for i, j in ((0, 1), (1, 2), (0, 2)):
+        adj[sp[:, i], sp[:, j]] = True
+        adj[sp[:, j], sp[:, i]] = True
+    ns, ew = adj[iN, iS], adj[iW, iE]
     if not (ns ^ ew).all():
         return None
     a = np.where(ns, iN, iW)
