@@ -429,6 +429,65 @@ def test_resident_generator_equals_host_post_validation(eng):
     plan.close()
 
 
+def test_generator_with_fill_workers_equals_the_in_process_path(eng, monkeypatch):
+    """fill_workers > 0 (round 5: own worker processes, jobs handed out and answers collected one pipeline step apart) yields
+    the bits of the in-process path: over several launches, with isolated holes and wide ones, with every batch forced through
+    the on-the-spot exchange of heavy messages, after a generator that was abandoned with answers still in the pipes, and
+    with the number of workers changed in between."""
+    import torchpiv_amd as T
+    from torchpiv_amd import synth, _qhull
+    H, W = 512, 640
+    rng = np.random.default_rng(5)
+    A, B = [], []
+    for i in range(10):
+        a, b = synth.make_pair(H, W, 700 + i, kind=("wavy", "vortex")[i % 2], noise=2.0)
+        for _ in range(3):                             # isolated dead windows (co-circular holes: Qhull's diagonal)
+            y, x = int(rng.integers(40, H - 80)), int(rng.integers(40, W - 80))
+            a[y:y + 20, x:x + 20] = 0
+            b[y:y + 20, x:x + 20] = 0
+        if i % 4 == 1:                                 # and a blob (a wide hole: the general path)
+            a[300:340, 100:230] = 0
+            b[300:340, 100:230] = 0
+        A.append(a)
+        B.append(b)
+    A, B = torch.stack(A).cuda(), torch.stack(B).cuda()
+
+    def run(workers, batch):
+        piv = T.ResidentPIV(A, B, 32, 16, multipass=2, multipass_mode="CWS")
+        piv.fill_workers = workers
+        try:
+            out = {i: (u.copy(), v.copy()) for i, x, y, u, v in piv.batched(batch)}
+            return out, dict(piv.stats), piv
+        except Exception:
+            piv.close()
+            raise
+
+    want, st0, p0 = run(0, 3)
+    p0.close()
+    assert st0["host_fallback"] >= 8 and st0["host_fallback_wide_holes"] >= 2 and len(want) == 10
+    got, st1, piv = run(2, 3)
+    try:
+        def same(res):
+            assert sorted(res) == sorted(want)
+            for i in want:
+                assert np.array_equal(res[i][0], want[i][0], equal_nan=True) and np.array_equal(res[i][1], want[i][1], equal_nan=True), i
+        same(got)
+        assert {k: st1[k] for k in st0} == st0
+        # abandoned after the first pair: answers of later launches stay in the pipes; the next run must not read them as its own
+        g = piv.batched(2)
+        next(g)
+        g.close()
+        same({i: (u.copy(), v.copy()) for i, x, y, u, v in piv.batched(4)})
+        # every message "heavy": exchanged on the spot, job by job
+        monkeypatch.setattr(_qhull.FillWorkers, "LIGHT", 0)
+        same({i: (u.copy(), v.copy()) for i, x, y, u, v in piv.batched(5)})
+        monkeypatch.undo()
+        piv.fill_workers = 3                           # another number of workers: the old ones go, new ones start
+        same({i: (u.copy(), v.copy()) for i, x, y, u, v in piv.batched(10)})
+    finally:
+        piv.close()
+
+
 @pytest.mark.parametrize("ws", [16, 32, 64])
 def test_fast_staging_close_to_reference_order(eng, ws):
     """precision="fast" forms the CWS sample as row lerps + a column lerp with the reference's float32

@@ -209,9 +209,14 @@ class FillWorkers:
         self._ready[t] = out
         return t
 
-    def collect(self, ticket):
+    def collect(self, ticket, forget_older=False):
+        """The answers of `ticket`.  forget_older: answers of earlier tickets that nobody collected (a generator abandoned with
+        batches in flight) are dropped -- for callers that collect in the order they submit."""
         if ticket not in self._ready:
             self._drain(ticket)
+        if forget_older:
+            for t in [t for t in self._ready if t < ticket]:
+                del self._ready[t]
         return self._ready.pop(ticket)
 
     def terminate(self):

@@ -553,7 +553,7 @@ class OfflinePIV:
         keep, need, host = state["keep"].copy(), state["need"], state["host"]
         if "pending" in state:
             pool, t_ = state.pop("pending")
-            state["sols"] = pool.collect(t_)
+            state["sols"] = pool.collect(t_, forget_older=True)
         if need.size:
             st = self.stats
             fu, fv = host["fu"].numpy(), host["fv"].numpy()
