@@ -65,15 +65,16 @@ def rate3(make_gen, n, trials=3):
 
 
 def main(n=128, H=2048, W=2048, batch=32, workers=0, read_threads=0, files=True, budget_s=None, precision="exact", reps=8,
-         resident_batch=64, resident_reps=32):
+         resident_batch=128, resident_reps=64):
     """Rates in pairs/s per case; `files` adds the BMP cases (skipped once `budget_s` seconds are spent).  Every case
     streams n * reps pairs (the n distinct pairs `reps` times over: 128 pairs alone last some 20 ms, which measures the
     pipeline's fill and drain, not its rate); the file cases hard-link the n pairs' files under n * reps names.  The resident
     cases stream n * resident_reps pairs: the host side is a three-stage pipeline (launch, census + triangulations handed to the
     workers, patch + hand-out), and with 64 pairs per launch 1024 pairs are 16 launches, two of them fill and drain -- round 5
-    measured 13.6 k pairs/s over 1024 pairs and 15.3 k over 2048 with the same code."""
-    # (resident frames: 64 pairs per launch -- tools/dev/e2e_batch.py, round 5: isolated spots 13.7 k pairs/s at 32, 14.2 k at 64,
-    #  13.1 k at 128; the file path is bound by the PCIe link at any batch size and keeps 32, the staging buffers' size)
+    measured 13.6 k pairs/s over 1024 pairs and 15.3 k over 2048 with the same code at 64 pairs per launch."""
+    # (resident frames: 128 pairs per launch -- round 5, 65 536 pairs streamed: isolated spots 15.6 k pairs/s at 64, 16.2 k at 128
+    #  (the passes themselves: 16.0 k / 16.6 k / 16.9 k pairs/s at 64 / 128 / 256 pairs per launch); the file path is bound by the
+    #  PCIe link at any batch size and keeps 32, the staging buffers' size)
     out = {"precision": precision, "pairs_streamed": n * reps, "resident_pairs_streamed": n * resident_reps,
            "resident_batch": resident_batch, "files_batch": batch}
     order = list(range(n)) * resident_reps
