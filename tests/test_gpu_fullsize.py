@@ -172,6 +172,41 @@ def test_large_windows_invariances():
     assert torch.equal(i0[0, 1:, 1:], i1[0, :-1, :-1])
 
 
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_64x64_cws_pass_with_every_item_on_the_list(precision):
+    """The 64x64 CWS pass runs as two launches (round 5): a fast-path-only kernel that sets aside the items with an
+    integral shift or a frame-border window, and the full kernel over the list of those.  Extremes of the list: (i)
+    byte-identical frames -- the predictor is exactly 0 everywhere, EVERY item is listed -- give a zero field to the float32
+    rounding of the second pass (1e-7 px; the first pass is exactly 0 at "exact");
+    (ii) mixed batches (identical pair, ordinary pairs) give each pair the bits it has alone, wherever it sits;
+    (iii) the ordinary pair agrees with the reference-order kernel (one launch, the per-pixel path in the same kernel)
+    to float32 rounding."""
+    from torchpiv_amd import engine, synth
+    H = W = 1024
+    a, b = synth.make_pair(H, W, 91, kind="wavy", noise=2.0, device="cuda")
+    a2, b2 = synth.make_pair(H, W, 92, kind="vortex", noise=2.0, device="cuda")
+    plan = engine.Plan(H, W, 128, 64, n_pass=2, mode="CWS", max_batch=4, precision=precision)
+    assert plan.geometry[1][0] == 64
+    u, v, inv = plan.run(torch.stack([a, a]), torch.stack([a, a]))             # (i)
+    assert float(u.abs().max()) < 1e-5 and float(v.abs().max()) < 1e-5 and int(inv.sum()) == 0
+    u_same, v_same = u[0].clone(), v[0].clone()
+    A, B = torch.stack([a, a, a2, a]), torch.stack([b, a, b2, b])               # (ii)
+    u, v, inv = plan.run(A, B)
+    assert torch.equal(u[0], u[3]) and torch.equal(v[0], v[3]) and torch.equal(inv[0], inv[3])
+    assert torch.equal(u[1], u_same) and torch.equal(v[1], v_same)
+    u1, v1, inv1 = plan.run(a2, b2)
+    assert torch.equal(u1[0], u[2]) and torch.equal(v1[0], v[2]) and torch.equal(inv1[0], inv[2])
+    ref = engine.Plan(H, W, 128, 64, n_pass=2, mode="CWS", max_batch=1, precision="reference")    # (iii)
+    ur, vr, invr = ref.run(a, b)
+    same = (inv[0] == 0) & (invr[0] == 0)
+    assert same.float().mean() > 0.9
+    d = max(float((u[0] - ur[0])[same].abs().max()), float((v[0] - vr[0])[same].abs().max()))
+    print(f"  {precision}: two-launch 64x64 CWS pass against the reference-order kernel: max |d| {d:.2e} px on {int(same.sum())} vectors")
+    assert d < 1e-3
+    plan.close()
+    ref.close()
+
+
 def test_batch_position_invariance(pair):
     """A pair gives bit-identical fields wherever it sits in a batch (windows are independent)."""
     from torchpiv_amd import engine, synth
