@@ -1,8 +1,14 @@
 // Tile kernels for 32x32 interrogation windows (see xcorr_tile.hpp).
 #include "xcorr_tile.hpp"
 namespace tpiv {
+hipError_t launch_xcorr_ws32_cws(const PassParams& p, int n_cu, hipStream_t stream);      // xcorr_ws32c.hip
 hipError_t launch_xcorr_ws32(const PassParams& p, int mode, int n_cu, hipStream_t stream) {
-    return launch_xcorr_tile_ws<32>(p, mode, n_cu, stream);
+    switch (mode) {
+        case MODE_PASS1: return launch_tile<32, MODE_PASS1>(p, n_cu, stream);
+        case MODE_DWS: return launch_tile<32, MODE_DWS>(p, n_cu, stream);
+        case MODE_CWS: return launch_xcorr_ws32_cws(p, n_cu, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 hipError_t launch_xcorr_cand_ws32(const PassParams& p, int n_cu, hipStream_t stream) {
     return launch_xcorr_tile_cand_ws<32>(p, n_cu, stream);
