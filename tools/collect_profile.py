@@ -10,6 +10,19 @@ for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(s
     shutil.copy(f, dst)
 for f in glob.glob(os.path.join(src, "other_configs", "*.txt")) + glob.glob(os.path.join(src, "other_configs", "*.csv")):
     shutil.copy(f, os.path.join(dst, "other_configs"))
+# the kernel statistics of the headline command list every kernel of the process (the synthetic frames are rendered by tens of
+# thousands of small torch kernels before the timed region): a companion file with this library's kernels only
+import csv
+for stats in glob.glob(os.path.join(dst, "rocprofv3_kernel_stats.csv")) + glob.glob(os.path.join(dst, "other_configs", "*_kernel_stats.csv")):
+    rows = list(csv.DictReader(open(stats)))
+    if rows and not stats.endswith("_tpiv.csv"):
+        keep = [r for r in rows if "tpiv::" in r["Name"]]
+        tot = sum(float(r["TotalDurationNs"]) for r in keep) or 1.0
+        with open(stats[:-4] + "_tpiv.csv", "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()) + ["PercentageOfTpivKernels"])
+            w.writeheader()
+            for r in keep:
+                w.writerow(dict(r, PercentageOfTpivKernels=f"{100.0 * float(r['TotalDurationNs']) / tot:.2f}"))
 path = os.path.join(dst, "bench_n1.json")
 r = json.loads(open(path).read().strip().splitlines()[-1])
 ks = {}
